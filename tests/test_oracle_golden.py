@@ -1,0 +1,112 @@
+"""Pin the CPU oracle (oracle/matchnerf_oracle.py) against outputs of the imported reference.
+
+The fixtures under tests/golden/ were produced by tools/gen_golden.py from /root/reference
+itself; the reference ships no tests of its own.  Tolerances: 1e-5 on rendered
+rgb/opacity, 2e-5 on depth (values up to ~4.5), 2e-4 absolute on encoder features whose
+magnitude reaches ~30 (7e-6 relative).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_case, linf, split_poses
+from matchnerf_amd import synthetic as syn
+from oracle import matchnerf_oracle as O
+
+CASES = ["c1_default", "rect_wide", "nonlegacy", "v4"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_weights_are_the_ones_the_golden_was_made_with(name):
+    g, cfg, _, _ = golden_case(name)
+    w = syn.seeded_state_dict(syn.state_dict_spec(n_src_views=cfg.n_src_views), 1)
+    h = hashlib.sha256()
+    for k, v in w.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v).tobytes())
+    assert h.hexdigest() == g["meta"]["weights_sha256"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_scene_generator_is_reproducible(name):
+    g, _, _, batch = golden_case(name)
+    scene = syn.make_scene(**g["meta"]["scene"])
+    for k in ("images", "extrinsics", "intrinsics", "near_fars"):
+        assert np.array_equal(scene[k], g[k]), k
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4"])
+def test_full_forward_matches_reference(name):
+    g, cfg, sd, batch = golden_case(name)
+    with torch.no_grad():
+        out = O.forward_test(cfg, sd, batch, chunk=4096, setbg_opaque=g["meta"]["setbg_opaque"])
+    assert linf(out["rgb"], g["rgb"]) < 1e-5
+    assert linf(out["opacity"], g["opacity"]) < 1e-5
+    assert linf(out["depth"], g["depth"]) < 2e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_encoder_and_stages_match_reference(name):
+    g, cfg, sd, batch = golden_case(name)
+    v = cfg.n_src_views
+    with torch.no_grad():
+        feats = O.encode_pairs(cfg, sd, batch["images"][0, :v])
+        ref_layout = O.pair_feats_to_view_chunks(feats, v)
+        for i in range(2):
+            if f"feat_scale{i}" in g:
+                assert linf(ref_layout[i], g[f"feat_scale{i}"]) < 2e-4
+            else:
+                assert linf(ref_layout[i][:, ::16], g[f"feat_scale{i}_sub"]) < 2e-4
+        st = O.render_rays(cfg, sd, torch.from_numpy(g["stage_rays"]), *split_poses(batch),
+                           batch["images"][0, :v], feats, g["meta"]["setbg_opaque"], return_stages=True)
+    assert linf(st["x_ref"], g["x_ref"]) < 1e-6
+    assert linf(st["dir_ref"], g["dir_ref"]) < 1e-6
+    assert linf(st["cond"], g["cond"]) < 5e-6
+    assert linf(st["rgb_samples"], g["rgb_samples"]) < 1e-5
+    assert linf(st["sigma"], g["sigma"]) < 1e-5
+    sel = g["stage_rays"]
+    assert linf(st["rgb"], g["rgb"][0, sel]) < 1e-5
+    assert linf(st["depth"], g["depth"][0, sel]) < 2e-5
+
+
+def test_backbone_matches_reference(golden):
+    g, cfg, sd, batch = golden_case("c1_default")
+    x = (batch["images"][0, :3] - O._IMAGENET_MEAN) / O._IMAGENET_STD
+    with torch.no_grad():
+        assert linf(O.backbone(sd, x), g["backbone"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_window_attention_matches_reference(golden, tag):
+    g = golden("window_attn")
+    b, h, w, c, splits = (int(x) for x in g[f"{tag}_dims"])
+    q, k, v = (torch.from_numpy(g[f"{tag}_{n}"]) for n in "qkv")
+    assert linf(O.window_attention(q, k, v, h, w, splits, False), g[f"{tag}_plain"]) < 5e-6
+    assert linf(O.window_attention(q, k, v, h, w, splits, True), g[f"{tag}_shift"]) < 5e-6
+    full = torch.softmax((q @ k.transpose(1, 2)) / c ** 0.5, -1) @ v
+    assert linf(full, g[f"{tag}_full"]) < 5e-6
+
+
+def test_chunking_does_not_change_results():
+    g, cfg, sd, batch = golden_case("nonlegacy")
+    with torch.no_grad():
+        a = O.forward_test(cfg, sd, batch, chunk=512)
+        b = O.forward_test(cfg, sd, batch, chunk=1536)
+    assert linf(a["rgb"], b["rgb"]) < 1e-6
+    assert linf(a["rgb"], g["rgb"]) < 1e-5
+
+
+def test_composite_properties():
+    cfg = O.OracleConfig()
+    gen = torch.Generator().manual_seed(0)
+    sigma = torch.rand(50, 64, generator=gen) * 0.2
+    rgb = torch.rand(50, 64, 3, generator=gen)
+    depth = torch.linspace(2, 4, 64)[None].expand(50, 64)
+    out_rgb, out_depth, op = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth)
+    assert float(op.max()) <= 1 + 1e-6 and float(op.min()) >= 0
+    # closed form: opacity = 1 - exp(-sum sigma)
+    assert linf(op[:, 0], 1 - torch.exp(-sigma.sum(1))) < 1e-5
+    bg, _, _ = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth, setbg_opaque=True)
+    assert linf(bg, out_rgb + (1 - op)) < 1e-6

@@ -1,0 +1,237 @@
+"""Generate golden fixtures from the IMPORTED reference — BUILD CONTAINER ONLY.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz, *.json
+
+The reference (/root/reference, pure Python) is imported in place through
+``tools/ref_import.py`` (in-memory stubs for absent, non-path modules), loaded with the
+build's own seeded weights (``matchnerf_amd.synthetic``) and run on seeded synthetic scenes on
+the CPU.  Only *data* is written: inputs and expected outputs (final and per stage, captured by
+wrapping the reference's own methods at run time).  No reference source is copied.
+
+Fixtures (all float32 unless noted):
+  c1_default.npz    BASELINE config[0]: 64x64, 3 views, S=64, 1024-ray chunks, test.yaml defaults
+  rect_wide.npz     64x96 images, wide baseline, IBRNet-style decoder switches + white background
+  nonlegacy.npz     legacy_coord=false, wo_render_interval=false
+  v4.npz            4 source views (6 pairs), 32 samples
+  window_attn.npz   single_head_split_window_attention in/out, shifted and not, + full attention
+  options.json      merged option trees of every shipped YAML + CLI-grammar cases
+  video_paths.npz   interpolate / spiral render paths for fixed c2w inputs
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from ref_import import import_reference, reference_options  # noqa: E402
+from matchnerf_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def weights_digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def build_reference(opt_overrides, yaml_name="test", weight_seed=1):
+    opt = reference_options(yaml_name, **opt_overrides)
+    _, RefModel, _ = import_reference()
+    model = RefModel(opt).eval()
+    spec = syn.state_dict_spec(n_src_views=opt.n_src_views, cos_n_group=tuple(opt.encoder.cos_n_group),
+                               net_width=opt.decoder.net_width, net_depth=opt.decoder.net_depth,
+                               skip=tuple(opt.decoder.skip), L_3D=opt.decoder.posenc.L_3D,
+                               L_view=opt.decoder.posenc.L_view,
+                               num_transformer_layers=opt.encoder.num_transformer_layers,
+                               upsample_factor=opt.encoder.upsample_factor)
+    assert list(spec.keys()) == list(model.state_dict().keys())
+    w = syn.seeded_state_dict(spec, weight_seed)
+    model.load_state_dict(syn.to_torch(w))
+    return opt, model, weights_digest(w)
+
+
+def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep_feats=True):
+    opt, model, digest = build_reference(opt_overrides)
+    model.nerf_setbg_opaque = setbg_opaque
+    _, _, EasyDict = import_reference()
+    scene = syn.make_scene(**scene_kw)
+    batch = EasyDict({k: torch.from_numpy(v) for k, v in scene.items()})
+    cap = {}
+
+    # --- wrap the reference's own methods to capture stage outputs (first chunk only)
+    orig_feat = model.get_img_feat
+
+    def feat_wrap(*a, **k):
+        r = orig_feat(*a, **k)
+        cap["feats"] = [x.detach().clone() for x in r]
+        return r
+
+    model.get_img_feat = feat_wrap
+    def backbone_hook(m, i, o):  # must return None (a return value would replace the output)
+        cap.setdefault("backbone", o[0].detach().clone())
+
+    hooks = [model.feat_enc.backbone.register_forward_hook(backbone_hook)]
+
+    orig_cond = model.query_cond_info
+
+    def cond_wrap(pts, *a, **k):
+        r = orig_cond(pts, *a, **k)
+        if "cond" not in cap:
+            cap["pts"] = pts.detach().clone()
+            cap["cond"] = torch.cat([r["feat_info"], r["color_info"], r["mask_info"]], -1).detach().clone()
+        return r
+
+    model.query_cond_info = cond_wrap
+    orig_dec = model.nerf_dec.forward
+
+    def dec_wrap(o, pts_ndc, ray_unit=None, cond_info=None, **k):
+        rgb, sigma = orig_dec(o, pts_ndc, ray_unit=ray_unit, cond_info=cond_info, **k)
+        if "rgb_samples" not in cap:
+            cap["x_ref"] = pts_ndc.detach().clone()
+            cap["dir_ref"] = ray_unit[:, :, 0].detach().clone()
+            cap["rgb_samples"] = rgb.detach().clone()
+            cap["sigma"] = sigma.detach().clone()
+        return rgb, sigma
+
+    model.nerf_dec.forward = dec_wrap
+    # nn.Module.__call__ resolves forward through the instance dict first, so the wrapper is used
+
+    with torch.no_grad():
+        out = model(batch, mode="test")
+    for h in hooks:
+        h.remove()
+
+    sel = np.asarray(stage_rays)
+    data = dict(
+        images=scene["images"], extrinsics=scene["extrinsics"], intrinsics=scene["intrinsics"],
+        near_fars=scene["near_fars"],
+        rgb=out.rgb.numpy(), depth=out.depth.numpy(), opacity=out.opacity.numpy(),
+        stage_rays=sel.astype(np.int64),
+        pts=cap["pts"][0, sel].numpy(), cond=cap["cond"][0, sel].numpy(),
+        x_ref=cap["x_ref"][0, sel].numpy(), dir_ref=cap["dir_ref"][0, sel].numpy(),
+        rgb_samples=cap["rgb_samples"][0, sel].numpy(), sigma=cap["sigma"][0, sel].numpy(),
+        backbone=cap["backbone"].numpy(),
+    )
+    if keep_feats:
+        for i, f in enumerate(cap["feats"]):
+            data[f"feat_scale{i}"] = f[0].numpy()  # [V,(V-1)*128,h,w] reference layout
+    else:  # keep a deterministic channel subset to bound fixture size
+        for i, f in enumerate(cap["feats"]):
+            data[f"feat_scale{i}_sub"] = f[0][:, ::16].numpy()
+    meta = dict(name=name, scene=scene_kw, opt_overrides=opt_overrides, weight_seed=1,
+                weights_sha256=digest, setbg_opaque=setbg_opaque,
+                torch=torch.__version__, numpy=np.__version__)
+    data["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"[golden] {name}: rgb mean {out.rgb.mean():.4f} opacity mean {out.opacity.mean():.4f} "
+          f"-> {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def window_attention_case():
+    import_reference()
+    from models.gmflow import transformer as T
+    g = torch.Generator().manual_seed(7)
+    data = {}
+    for tag, (b, h, w, c, splits) in dict(a=(2, 8, 12, 128, 2), b=(1, 12, 8, 128, 4)).items():
+        q, k, v = (torch.randn(b, h * w, c, generator=g) for _ in range(3))
+        q = q * 1.5
+        mask = T.generate_shift_window_attn_mask((h, w), h // splits, w // splits, h // splits // 2,
+                                                 w // splits // 2, device=torch.device("cpu"))
+        plain = T.single_head_split_window_attention(q, k, v, num_splits=splits, with_shift=False, h=h, w=w)
+        shift = T.single_head_split_window_attention(q, k, v, num_splits=splits, with_shift=True, h=h, w=w,
+                                                     attn_mask=mask)
+        full = T.single_head_full_attention(q, k, v)
+        data.update({f"{tag}_q": q.numpy(), f"{tag}_k": k.numpy(), f"{tag}_v": v.numpy(),
+                     f"{tag}_plain": plain.numpy(), f"{tag}_shift": shift.numpy(), f"{tag}_full": full.numpy(),
+                     f"{tag}_dims": np.array([b, h, w, c, splits])})
+    np.savez_compressed(os.path.join(OUT, "window_attn.npz"), **data)
+    print("[golden] window_attn")
+
+
+def options_case():
+    ref_options, _, _ = import_reference()
+    from misc.utils import to_dict
+    trees = {}
+    for y in ("base", "test", "train", "train_ibrnet", "demo_own", "test_video", "test_video_own", "test_tnt"):
+        trees[y] = to_dict(ref_options.load_options(f"configs/{y}.yaml"))
+    cli = {}
+    cases = {
+        "basic": ["--yaml=test", "--name=run1", "--nerf.rand_rays_test=4096", "--nerf.sample_intvs=64"],
+        "flags": ["--yaml=test", "--tb", "--vis_depth!", "--load="],
+        "lists": ["--yaml=test", "--gpu_ids=0,1,", "--encoder.cos_n_group=2,8", "--data_test.dtu.scene_list=a,b"],
+        "types": ["--yaml=train", "--optim.lr_enc=1.e-5", "--max_epoch=3", "--name=abc_debug", "--seed=3"],
+    }
+    for k, argv in cases.items():
+        cli[k] = dict(argv=argv, parsed=to_dict(ref_options.parse_arguments(argv)))
+    with open(os.path.join(OUT, "options.json"), "w") as f:
+        json.dump(dict(yaml_trees=trees, cli=cli), f, indent=1, sort_keys=True)
+    print("[golden] options")
+
+
+def video_paths_case():
+    import_reference()
+    from misc import camera
+    rng = np.random.default_rng(3)
+    from scipy.spatial.transform import Rotation
+    c2ws = []
+    for i in range(3):
+        r = Rotation.from_euler("xyz", rng.normal(0, 0.2, 3)).as_matrix()
+        t = rng.normal(0, 0.5, 3)
+        c2ws.append(np.concatenate([r, t[:, None]], 1))
+    c2ws = np.stack(c2ws, 0).astype(np.float32)
+    interp = np.asarray(camera.get_interpolate_render_path(c2ws, 8))
+    spiral = np.asarray(camera.get_spiral_render_path(c2ws, [2.0, 6.0], rads_scale=0.3, N_views=8))
+    np.savez_compressed(os.path.join(OUT, "video_paths.npz"), c2ws=c2ws, interpolate=interp, spiral=spiral)
+    print("[golden] video_paths", interp.shape, spiral.shape)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+
+    def want(n):
+        return not only or n in only
+
+    if want("c1_default"):
+        run_case("c1_default", dict(height=64, width=64, n_src_views=3, seed=0),
+                 {"nerf.sample_intvs": 64, "nerf.rand_rays_test": 1024},
+                 stage_rays=list(range(0, 1024, 8)))
+    if want("rect_wide"):
+        run_case("rect_wide", dict(height=64, width=96, n_src_views=3, seed=5, wide=True, focal_scale=1.389,
+                                   near_far=(2.0, 6.0)),
+                 {"nerf.sample_intvs": 64, "nerf.rand_rays_test": 2048, "decoder.density_maskfill": True,
+                  "decoder.raytrans_posenc": True, "decoder.raytrans_act": "ELU",
+                  "encoder.attn_splits_list": [4]},
+                 stage_rays=list(range(0, 2048, 32)), setbg_opaque=True, keep_feats=False)
+    if want("nonlegacy"):
+        run_case("nonlegacy", dict(height=32, width=48, n_src_views=3, seed=6),
+                 {"nerf.sample_intvs": 32, "nerf.rand_rays_test": 1536, "nerf.legacy_coord": False,
+                  "nerf.wo_render_interval": False},
+                 stage_rays=list(range(0, 1536, 24)), keep_feats=False)
+    if want("v4"):
+        run_case("v4", dict(height=32, width=32, n_src_views=4, seed=7),
+                 {"nerf.sample_intvs": 32, "nerf.rand_rays_test": 1024, "n_src_views": 4},
+                 stage_rays=list(range(0, 1024, 16)), keep_feats=False)
+    if want("window_attn"):
+        window_attention_case()
+    if want("options"):
+        options_case()
+    if want("video_paths"):
+        video_paths_case()
+
+
+if __name__ == "__main__":
+    main()
