@@ -1,0 +1,166 @@
+/*
+ * mnerf.h — C ABI of libmnerf_hip.so: the MI355X (gfx950) kernels of the MatchNeRF per-ray
+ * rendering hot path.
+ *
+ * The reference (donydchen/matchnerf) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md §8b): the seam is the Python class `MatchNeRF` (models/matchnerf.py:13-325).
+ * This header is the boundary the build introduces *beneath* that class.  Each entry point
+ * replaces one chain of eager PyTorch ops in the reference (file:line given per function).
+ * The Python host (matchnerf_amd/hip.py) binds it with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes, no torch / C++ types in any signature;
+ *   - all tensors are fp32, row-major, contiguous unless a stride is given;
+ *   - the caller allocates every buffer (inputs, outputs, scratch); functions only enqueue
+ *     work on `stream` (a hipStream_t passed as void*; NULL = default stream): no
+ *     allocation, no synchronisation => safe inside hipGraph capture;
+ *   - small camera matrices travel BY VALUE inside the argument structs (kernel arguments),
+ *     so no host->device copy is hidden in a call;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     MNERF_E_* argument-check code.  Nothing throws across the ABI.  The message of the
+ *     last failure on the calling thread is available from mnerf_last_error().
+ */
+#ifndef MNERF_H_
+#define MNERF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNERF_ABI_VERSION 1
+#define MNERF_MAX_VIEWS 16
+#define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
+
+enum {
+  MNERF_OK = 0,
+  MNERF_E_NULL = -1,        /* required pointer is NULL                         */
+  MNERF_E_RANGE = -2,       /* a size / count is out of the supported range     */
+  MNERF_E_UNSUPPORTED = -3, /* valid in the reference, not built in this kernel */
+  MNERF_E_ALIGN = -4        /* pointer not aligned as required (16 B)           */
+};
+
+/* One source view (models/matchnerf.py:75-86 `ref_poses`). */
+typedef struct mnerf_view {
+  float extr[12]; /* world->camera [R|t], row-major 3x4  (batch.extrinsics[:, v, :3, :]) */
+  float intr[9];  /* 3x3 intrinsics                       (batch.intrinsics[:, v])        */
+  float near_, far_;
+} mnerf_view;
+
+/* The rays of one chunk of one target view.
+ * Replaces camera.get_center_and_ray + sample_depth + get_3D_points_from_depth, which the
+ * reference evaluates for the FULL image on every chunk (models/matchnerf.py:104-115,
+ * misc/camera.py:255-286): here each ray is rebuilt in-kernel from the pixel index. */
+typedef struct mnerf_rays {
+  int32_t n_rays;         /* rays in this chunk                                               */
+  int32_t n_samples;      /* S = opt.nerf.sample_intvs                                        */
+  int32_t ray_begin;      /* first pixel index (row-major y*W+x) when ray_idx == NULL          */
+  int32_t legacy_coord;   /* opt.nerf.legacy_coord: integer pixel centres, i/(S-1) depths      */
+  int32_t depth_inverse;  /* opt.nerf.depth.param == "inverse"                                 */
+  int32_t height, width;  /* image size of the views                                          */
+  const int32_t* ray_idx; /* device, [n_rays] pixel indices (train / test-optim), or NULL      */
+  const float* strat_u;   /* device, [n_rays, S] U[0,1) offsets (stratified train), or NULL    */
+  float kinv[9];          /* inverse target intrinsics, fp32 (camera.py:221-222)              */
+  float c2w[12];          /* target camera->world 3x4 (legacy: fp64 inverse cast to fp32,      */
+                          /* camera.py:231-240; else [R^T | -R^T t], camera.py:36-42)          */
+  float near_, far_;      /* target near / far (batch.near_fars[:, -1])                       */
+} mnerf_rays;
+
+/* Source-view data resident in HBM.  Feature maps are PAIR-MAJOR and CHANNEL-LAST:
+ *   feat[s] : [n_pairs][2][fh[s]][fw[s]][128] fp32,  pair p=(a,b), a<b lexicographic,
+ *             side 0 = feature of view a, side 1 = feature of view b after the GMFlow
+ *             transformer ran on (a,b)  (models/gmflow/gmflow.py:47-67).
+ * The reference keeps them as per-view channel chunks [V,(V-1)*128,h,w] (matchnerf.py:192-205)
+ * and pairs chunk j of view i with chunk i of view j+1 (matchnerf.py:260-268) — the same data.
+ *   images  : [n_views][H][W][4] fp32, RGB in [0,1] + one pad float (16-byte texels). */
+typedef struct mnerf_scene {
+  int32_t n_views;
+  int32_t n_scales;       /* 2: raw 1/8 features + up-sampled 1/4 features                    */
+  int32_t fh[2], fw[2];
+  int32_t n_group[2];     /* opt.encoder.cos_n_group, each in {1,2,4,8}                        */
+  const float* feat[2];
+  const float* images;
+  mnerf_view views[MNERF_MAX_VIEWS];
+} mnerf_scene;
+
+/* Decoder parameters, pre-packed by the host (matchnerf_amd/cond_nerf.py:pack_decoder):
+ *   wstream : MFMA A-operand fragments of every Linear of CondNeRF in consumption order
+ *             (layout in DESIGN.md §Decoder weight stream); 16-byte aligned
+ *   small   : ray-transformer + density-head parameters (fp32, layout in DESIGN.md)
+ * Architecture switches mirror opt.decoder.* / opt.nerf.* (configs/base.yaml:29-48). */
+typedef struct mnerf_decoder {
+  const float* wstream;
+  int64_t wstream_floats;
+  const float* small_;
+  int32_t n_views;         /* V = opt.n_src_views                                               */
+  int32_t cond_dim;        /* sum(cos_n_group) + 4*V (cond_nerf.py:18)                          */
+  int32_t cond_stride;     /* floats per sample in `cond` buffers: multiple of 8, > cond_dim, <=64 */
+  int32_t L_3D;            /* opt.decoder.posenc.L_3D (L_view must be 0)                        */
+  int32_t raytrans_posenc; /* opt.decoder.raytrans_posenc                                       */
+  int32_t raytrans_elu;    /* opt.decoder.raytrans_act == "ELU" (else ReLU)                     */
+  int32_t density_maskfill;/* opt.decoder.density_maskfill                                      */
+  int32_t wo_render_interval; /* opt.nerf.wo_render_interval                                    */
+  int32_t setbg_opaque;    /* MatchNeRF.nerf_setbg_opaque                                       */
+} mnerf_decoder;
+
+int mnerf_abi_version(void);
+const char* mnerf_last_error(void);
+
+/* a8-a10 — target rays, depth samples, world points and their (u,v,z) in one source view.
+ * Replaces camera.get_center_and_ray (misc/camera.py:255-278), MatchNeRF.sample_depth
+ * (models/matchnerf.py:163-181), get_3D_points_from_depth (camera.py:281-286) and
+ * get_coord_ref_ndc (camera.py:351-379).  Any of pts [R,S,3], ndc [R,S,3], depth [R,S] may be
+ * NULL.  Bit-exact against the reference's CPU path (same k-ordered FMA chains). */
+int mnerf_ray_samples(const mnerf_rays* rays, const mnerf_view* view, float* pts, float* ndc,
+                      float* depth, void* stream);
+
+/* K5 — volume-rendering quadrature.  Replaces NeRF.composite
+ * (models/rfdecoder/nerf.py:101-124).  rgb_s [R,S,3], sigma [R,S], depth_s [R,S],
+ * ray_len [R] (|ray|, only read when wo_render_interval == 0; may be NULL otherwise)
+ * -> rgb [R,3], depth [R], opacity [R]. */
+int mnerf_composite(int32_t n_rays, int32_t n_samples, const float* rgb_s, const float* sigma,
+                    const float* depth_s, const float* ray_len, int32_t wo_render_interval,
+                    int32_t setbg_opaque, float* rgb, float* depth, float* opacity, void* stream);
+
+/* K1+K2 — epipolar feature sampling + group-cosine cost volume + colours + visibility mask.
+ * Replaces MatchNeRF.query_cond_info (models/matchnerf.py:209-293), sample_features_by_grid
+ * (models/gmflow/utils.py:131-134) and get_coord_ref_ndc (misc/camera.py:351-379).
+ * cond [n_rays*S, cond_stride]: [cos@scale0 | cos@scale1 | rgb_v0.. | mask_v0.. | 1.0 | 0 pad]
+ * (the order CondNeRF concatenates them in, cond_nerf.py:59; the trailing 1.0 feeds the
+ * bias column of the packed FiLM layer). */
+int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
+                      float* cond, void* stream);
+
+/* K3+K4+K5 — conditional radiance MLP, per-ray transformer and compositing for one chunk.
+ * Replaces CondNeRF.forward (models/rfdecoder/cond_nerf.py:52-100), MultiHeadAttention
+ * (ray_transformer.py:29-79), the ref-view-0 NDC warp and view-direction rotation
+ * (models/matchnerf.py:118-132) and NeRF.composite (nerf.py:101-124).
+ * view0 = source view 0 (coordinate reference).  cond as produced by mnerf_cost_volume.
+ * Outputs rgb [R,3], depth [R], opacity [R]; dbg_rgb_s [R,S,3] / dbg_sigma [R,S] receive the
+ * per-sample decoder outputs when non-NULL (parity tests). */
+int64_t mnerf_decoder_wstream_floats(int32_t cond_stride, int32_t L_3D); /* expected wstream size */
+int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0, const mnerf_rays* rays,
+                        const float* cond, float* rgb, float* depth, float* opacity,
+                        float* dbg_rgb_s, float* dbg_sigma, void* stream);
+
+/* a7 — one full render chunk = cost volume + decoder + compositing
+ * (MatchNeRF.render, models/matchnerf.py:88-143).  `workspace` must hold
+ * mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride) bytes. */
+int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_samples, int32_t cond_stride);
+int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,
+                       void* workspace, float* rgb, float* depth, float* opacity, void* stream);
+
+/* K6 — GMFlow single-head (shifted-)window attention, flash style (no score matrix).
+ * Replaces single_head_split_window_attention / single_head_full_attention and the
+ * shift-mask tensor (models/gmflow/transformer.py:8-16, 19-43, 46-105).
+ * q,k,v,out [batch, h*w, 128]; num_splits >= 1 (1 = full attention); `shifted` applies the
+ * swin roll by half a window with wrap-region masking (-100 added across regions). */
+int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
+                           int32_t batch, int32_t h, int32_t w, int32_t num_splits,
+                           int32_t shifted, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNERF_H_ */

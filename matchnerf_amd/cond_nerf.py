@@ -1,0 +1,291 @@
+"""CondNeRF — the conditional radiance-field decoder of MatchNeRF, MI355X-native.
+
+Host-side mirror of /root/reference/models/rfdecoder/cond_nerf.py:8-50 (+ nerf.py,
+ray_transformer.py): the module owns the same parameters under the same ``state_dict`` keys
+(binding for checkpoint drop-in), but it does not evaluate them with
+torch ops.  ``pack_decoder`` re-lays the weights out as the MFMA A-fragment stream consumed by
+the fused HIP kernel (csrc/decoder.hip) and the evaluation itself happens in
+``libmnerf_hip.so`` (``mnerf_decoder_chunk`` / ``mnerf_render_chunk``).
+
+Weight-stream layout (also DESIGN.md §Decoder weight stream)
+------------------------------------------------------------
+Every Linear ``y = W x + b`` is evaluated transposed with ``v_mfma_f32_32x32x2_f32``:
+for K-step ``t`` and output block ``m`` the wave needs one float per lane,
+``A[t][lane][m] = W[m*32 + (lane & 31)][col(t, lane >> 5)]`` where ``col(t, half)`` is the
+input feature the lower / upper half-wave feeds at that step:
+
+* hidden activations arrive in accumulator-register order: step ``t = 16*mb + r`` pairs
+  features ``32*mb + (r & 3) + 8*(r >> 2)`` (lower half) and that ``+ 4`` (upper half);
+* positional encoding: step ``t = 3*l + c`` pairs ``sin(2^l x_c)`` and ``cos(2^l x_c)``;
+  the two trailing steps carry ``(x | y)`` and ``(z | 1)``;
+* conditioning vector: step ``t`` pairs ``cond[t]`` and ``cond[stride/2 + t]``;
+* a bias is one more column multiplied by the constant 1 operand.
+
+Stages in consumption order (steps x output blocks):
+FiLM(stride/2 x4) L0(3L+2 x4) L1..L4(65 x4) L5-enc(3L+2 x4) L5-h(64 x4) alpha(65 x1)
+feature(65 x4) views(66 x2) rgb(33 x1); each stage is cut into segments of at most 33 KiB,
+each segment padded to a multiple of 256 floats (1 KiB DMA pieces).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+SEG_CAP_FLOATS = 33 * 256
+SMALL_FIXED = 1360
+
+
+# ----------------------------------------------------------------------------- schedule
+
+
+def decoder_stages(cond_stride, L_3D):
+    fs, es = cond_stride // 2, 3 * L_3D + 2
+    names = ["film", "l0", "l1", "l2", "l3", "l4", "l5e", "l5h", "alpha", "feature", "views", "rgb"]
+    steps = [fs, es, 65, 65, 65, 65, es, 64, 65, 65, 66, 33]
+    nmb = [4, 4, 4, 4, 4, 4, 4, 4, 1, 4, 2, 1]
+    return list(zip(names, steps, nmb))
+
+
+def decoder_schedule(cond_stride, L_3D):
+    """Mirror of build_schedule() in csrc/decoder.hip -> (segments, total_floats);
+    segment = (stage, first_step, n_steps, nmb, float_offset, padded_floats)."""
+    segs, off = [], 0
+    for name, t, m in decoder_stages(cond_stride, L_3D):
+        cap = SEG_CAP_FLOATS // (64 * m)
+        nseg = (t + cap - 1) // cap
+        base = t // nseg
+        first = 0
+        for k in range(nseg):
+            steps = t - base * (nseg - 1) if k == nseg - 1 else base
+            fl = ((steps * 64 * m + 255) // 256) * 256
+            assert fl <= SEG_CAP_FLOATS
+            segs.append((name, first, steps, m, off, fl))
+            off += fl
+            first += steps
+    return segs, off
+
+
+# ----------------------------------------------------------------------------- column maps
+
+BIAS, ZERO = -1, -2
+
+
+def _reg_order(n_blocks):
+    """input feature fed by (lower, upper) half-wave at step t when the operand is a previous
+    layer's accumulator (C/D layout of v_mfma_f32_32x32x2_f32)."""
+    lo, hi = [], []
+    for mb in range(n_blocks):
+        for r in range(16):
+            f = 32 * mb + (r & 3) + 8 * (r >> 2)
+            lo.append(f)
+            hi.append(f + 4)
+    return lo, hi
+
+
+def _enc_cols(L, legacy, base=0):
+    """columns of the positional-encoding part of a weight matrix per step.
+    legacy layout  [x(3) | sin(l-major,c) (3L) | cos (3L)]      (cond_nerf.py:108-116)
+    regular layout [x(3) | per c: sin(l=0..L-1), cos(l=0..L-1)] (nerf.py:126-133)"""
+    lo, hi = [], []
+    for t in range(3 * L):
+        l, c = divmod(t, 3)
+        if legacy:
+            lo.append(base + 3 + t)
+            hi.append(base + 3 + 3 * L + t)
+        else:
+            lo.append(base + 3 + c * 2 * L + l)
+            hi.append(base + 3 + c * 2 * L + L + l)
+    lo += [base + 0, base + 2]
+    hi += [base + 1, BIAS]
+    return lo, hi
+
+
+def _fragments(weight, bias, lo, hi, nmb):
+    """A[t, lane, m] for one stage (numpy float32 [T, 64, nmb])."""
+    n_out, n_in = weight.shape
+    rows = nmb * 32
+    ext = np.zeros((rows, n_in + 2), np.float32)
+    ext[:n_out, :n_in] = weight
+    if bias is not None:
+        ext[:n_out, n_in] = bias
+    lo = np.asarray([n_in if c == BIAS else (n_in + 1 if c == ZERO else c) for c in lo])
+    hi = np.asarray([n_in if c == BIAS else (n_in + 1 if c == ZERO else c) for c in hi])
+    t_n = len(lo)
+    lane = np.arange(64)
+    col = np.where((lane >> 5)[None, :] == 0, lo[:, None], hi[:, None])          # [T,64]
+    row = (lane & 31)[None, :, None] + 32 * np.arange(nmb)[None, None, :]         # [1,64,nmb]
+    return ext[np.broadcast_to(row, (t_n, 64, nmb)), np.broadcast_to(col[:, :, None], (t_n, 64, nmb))]
+
+
+def pack_wstream(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_dec."):
+    """state_dict (numpy or torch, reference keys) -> (wstream float32 [total], cond_dim, cond_stride)."""
+
+    def g(name):
+        v = sd[prefix + name]
+        return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+    cond_dim = int(sum(cos_n_group)) + 4 * n_views
+    cond_stride = ((cond_dim + 1 + 7) // 8) * 8
+    fs = cond_stride // 2
+    d_enc = 3 + 6 * L_3D
+    h_lo, h_hi = _reg_order(4)
+    e_lo, e_hi = _enc_cols(L_3D, legacy)
+    film_lo = [t if t < cond_dim else (BIAS if t == cond_dim else ZERO) for t in range(fs)]
+    film_hi = [fs + t if fs + t < cond_dim else (BIAS if fs + t == cond_dim else ZERO) for t in range(fs)]
+    w5 = g("pts_linears.5.weight")
+    assert w5.shape[1] == d_enc + 128, "decoder.skip must be [4] with net_width 128"
+    hv_lo, hv_hi = _reg_order(2)
+    frags = {
+        "film": _fragments(g("pts_bias.weight"), g("pts_bias.bias"), film_lo, film_hi, 4),
+        "l0": _fragments(g("pts_linears.0.weight"), g("pts_linears.0.bias"), e_lo, e_hi, 4),
+        "l5e": _fragments(w5[:, :d_enc], g("pts_linears.5.bias"), e_lo, e_hi, 4),
+        "l5h": _fragments(w5[:, d_enc:], None, h_lo, h_hi, 4),
+        "alpha": _fragments(g("alpha_linear.0.weight"), g("alpha_linear.0.bias"), h_lo + [BIAS], h_hi + [ZERO], 1),
+        "feature": _fragments(g("feature_linear.weight"), g("feature_linear.bias"), h_lo + [BIAS], h_hi + [ZERO], 4),
+        "views": _fragments(g("views_linears.0.weight"), g("views_linears.0.bias"),
+                            h_lo + [128, 130], h_hi + [129, BIAS], 2),
+        "rgb": _fragments(g("rgb_linear.weight"), g("rgb_linear.bias"), hv_lo + [BIAS], hv_hi + [ZERO], 1),
+    }
+    for i in range(1, 5):
+        frags[f"l{i}"] = _fragments(g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias"),
+                                    h_lo + [BIAS], h_hi + [ZERO], 4)
+    segs, total = decoder_schedule(cond_stride, L_3D)
+    out = np.zeros(total, np.float32)
+    for name, first, steps, m, off, _ in segs:
+        a = frags[name][first:first + steps]
+        assert a.shape == (steps, 64, m), (name, a.shape, steps, m)
+        out[off:off + a.size] = a.reshape(-1)
+    return out, cond_dim, cond_stride
+
+
+def raytrans_table(n_samples, d_hid=16):
+    """Sinusoid table of the ray transformer, float64 -> float32 as the reference builds it
+    (cond_nerf.py:118-127)."""
+    pos = np.arange(n_samples, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    tab = pos / np.power(10000, 2 * (j // 2) / d_hid)
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return tab.astype(np.float32)
+
+
+def pack_small(sd, n_samples, raytrans_posenc, prefix="nerf_dec."):
+    """Ray-transformer + density-head parameters:
+    [0:256) w_qs  [256:512) w_ks  [512:768) w_vs  [768:1024) fc   (row-major [out][in])
+    [1024:1040) ln.weight [1040:1056) ln.bias [1056:1312) out_alpha.0.weight [1312:1328) .0.bias
+    [1328:1344) out_alpha.2.weight [1344] .2.bias, zero pad to 1360, then the [S,16] posenc table."""
+
+    def g(name):
+        v = sd[prefix + name]
+        return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32).reshape(-1)
+
+    out = np.zeros(SMALL_FIXED + (n_samples * 16 if raytrans_posenc else 0), np.float32)
+    out[0:256] = g("ray_attention.w_qs.weight")
+    out[256:512] = g("ray_attention.w_ks.weight")
+    out[512:768] = g("ray_attention.w_vs.weight")
+    out[768:1024] = g("ray_attention.fc.weight")
+    out[1024:1040] = g("ray_attention.layer_norm.weight")
+    out[1040:1056] = g("ray_attention.layer_norm.bias")
+    out[1056:1312] = g("out_alpha_linear.0.weight")
+    out[1312:1328] = g("out_alpha_linear.0.bias")
+    out[1328:1344] = g("out_alpha_linear.2.weight")
+    out[1344] = g("out_alpha_linear.2.bias")[0]
+    if raytrans_posenc:
+        out[SMALL_FIXED:] = raytrans_table(n_samples).reshape(-1)
+    return out
+
+
+# ----------------------------------------------------------------------------- module
+
+
+class _RayAttentionParams(nn.Module):
+    """Parameter holder with the keys of MultiHeadAttention(4, 16, 4, 4)
+    (ray_transformer.py:32-47); evaluated inside csrc/decoder.hip."""
+
+    def __init__(self):
+        super().__init__()
+        self.w_qs = nn.Linear(16, 16, bias=False)
+        self.w_ks = nn.Linear(16, 16, bias=False)
+        self.w_vs = nn.Linear(16, 16, bias=False)
+        self.fc = nn.Linear(16, 16, bias=False)
+        self.layer_norm = nn.LayerNorm(16, eps=1e-6)
+
+
+class CondNeRF(nn.Module):
+    """Same constructor contract and parameter names as the reference's CondNeRF
+    (cond_nerf.py:11-50).  ``forward`` is not an eager op chain here: use
+    ``MatchNeRF.render`` (fused HIP path).  ``composite`` keeps the reference signature
+    (nerf.py:101) and runs the K5 HIP kernel."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        dec, nerf = opt.decoder, opt.nerf
+        W, D = dec.net_width, dec.net_depth
+        skip = list(dec.skip)
+        if not nerf.view_dep:
+            raise NotImplementedError("nerf.view_dep=false is unusable in the reference as well "
+                                      "(cond_nerf.py:47-50 references views_linears unconditionally)")
+        if W != 128 or D != 6 or skip != [4]:
+            raise NotImplementedError(
+                f"fused decoder kernel is built for net_width=128, net_depth=6, skip=[4] "
+                f"(configs/base.yaml:30-32); got {W}, {D}, {skip}")
+        L_3D = dec.posenc.L_3D if dec.posenc else 0
+        L_view = dec.posenc.L_view if dec.posenc else 0
+        if L_view != 0:
+            raise NotImplementedError("decoder.posenc.L_view > 0 is not built (base.yaml:35 uses 0)")
+        if dec.raytrans_act not in ("ReLU", "ELU"):
+            raise NotImplementedError(f"decoder.raytrans_act={dec.raytrans_act}")
+        self.L_3D = L_3D
+        d3 = 3 + 6 * L_3D
+        self.cond_dim = int(sum(opt.encoder.cos_n_group)) + opt.n_src_views * 4
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(d3, W)] + [nn.Linear(W + d3, W) if i in skip else nn.Linear(W, W) for i in range(D - 1)])
+        self.pts_bias = nn.Linear(self.cond_dim, W)
+        act = getattr(nn, dec.raytrans_act)
+        self.views_linears = nn.ModuleList([nn.Linear(3 + W, W // 2)])
+        self.alpha_linear = nn.Sequential(nn.Linear(W, 16), act())
+        self.ray_attention = _RayAttentionParams()
+        self.out_alpha_linear = nn.Sequential(nn.Linear(16, 16), act(), nn.Linear(16, 1), nn.ReLU())
+        self.feature_linear = nn.Linear(W, W)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        for m in [*self.pts_linears, *self.views_linears, self.feature_linear, self.alpha_linear[0], self.rgb_linear]:
+            nn.init.kaiming_normal_(m.weight.data)   # cond_nerf.py:102-106
+            nn.init.zeros_(m.bias.data)
+        self._packed = None  # (key, wstream, small)
+
+    # -- packing cache -----------------------------------------------------------------
+    def _pack_key(self, n_samples):
+        ver = tuple(int(p._version) for p in self.parameters())
+        ptr = tuple(int(p.data_ptr()) for p in self.parameters())
+        return (ver, ptr, n_samples, bool(self.opt.decoder.raytrans_posenc), bool(self.opt.nerf.legacy_coord))
+
+    def packed(self, n_samples, device):
+        """(wstream, small, cond_stride) device tensors for the HIP kernel; re-packed when any
+        parameter changed (load_state_dict / optimizer step) or S changed."""
+        key = self._pack_key(n_samples)
+        if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
+            sd = {"nerf_dec." + k: v for k, v in self.state_dict().items()}
+            ws, cond_dim, cond_stride = pack_wstream(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
+                                                     self.L_3D, bool(self.opt.nerf.legacy_coord))
+            assert cond_dim == self.cond_dim
+            small = pack_small(sd, n_samples, bool(self.opt.decoder.raytrans_posenc))
+            self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride)
+        return self._packed[1], self._packed[2], self._packed[3]
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            "CondNeRF is evaluated by the fused HIP ray-chunk kernel (mnerf_render_chunk); "
+            "call MatchNeRF.render / MatchNeRF.forward instead of CondNeRF.forward")
+
+    def composite(self, opt, ray, rgb_samples, density_samples, depth_samples, setbg_opaque):
+        """nerf.py:101-124 with the reference signature; tensors [B,R,S,*] on the GPU."""
+        from . import hip
+        b, r, s = density_samples.shape
+        ray_len = None if opt.nerf.wo_render_interval else ray.norm(dim=-1).reshape(b * r).contiguous()
+        rgb, depth, opacity = hip.composite(
+            rgb_samples.reshape(b * r, s, 3).contiguous(), density_samples.reshape(b * r, s).contiguous(),
+            depth_samples.reshape(b * r, s).contiguous(), ray_len,
+            wo_render_interval=bool(opt.nerf.wo_render_interval), setbg_opaque=bool(setbg_opaque))
+        return rgb.reshape(b, r, 3), depth.reshape(b, r, 1), opacity.reshape(b, r, 1), None

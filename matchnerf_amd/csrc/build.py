@@ -1,0 +1,51 @@
+"""Build libmnerf_hip.so (gfx950) in-tree:  python -m matchnerf_amd.csrc.build
+
+hipcc cross-compiles without a GPU.  The .so lands next to the package
+(matchnerf_amd/libmnerf_hip.so): git-ignored, but it travels to the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libmnerf_hip.so")
+SOURCES = ["api.cpp", "composite.hip", "cost_volume.hip", "decoder.hip", "geometry.hip", "render_chunk.hip",
+           "window_attention.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    deps = [os.path.join(HERE, "common.hpp"), os.path.join(PKG, "..", "include", "mnerf.h")]
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(HERE, src)
+        if not os.path.exists(sp):
+            raise FileNotFoundError(sp)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if force or _newer(sp, obj) or any(_newer(d, obj) for d in deps):
+            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or any(_newer(o, OUT) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

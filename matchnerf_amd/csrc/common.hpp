@@ -1,0 +1,114 @@
+// Shared host/device helpers for libmnerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mnerf.h"
+
+// ------------------------------------------------------------------ host: error channel
+void mnerf_set_error(const char* fmt, ...);
+
+#define MNERF_REQUIRE(cond, code, ...)   \
+  do {                                   \
+    if (!(cond)) {                       \
+      mnerf_set_error(__VA_ARGS__);      \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+static inline int mnerf_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mnerf_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return MNERF_OK;
+}
+
+static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ------------------------------------------------------------------ device: geometry
+// The positional encoding multiplies the projected coordinate by up to 2^9 (x pi), so a
+// 1-ulp difference in (u,v,z) becomes a 1e-4-class difference in sin/cos and, through random
+// MLP weights, in RGB.  The reference's small matmuls ([N,4]@[4,3], [N,3]@[3,3]) evaluate on
+// the CPU as a k-ordered FMA chain  acc = x0*w0; acc = fma(xk, wk, acc)  and its elementwise
+// expressions round every op separately; tools/gen_golden.py fixtures confirm that this order
+// reproduces the reference's `pts` and NDC coordinates BIT-FOR-BIT.  So the device code pins
+// exactly that order: contraction is switched off in this block and every FMA is explicit.
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float dot3_chain(float x0, float x1, float x2, const float* w) {
+  return __builtin_fmaf(x2, w[2], __builtin_fmaf(x1, w[1], x0 * w[0]));
+}
+// [x0 x1 x2 1] . w[0..3]
+__device__ __forceinline__ float dot4h_chain(float x0, float x1, float x2, const float* w) {
+  return __builtin_fmaf(x2, w[2], __builtin_fmaf(x1, w[1], x0 * w[0])) + w[3];
+}
+
+// One target ray rebuilt from its pixel index (misc/camera.py:255-278).
+struct RayGeom {
+  float cx, cy, cz;  // centre (camera position in world)
+  float rx, ry, rz;  // un-normalised direction
+};
+
+__device__ __forceinline__ RayGeom make_ray(const mnerf_rays& R, int ray_local) {
+  int pix = R.ray_idx ? R.ray_idx[ray_local] : (R.ray_begin + ray_local);
+  int py = pix / R.width;
+  int px = pix - py * R.width;
+  float off = R.legacy_coord ? 0.0f : 0.5f;
+  float x = (float)px + off, y = (float)py + off;
+  // cam = [x y 1] @ Kinv^T   (img2cam, camera.py:221-222)
+  float c0 = __builtin_fmaf(y, R.kinv[1], x * R.kinv[0]) + R.kinv[2];
+  float c1 = __builtin_fmaf(y, R.kinv[4], x * R.kinv[3]) + R.kinv[5];
+  float c2 = __builtin_fmaf(y, R.kinv[7], x * R.kinv[6]) + R.kinv[8];
+  RayGeom g;
+  g.cx = R.c2w[3];
+  g.cy = R.c2w[7];
+  g.cz = R.c2w[11];
+  // ray = ([cam 1] @ c2w^T) - centre   (camera.py:273-276)
+  g.rx = dot4h_chain(c0, c1, c2, R.c2w + 0) - g.cx;
+  g.ry = dot4h_chain(c0, c1, c2, R.c2w + 4) - g.cy;
+  g.rz = dot4h_chain(c0, c1, c2, R.c2w + 8) - g.cz;
+  return g;
+}
+
+// depth of sample j on a ray (models/matchnerf.py:163-181); every op rounded on its own
+__device__ __forceinline__ float sample_depth(const mnerf_rays& R, int ray_local, int j) {
+  float shift = R.legacy_coord ? 0.0f : 0.5f;
+  if (R.strat_u) shift = R.strat_u[(size_t)ray_local * R.n_samples + j];
+  float denom = R.legacy_coord ? (float)(R.n_samples - 1) : (float)R.n_samples;
+  float t = ((float)j + shift) / denom;
+  float span = R.far_ - R.near_;
+  float d = t * span;
+  d = d + R.near_;
+  if (R.depth_inverse) d = 1.0f / (d + 1e-8f);
+  return d;
+}
+
+// x = c + d v  (camera.py:281-286): multiply and add are separate torch ops
+__device__ __forceinline__ void ray_point(const RayGeom& g, float d, float& px, float& py, float& pz) {
+  float tx = g.rx * d, ty = g.ry * d, tz = g.rz * d;
+  px = g.cx + tx;
+  py = g.cy + ty;
+  pz = g.cz + tz;
+}
+
+// world point -> (u, v, z) of a source view (misc/camera.py:351-379)
+__device__ __forceinline__ void project(const mnerf_view& V, float px, float py, float pz,
+                                        float wm1, float hm1, float& u, float& v,
+                                        float& z) {
+  float c0 = dot4h_chain(px, py, pz, V.extr + 0);
+  float c1 = dot4h_chain(px, py, pz, V.extr + 4);
+  float c2 = dot4h_chain(px, py, pz, V.extr + 8);
+  float q0 = dot3_chain(c0, c1, c2, V.intr + 0);
+  float q1 = dot3_chain(c0, c1, c2, V.intr + 3);
+  float q2 = dot3_chain(c0, c1, c2, V.intr + 6);
+  u = q0 / q2;
+  u = u / wm1;
+  v = q1 / q2;
+  v = v / hm1;
+  float span = V.far_ - V.near_;
+  z = (q2 - V.near_) / span;
+}
+#pragma clang fp contract(fast)

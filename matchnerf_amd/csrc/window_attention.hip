@@ -1,0 +1,209 @@
+// K6 — GMFlow single-head (shifted-)window attention, flash style, exact-f32 MFMA (gfx950).
+//
+// Replaces (paths relative to /root/reference/models/gmflow):
+//   transformer.py:8-16    single_head_full_attention   (num_splits == 1)
+//   transformer.py:46-105  single_head_split_window_attention: roll by -window/2, split into
+//                          K x K windows, softmax(QK^T/sqrt(C) + mask) V, merge, roll back
+//   transformer.py:19-43   generate_shift_window_attn_mask: -100 between tokens whose rolled
+//                          positions lie in different wrap regions
+//   utils.py:7-54          split_feature / merge_splits (pure index permutations)
+// The reference materialises the [B*K*K, Lw, Lw] score tensor (157 MB per layer at
+// 512x640x3 views) plus three rolled/split copies of q,k,v.  Here the roll, the window split
+// and the region mask are index arithmetic on the token id, and scores never leave registers.
+//
+// MFMA formulation (d = C = 128, one head).  A wave owns 32 queries (lane&31 = query n).
+//   S^T[key, n]  = sum_d K[key,d] Q[n,d]      : A = K tile (from LDS, row stride 129 floats so
+//                  the 32 lanes of a half-wave hit 32 distinct banks), B = Q (64 VGPRs/lane:
+//                  half-wave hl holds d in [64hl, 64hl+64))
+//   O^T[d, n]   += sum_key V[key,d] P[n,key]  : A = V tile (natural row-major LDS image),
+//                  B = P — and P is *already* in B-operand layout: the C/D layout of S^T puts
+//                  key (r&3)+8(r>>2)+4*hl of the tile in register r of lane (n,hl), which is
+//                  what K-step r of the PV product needs.  No transpose, no LDS round trip.
+// Softmax statistics (running max / sum per query) are per-lane scalars; the two half-waves
+// of a query exchange them with one cross-half shuffle per tile.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WA_C 128
+#define WA_KT 32            // keys per tile
+#define WA_KSTRIDE 129      // padded K row (floats)
+
+struct WinGeom {
+  int h, w, wh, ww, sh, sw, splits, Lw;
+};
+
+// window-local index -> token id in the un-rolled [h*w] sequence, and the wrap region of its
+// rolled position (0..8), cf. transformer.py:24-36
+__device__ __forceinline__ int win_token(const WinGeom& G, int wy, int wx, int li, int& region) {
+  const int ly = li / G.ww, lx = li - ly * G.ww;
+  const int ry = wy * G.wh + ly, rx = wx * G.ww + lx;  // position after roll by (-sh,-sw)
+  int oy = ry + G.sh, ox = rx + G.sw;                  // original position
+  if (oy >= G.h) oy -= G.h;
+  if (ox >= G.w) ox -= G.w;
+  const int regy = (ry >= G.h - G.wh) + (ry >= G.h - G.sh);
+  const int regx = (rx >= G.w - G.ww) + (rx >= G.w - G.sw);
+  region = regy * 3 + regx;
+  return oy * G.w + ox;
+}
+
+template <int NQW>
+__global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ out, WinGeom G, int shifted, float scale) {
+  constexpr int NT = NQW * 64;
+  __shared__ __attribute__((aligned(16))) float kS[WA_KT * WA_KSTRIDE];
+  __shared__ __attribute__((aligned(16))) float vS[WA_KT * WA_C];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  const int win = blockIdx.y, b = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
+
+  // ---- this lane's query
+  const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
+  const bool q_ok = qi_raw < G.Lw;
+  int q_region;
+  const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
+  float qreg[64];
+  {
+    const float4* src = reinterpret_cast<const float4*>(q + seq_base + (size_t)q_tok * WA_C + hl * 64);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 t = src[i];
+      qreg[4 * i] = t.x;
+      qreg[4 * i + 1] = t.y;
+      qreg[4 * i + 2] = t.z;
+      qreg[4 * i + 3] = t.w;
+    }
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
+  float m_run = -3.0e38f, l_run = 0.0f;
+
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K (padded rows) and V (row-major) tiles: 32 keys x 128 ch
+    for (int idx = tid; idx < WA_KT * (WA_C / 4); idx += NT) {
+      const int key = idx >> 5, c4 = idx & 31;
+      int li = kt * WA_KT + key;
+      if (li >= G.Lw) li = G.Lw - 1;
+      int reg_unused;
+      const int tok = win_token(G, wy, wx, li, reg_unused);
+      const size_t off = seq_base + (size_t)tok * WA_C + c4 * 4;
+      const float4 kk = *reinterpret_cast<const float4*>(k + off);
+      const float4 vv = *reinterpret_cast<const float4*>(v + off);
+      float* kd = kS + key * WA_KSTRIDE + c4 * 4;
+      kd[0] = kk.x;
+      kd[1] = kk.y;
+      kd[2] = kk.z;
+      kd[3] = kk.w;
+      *reinterpret_cast<float4*>(vS + key * WA_C + c4 * 4) = vv;
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T  (64 K-steps over d)
+    f32x16 s = (f32x16)(0.0f);
+    {
+      const float* ka = kS + n * WA_KSTRIDE + hl * 64;
+#pragma unroll
+      for (int t = 0; t < 64; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qreg[t], s, 0, 0, 0);
+    }
+    // ---- scale, masks, online softmax
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+      const int li = kt * WA_KT + key;
+      float sv = s[r] * scale;
+      if (shifted) {
+        int kreg;
+        (void)win_token(G, wy, wx, li < G.Lw ? li : (G.Lw - 1), kreg);
+        if (kreg != q_region) sv += -100.0f;
+      }
+      if (li >= G.Lw) sv = -3.0e38f;
+      s[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+    // ---- O^T += V^T P^T  (16 K-steps over the tile's keys, 4 M-blocks over d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+      const float* va = vS + key * WA_C + n;
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s[r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s[r], o[1], 0, 0, 0);
+      o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[64], s[r], o[2], 0, 0, 0);
+      o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[96], s[r], o[3], 0, 0, 0);
+    }
+  }
+  // ---- normalise and store: register quad (4g..4g+3) of block m = channels m*32+8g+4hl+{0..3}
+  if (q_ok) {
+    const float inv_l = 1.0f / l_run;
+    float* dst = out + seq_base + (size_t)q_tok * WA_C;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 t = make_float4(o[m][4 * g4] * inv_l, o[m][4 * g4 + 1] * inv_l,
+                                     o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
+        *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
+      }
+  }
+}
+
+extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
+                                      int32_t batch, int32_t h, int32_t w, int32_t num_splits,
+                                      int32_t shifted, void* stream) {
+  MNERF_REQUIRE(q && k && v && out, MNERF_E_NULL, "mnerf_window_attention: NULL buffer");
+  MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(k) && mnerf_aligned16(v) && mnerf_aligned16(out),
+                MNERF_E_ALIGN, "mnerf_window_attention: buffers must be 16-byte aligned");
+  MNERF_REQUIRE(batch >= 0 && h >= 1 && w >= 1 && num_splits >= 1, MNERF_E_RANGE,
+                "mnerf_window_attention: batch=%d h=%d w=%d splits=%d", batch, h, w, num_splits);
+  MNERF_REQUIRE(h % num_splits == 0 && w % num_splits == 0, MNERF_E_RANGE,
+                "mnerf_window_attention: %dx%d not divisible into %d splits", h, w, num_splits);
+  MNERF_REQUIRE(batch <= 65535 && num_splits * num_splits <= 65535, MNERF_E_RANGE,
+                "mnerf_window_attention: grid too large");
+  if (batch == 0) return MNERF_OK;
+  WinGeom G;
+  G.h = h;
+  G.w = w;
+  G.splits = num_splits;
+  G.wh = h / num_splits;
+  G.ww = w / num_splits;
+  const int do_shift = (shifted && num_splits > 1) ? 1 : 0;
+  G.sh = do_shift ? G.wh / 2 : 0;
+  G.sw = do_shift ? G.ww / 2 : 0;
+  G.Lw = G.wh * G.ww;
+  const float scale = 1.0f / sqrtf((float)WA_C);
+  hipStream_t st = (hipStream_t)stream;
+  const long long wgs4 = (long long)((G.Lw + 127) / 128) * num_splits * num_splits * batch;
+  if (wgs4 >= 512) {
+    dim3 grid((G.Lw + 127) / 128, num_splits * num_splits, batch);
+    hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), 0, st, q, k, v, out, G, do_shift, scale);
+  } else {
+    dim3 grid((G.Lw + 63) / 64, num_splits * num_splits, batch);
+    hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), 0, st, q, k, v, out, G, do_shift, scale);
+  }
+  return mnerf_check_launch("mnerf_window_attention");
+}

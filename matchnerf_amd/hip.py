@@ -1,0 +1,242 @@
+"""ctypes binding of libmnerf_hip.so (include/mnerf.h) — the only door to the HIP kernels.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+``MnerfError`` is raised.  The product path never routes through the CPU oracle.
+Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus explicit sizes; the
+stream is ``torch.cuda.current_stream().cuda_stream``.  The binding itself needs no GPU
+(``load()`` works on a CPU-only box; that is what the ``-m "not gpu"`` ABI tests exercise).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+MNERF_ABI_VERSION = 1
+MNERF_MAX_VIEWS = 16
+SMALL_FIXED = 1360  # floats of the `small` parameter block before the ray-posenc table
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
+
+EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
+           "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_render_workspace_bytes",
+           "mnerf_render_chunk", "mnerf_window_attention")
+
+
+class MnerfError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [("extr", C.c_float * 12), ("intr", C.c_float * 9), ("near_", C.c_float), ("far_", C.c_float)]
+
+
+class Rays(C.Structure):
+    _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("ray_begin", C.c_int32),
+                ("legacy_coord", C.c_int32), ("depth_inverse", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("ray_idx", C.c_void_p), ("strat_u", C.c_void_p),
+                ("kinv", C.c_float * 9), ("c2w", C.c_float * 12), ("near_", C.c_float), ("far_", C.c_float)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("n_scales", C.c_int32), ("fh", C.c_int32 * 2), ("fw", C.c_int32 * 2),
+                ("n_group", C.c_int32 * 2), ("feat", C.c_void_p * 2), ("images", C.c_void_p),
+                ("views", View * MNERF_MAX_VIEWS)]
+
+
+class Decoder(C.Structure):
+    _fields_ = [("wstream", C.c_void_p), ("wstream_floats", C.c_int64), ("small_", C.c_void_p),
+                ("n_views", C.c_int32), ("cond_dim", C.c_int32), ("cond_stride", C.c_int32),
+                ("L_3D", C.c_int32), ("raytrans_posenc", C.c_int32), ("raytrans_elu", C.c_int32),
+                ("density_maskfill", C.c_int32), ("wo_render_interval", C.c_int32),
+                ("setbg_opaque", C.c_int32)]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the library (once) and declare signatures.  Raises MnerfError if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise MnerfError(
+            f"{_LIB_PATH} not found: build it with `python -m matchnerf_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the render path.")
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:  # noqa: PERF203
+        raise MnerfError(f"cannot load {_LIB_PATH}: {e}") from e
+    vp, i32, i64, fp = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+    lib.mnerf_abi_version.restype = C.c_int
+    lib.mnerf_abi_version.argtypes = []
+    lib.mnerf_last_error.restype = C.c_char_p
+    lib.mnerf_last_error.argtypes = []
+    lib.mnerf_ray_samples.restype = C.c_int
+    lib.mnerf_ray_samples.argtypes = [C.POINTER(Rays), C.POINTER(View), fp, fp, fp, vp]
+    lib.mnerf_composite.restype = C.c_int
+    lib.mnerf_composite.argtypes = [i32, i32, fp, fp, fp, fp, i32, i32, fp, fp, fp, vp]
+    lib.mnerf_cost_volume.restype = C.c_int
+    lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
+    lib.mnerf_decoder_wstream_floats.restype = i64
+    lib.mnerf_decoder_wstream_floats.argtypes = [i32, i32]
+    lib.mnerf_decoder_chunk.restype = C.c_int
+    lib.mnerf_decoder_chunk.argtypes = [C.POINTER(Decoder), C.POINTER(View), C.POINTER(Rays), fp, fp, fp, fp, fp, fp, vp]
+    lib.mnerf_render_workspace_bytes.restype = i64
+    lib.mnerf_render_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.mnerf_render_chunk.restype = C.c_int
+    lib.mnerf_render_chunk.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), vp, fp, fp, fp, vp]
+    lib.mnerf_window_attention.restype = C.c_int
+    lib.mnerf_window_attention.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    ver = lib.mnerf_abi_version()
+    if ver != MNERF_ABI_VERSION:
+        raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mnerf_last_error().decode(errors="replace")
+        raise MnerfError(f"{what} failed (rc={rc}): {msg}")
+
+
+# ----------------------------------------------------------------------- struct builders
+
+
+def _fill(arr, values):
+    flat = np.asarray(values, dtype=np.float32).reshape(-1)
+    assert flat.size == len(arr), (flat.size, len(arr))
+    for i, x in enumerate(flat):
+        arr[i] = float(x)
+
+
+def make_view(extr34, intr33, near, far):
+    v = View()
+    _fill(v.extr, extr34)
+    _fill(v.intr, intr33)
+    v.near_, v.far_ = float(near), float(far)
+    return v
+
+
+def make_rays(n_rays, n_samples, height, width, kinv, c2w, near, far, ray_begin=0, legacy=True,
+              depth_inverse=False, ray_idx_ptr=None, strat_u_ptr=None):
+    r = Rays()
+    r.n_rays, r.n_samples, r.ray_begin = int(n_rays), int(n_samples), int(ray_begin)
+    r.legacy_coord, r.depth_inverse = int(bool(legacy)), int(bool(depth_inverse))
+    r.height, r.width = int(height), int(width)
+    r.ray_idx = ray_idx_ptr
+    r.strat_u = strat_u_ptr
+    _fill(r.kinv, kinv)
+    _fill(r.c2w, c2w)
+    r.near_, r.far_ = float(near), float(far)
+    return r
+
+
+def _stream_ptr(stream=None):
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32c(t, name):
+    import torch
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise MnerfError(f"{name}: expected a contiguous float32 CUDA tensor, got {t.dtype} "
+                         f"contig={t.is_contiguous()} device={t.device}")
+    return t
+
+
+# ----------------------------------------------------------------------- op wrappers
+
+
+def ray_samples(rays, view, stream=None):
+    """a8-a10 (camera.py:255-286, 351-379) -> pts [R,S,3], ndc [R,S,3], depth [R,S]."""
+    import torch
+    lib = load()
+    r, s = rays.n_rays, rays.n_samples
+    pts = torch.empty(r, s, 3, device="cuda")
+    ndc = torch.empty(r, s, 3, device="cuda")
+    depth = torch.empty(r, s, device="cuda")
+    check(lib.mnerf_ray_samples(C.byref(rays), C.byref(view), _ptr(pts), _ptr(ndc), _ptr(depth),
+                                _stream_ptr(stream)), "mnerf_ray_samples")
+    return pts, ndc, depth
+
+
+def composite(rgb_s, sigma, depth_s, ray_len=None, wo_render_interval=True, setbg_opaque=False, stream=None):
+    """K5 (nerf.py:101-124). rgb_s [R,S,3], sigma [R,S], depth_s [R,S] -> rgb [R,3], depth [R], opacity [R]."""
+    import torch
+    lib = load()
+    r, s = sigma.shape
+    _f32c(rgb_s, "rgb_s"), _f32c(sigma, "sigma"), _f32c(depth_s, "depth_s")
+    rgb = torch.empty(r, 3, device=sigma.device)
+    depth = torch.empty(r, device=sigma.device)
+    opacity = torch.empty(r, device=sigma.device)
+    check(lib.mnerf_composite(r, s, _ptr(rgb_s), _ptr(sigma), _ptr(depth_s), _ptr(ray_len),
+                              int(wo_render_interval), int(setbg_opaque), _ptr(rgb), _ptr(depth),
+                              _ptr(opacity), _stream_ptr(stream)), "mnerf_composite")
+    return rgb, depth, opacity
+
+
+def cost_volume(scene, rays, cond_stride, out=None, stream=None):
+    """K1+K2 (matchnerf.py:209-293) -> cond [n_rays*S, cond_stride]."""
+    import torch
+    lib = load()
+    n = rays.n_rays * rays.n_samples
+    if out is None:
+        out = torch.empty(n, cond_stride, device="cuda")
+    check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), int(cond_stride), _ptr(out),
+                                _stream_ptr(stream)), "mnerf_cost_volume")
+    return out
+
+
+def decoder_chunk(dec, view0, rays, cond, want_samples=False, stream=None):
+    """K3+K4+K5 (cond_nerf.py:52-100, ray_transformer.py, nerf.py:101-124)."""
+    import torch
+    lib = load()
+    r, s = rays.n_rays, rays.n_samples
+    dev = cond.device
+    rgb = torch.empty(r, 3, device=dev)
+    depth = torch.empty(r, device=dev)
+    opacity = torch.empty(r, device=dev)
+    rgb_s = torch.empty(r, s, 3, device=dev) if want_samples else None
+    sigma = torch.empty(r, s, device=dev) if want_samples else None
+    check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(view0), C.byref(rays), _ptr(cond), _ptr(rgb),
+                                  _ptr(depth), _ptr(opacity), _ptr(rgb_s), _ptr(sigma),
+                                  _stream_ptr(stream)), "mnerf_decoder_chunk")
+    if want_samples:
+        return rgb, depth, opacity, rgb_s, sigma
+    return rgb, depth, opacity
+
+
+def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None):
+    """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place."""
+    lib = load()
+    check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
+                                 _ptr(depth), _ptr(opacity), _stream_ptr(stream)), "mnerf_render_chunk")
+
+
+def render_workspace_bytes(n_rays, n_samples, cond_stride):
+    return int(load().mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride))
+
+
+def window_attention(q, k, v, h, w, num_splits, shifted, out=None, stream=None):
+    """K6 (gmflow/transformer.py:8-105). q,k,v [B,h*w,128] -> [B,h*w,128]."""
+    import torch
+    lib = load()
+    _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
+    b, n, c = q.shape
+    if c != 128 or n != h * w:
+        raise MnerfError(f"window_attention: expected [B,{h * w},128], got {tuple(q.shape)}")
+    if out is None:
+        out = torch.empty_like(q)
+    check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
+                                     int(bool(shifted)), _stream_ptr(stream)), "mnerf_window_attention")
+    return out

@@ -1,0 +1,194 @@
+"""GPU parity of every C-ABI entry point against the oracle and the reference goldens.
+
+Tolerances (fp32 path; north_star gate is 1e-4 RGB L-inf):
+  cost volume cond     2e-5   (cosine of 64/16-channel groups, bilinear taps)
+  per-sample rgb/sigma 5e-5
+  rendered rgb/opacity 1e-4, depth 3e-4 (depth values reach ~4.5)
+  window attention     2e-5
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_helpers import (cond_with_stride, images_rgba, make_decoder_struct, make_rays_struct, make_scene_struct,
+                         pair_feats_to_pair_major, ref_layout_to_pair_major)
+from helpers import golden_case, linf, split_poses
+from oracle import matchnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from matchnerf_amd import hip as h
+    h.load()
+    assert torch.cuda.is_available(), "the gpu-marked tests need a GPU"
+    return h
+
+
+@pytest.mark.parametrize("S,interval,bg", [(64, True, False), (64, False, True), (33, True, False), (200, False, False)])
+def test_composite_matches_oracle(hip, S, interval, bg):
+    g = torch.Generator().manual_seed(S)
+    r = 257
+    sigma = torch.rand(r, S, generator=g) * 0.3 * (torch.rand(r, S, generator=g) > 0.5)
+    rgb_s = torch.rand(r, S, 3, generator=g)
+    depth = torch.sort(torch.rand(r, S, generator=g) * 2 + 2, dim=1).values
+    ray = torch.randn(r, 3, generator=g)
+    cfg = O.OracleConfig(wo_render_interval=interval)
+    ref = O.composite(cfg, ray, rgb_s, sigma, depth, setbg_opaque=bg)
+    out = hip.composite(rgb_s.cuda(), sigma.cuda(), depth.cuda(), ray.norm(dim=-1).cuda().contiguous(),
+                        wo_render_interval=interval, setbg_opaque=bg)
+    assert linf(out[0], ref[0]) < 2e-6
+    assert linf(out[1], ref[1][:, 0]) < 1e-5
+    assert linf(out[2], ref[2][:, 0]) < 2e-6
+
+
+def test_composite_empty_and_errors(hip):
+    z = torch.empty(0, 64, device="cuda")
+    out = hip.composite(torch.empty(0, 64, 3, device="cuda"), z, z)
+    assert out[0].shape == (0, 3)
+    with pytest.raises(hip.MnerfError):
+        hip.composite(torch.rand(4, 8, 3, device="cuda"), torch.rand(4, 8, device="cuda"),
+                      torch.rand(4, 8, device="cuda"), None, wo_render_interval=False)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_window_attention_matches_reference(hip, golden, tag):
+    g = golden("window_attn")
+    b, h, w, c, splits = (int(x) for x in g[f"{tag}_dims"])
+    q, k, v = (torch.from_numpy(g[f"{tag}_{n}"]).cuda() for n in "qkv")
+    assert linf(hip.window_attention(q, k, v, h, w, splits, False), g[f"{tag}_plain"]) < 2e-5
+    assert linf(hip.window_attention(q, k, v, h, w, splits, True), g[f"{tag}_shift"]) < 2e-5
+    assert linf(hip.window_attention(q, k, v, h, w, 1, False), g[f"{tag}_full"]) < 2e-5
+
+
+def test_window_attention_dtu_shape_matches_oracle(hip):
+    """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case."""
+    gen = torch.Generator().manual_seed(3)
+    for (b, h, w, splits) in ((2, 64, 80, 2), (1, 50, 50, 2)):
+        q, k, v = (torch.randn(b, h * w, 128, generator=gen) for _ in range(3))
+        for shifted in (False, True):
+            ref = O.window_attention(q, k, v, h, w, splits, shifted)
+            out = hip.window_attention(q.cuda(), k.cuda(), v.cuda(), h, w, splits, shifted)
+            assert linf(out, ref) < 2e-5, (h, w, shifted)
+
+
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+def test_ray_geometry_is_bit_exact(hip, name):
+    """world points and ref-view-0 NDC coordinates: identical bits to the reference CPU path."""
+    g, cfg, sd, batch = golden_case(name)
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                          float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+    pts, ndc, depth = hip.ray_samples(rays, view0)
+    assert np.array_equal(pts.cpu().numpy().view(np.int32), g["pts"].view(np.int32))
+    assert np.array_equal(ndc.cpu().numpy().view(np.int32), g["x_ref"].view(np.int32))
+
+
+def _case_on_gpu(name):
+    g, cfg, sd, batch = golden_case(name)
+    v = cfg.n_src_views
+    if "feat_scale0" in g:
+        feats_pm = [ref_layout_to_pair_major(torch.from_numpy(g[f"feat_scale{i}"]), v) for i in range(2)]
+    else:
+        with torch.no_grad():
+            feats_pm = pair_feats_to_pair_major(O.encode_pairs(cfg, sd, batch["images"][0, :v]))
+    feats_gpu = [f.cuda() for f in feats_pm]
+    img_gpu = images_rgba(batch["images"][0, :v]).cuda()
+    return g, cfg, sd, batch, feats_gpu, img_gpu
+
+
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+def test_cost_volume_matches_reference(hip, name):
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    dc = g["cond"].shape[-1]
+    cs = ((dc + 1 + 7) // 8) * 8
+    cond = hip.cost_volume(sc, rays, cs).cpu().reshape(idx.numel(), cfg.sample_intvs, cs)
+    assert linf(cond[..., :dc], g["cond"]) < 2e-5
+    assert float((cond[..., dc] - 1).abs().max()) == 0.0 and float(cond[..., dc + 1:].abs().max()) == 0.0
+    # property: cosines in [-1,1], masks exactly 0/1
+    sum_g = sum(cfg.cos_n_group)
+    assert float(cond[..., :sum_g].abs().max()) <= 1 + 1e-5
+    m = cond[..., dc - cfg.n_src_views:dc]
+    assert bool(((m == 0) | (m == 1)).all())
+
+
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+def test_decoder_chunk_matches_reference(hip, name):
+    g, cfg, sd, batch, _, _ = _case_on_gpu(name)
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"])
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    n, s, dc = g["cond"].shape
+    cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
+    view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                          float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+    rgb, depth, opacity, rgb_s, sigma = hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)
+    assert linf(rgb_s, g["rgb_samples"]) < 5e-5
+    assert linf(sigma, g["sigma"]) < 5e-5
+    sel = g["stage_rays"]
+    assert linf(rgb, g["rgb"][0, sel]) < 1e-4
+    assert linf(opacity, g["opacity"][0, sel, 0]) < 1e-4
+    assert linf(depth, g["depth"][0, sel, 0]) < 3e-4
+
+
+@pytest.mark.parametrize("name,chunk", [("c1_default", 1024), ("c1_default", 4096), ("rect_wide", 1000),
+                                        ("nonlegacy", 1536), ("v4", 37)])
+def test_render_chunk_full_frame_matches_reference(hip, name, chunk):
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"])
+    h, w = batch["images"].shape[-2:]
+    n = h * w
+    rgb = torch.empty(n, 3, device="cuda")
+    depth = torch.empty(n, device="cuda")
+    opacity = torch.empty(n, device="cuda")
+    ws = torch.empty(hip.render_workspace_bytes(chunk, cfg.sample_intvs, dec.cond_stride) // 4, device="cuda")
+    for c in range(0, n, chunk):
+        m = min(chunk, n - c)
+        rays = make_rays_struct(cfg, batch, m, ray_begin=c)
+        hip.render_chunk(sc, dec, rays, ws, rgb[c:c + m], depth[c:c + m], opacity[c:c + m])
+    assert linf(rgb, g["rgb"][0]) < 1e-4
+    assert linf(opacity, g["opacity"][0, :, 0]) < 1e-4
+    assert linf(depth, g["depth"][0, :, 0]) < 3e-4
+    mse = float(((rgb.cpu() - torch.from_numpy(g["rgb"][0])) ** 2).mean())
+    assert mse < 1e-10  # => PSNR delta vs any ground truth far below 0.01 dB
+
+
+def test_odd_sample_counts_match_oracle(hip):
+    """S not a power of two (padded ray slots inside the fused kernel) vs the oracle."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    v = cfg.n_src_views
+    pair_feats = [(f[:, 0].permute(0, 3, 1, 2).cpu(), f[:, 1].permute(0, 3, 1, 2).cpu()) for f in feats_gpu]
+    for S in (48, 100):
+        cfg.sample_intvs = S
+        sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+        dec, keep = make_decoder_struct(cfg, sd)
+        n = 96
+        rays = make_rays_struct(cfg, batch, n, ray_begin=1000)
+        rgb = torch.empty(n, 3, device="cuda")
+        depth = torch.empty(n, device="cuda")
+        opacity = torch.empty(n, device="cuda")
+        ws = torch.empty(hip.render_workspace_bytes(n, S, dec.cond_stride) // 4, device="cuda")
+        hip.render_chunk(sc, dec, rays, ws, rgb, depth, opacity)
+        with torch.no_grad():
+            ref = O.render_rays(cfg, sd, torch.arange(1000, 1000 + n), *split_poses(batch), batch["images"][0, :v],
+                                pair_feats)
+        assert linf(rgb, ref[0]) < 1e-4 and linf(opacity, ref[2][:, 0]) < 1e-4 and linf(depth, ref[1][:, 0]) < 3e-4
+
+
+def test_argument_checks(hip):
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    sc.n_group[0] = 3
+    rays = make_rays_struct(cfg, batch, 16)
+    with pytest.raises(hip.MnerfError, match="cos_n_group"):
+        hip.cost_volume(sc, rays, 24)
+    dec, keep = make_decoder_struct(cfg, sd)
+    dec.wstream_floats -= 256
+    with pytest.raises(hip.MnerfError, match="wstream"):
+        hip.decoder_chunk(dec, sc.views[0], rays, torch.zeros(16 * 64, 24, device="cuda"))

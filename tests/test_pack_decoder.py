@@ -1,0 +1,124 @@
+"""Host logic of the decoder weight stream (no GPU): a numpy emulation of the kernel's MFMA
+dataflow (csrc/decoder.hip) consumes the packed stream exactly as the wavefront does — same
+segment schedule, same (lower | upper) half-wave operand rules — and must reproduce the
+oracle decoder.  This pins pack_wstream / decoder_schedule / pack_small without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_case, linf
+from matchnerf_amd import cond_nerf as CN
+from oracle import matchnerf_oracle as O
+
+
+def emulate_stage(ws, segs, name, b_lo, b_hi):
+    """b_lo/b_hi [T, N] operands of the lower/upper half-wave -> Y [nmb*32, N]."""
+    parts = [s for s in segs if s[0] == name]
+    nmb = parts[0][3]
+    y = np.zeros((nmb * 32, b_lo.shape[1]), np.float64)
+    for _, first, steps, m, off, _ in parts:
+        a = ws[off:off + steps * 64 * m].reshape(steps, 64, m).astype(np.float64)
+        for mb in range(m):
+            y[mb * 32:(mb + 1) * 32] += a[:, :32, mb].T @ b_lo[first:first + steps]
+            y[mb * 32:(mb + 1) * 32] += a[:, 32:, mb].T @ b_hi[first:first + steps]
+    return y
+
+
+def reg_order_operands(h, n_blocks):
+    lo, hi = CN._reg_order(n_blocks)
+    return h[lo], h[hi]
+
+
+def enc_operands(x, L, legacy):
+    """x [3,N] -> operands of the 3L+2 positional-encoding steps (decoder.hip: enc_operand)."""
+    lo, hi = [], []
+    fm = 1.0 if legacy else np.pi
+    for t in range(3 * L):
+        l, c = divmod(t, 3)
+        arg = x[c].astype(np.float32) * np.float32(2.0 ** l * fm)
+        lo.append(np.sin(arg.astype(np.float64)))
+        hi.append(np.cos(arg.astype(np.float64)))
+    lo += [x[0], x[2]]
+    hi += [x[1], np.ones_like(x[0])]
+    return np.stack(lo), np.stack(hi)
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4", "nonlegacy"])
+def test_emulated_mfma_chain_matches_oracle(name):
+    g, cfg, sd, batch = golden_case(name)
+    n_rays = 8
+    x_ref = torch.from_numpy(g["x_ref"][:n_rays])
+    dir_ref = torch.from_numpy(g["dir_ref"][:n_rays])
+    cond = torch.from_numpy(g["cond"][:n_rays])
+    v = cfg.n_src_views
+    mask = cond[..., -v:]
+    with torch.no_grad():
+        rgb_o, sigma_o = O.decoder(cfg, sd, x_ref, dir_ref, cond, mask)
+
+    ws, cond_dim, cs = CN.pack_wstream(sd, v, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    segs, total = CN.decoder_schedule(cs, cfg.L_3D)
+    assert ws.size == total and cond_dim == cond.shape[-1]
+    n = n_rays * cfg.sample_intvs
+    x = x_ref.reshape(n, 3).numpy().T.astype(np.float64)
+    cpad = np.zeros((cs, n))
+    cpad[:cond_dim] = cond.reshape(n, cond_dim).numpy().T
+    cpad[cond_dim] = 1.0
+    fs = cs // 2
+    film = emulate_stage(ws, segs, "film", cpad[:fs], cpad[fs:])
+    e_lo, e_hi = enc_operands(x, cfg.L_3D, cfg.legacy_coord)
+    h = np.maximum(emulate_stage(ws, segs, "l0", e_lo, e_hi) * film, 0)
+    one, zero = np.ones((1, n)), np.zeros((1, n))
+    for i in range(1, 5):
+        lo, hi = reg_order_operands(h, 4)
+        h = np.maximum(emulate_stage(ws, segs, f"l{i}", np.vstack([lo, one]), np.vstack([hi, zero])) * film, 0)
+    lo, hi = reg_order_operands(h, 4)
+    h = np.maximum((emulate_stage(ws, segs, "l5e", e_lo, e_hi) + emulate_stage(ws, segs, "l5h", lo, hi)) * film, 0)
+    lo, hi = reg_order_operands(h, 4)
+    a = emulate_stage(ws, segs, "alpha", np.vstack([lo, one]), np.vstack([hi, zero]))
+    assert np.abs(a[16:]).max() == 0.0  # padded output rows stay zero
+    feat = emulate_stage(ws, segs, "feature", np.vstack([lo, one]), np.vstack([hi, zero]))
+    d = np.repeat(dir_ref.numpy().astype(np.float64), cfg.sample_intvs, 0).T
+    lo, hi = reg_order_operands(feat, 4)
+    hv = np.maximum(emulate_stage(ws, segs, "views", np.vstack([lo, d[0:1], d[2:3]]),
+                                  np.vstack([hi, d[1:2], one])), 0)
+    lo, hi = reg_order_operands(hv, 2)
+    rgb = 1 / (1 + np.exp(-emulate_stage(ws, segs, "rgb", np.vstack([lo, one]), np.vstack([hi, zero]))[:3]))
+    assert linf(rgb.T.reshape(n_rays, -1, 3), rgb_o) < 2e-6
+
+    # density branch through the oracle's own attention on the emulated alpha features
+    a_t = torch.from_numpy(a[:16].T.reshape(n_rays, -1, 16)).float()
+    a_t = O._act(cfg.raytrans_act, a_t)
+    if cfg.raytrans_posenc:
+        a_t = a_t + torch.from_numpy(CN.raytrans_table(a_t.shape[1]))[None]
+    o = O.ray_attention(sd, a_t, (mask.sum(-1) > 1).float())
+    nd = "nerf_dec."
+    o = O._act(cfg.raytrans_act, o @ sd[nd + "out_alpha_linear.0.weight"].t() + sd[nd + "out_alpha_linear.0.bias"])
+    sig = torch.relu(o @ sd[nd + "out_alpha_linear.2.weight"].t() + sd[nd + "out_alpha_linear.2.bias"])[..., 0]
+    assert linf(sig, sigma_o) < 2e-6
+
+
+def test_schedule_invariants():
+    for cs, L in ((24, 10), (32, 10), (56, 10), (64, 10), (24, 6), (24, 0)):
+        segs, total = CN.decoder_schedule(cs, L)
+        assert total % 256 == 0
+        off = 0
+        for name, first, steps, m, o, fl in segs:
+            assert o == off and fl % 256 == 0 and fl <= CN.SEG_CAP_FLOATS and steps * 64 * m <= fl
+            off += fl
+        for name, t, m in CN.decoder_stages(cs, L):
+            assert sum(s[2] for s in segs if s[0] == name) == t
+        # stages fed from accumulator registers must split 32 | 32(+1) (static unrolling in the kernel)
+        for name in ("l1", "l2", "l3", "l4", "feature"):
+            assert [s[2] for s in segs if s[0] == name] == [32, 33]
+        assert [s[2] for s in segs if s[0] == "l5h"] == [32, 32]
+        for name in ("alpha", "views", "rgb", "film"):
+            assert len([s for s in segs if s[0] == name]) == 1
+
+
+def test_small_block_layout():
+    g, cfg, sd, _ = golden_case("c1_default")
+    s = CN.pack_small(sd, 64, True)
+    assert s.size == CN.SMALL_FIXED + 64 * 16
+    assert np.array_equal(s[768:1024], sd["nerf_dec.ray_attention.fc.weight"].numpy().reshape(-1))
+    assert s[1344] == float(sd["nerf_dec.out_alpha_linear.2.bias"][0])
+    assert linf(s[CN.SMALL_FIXED:].reshape(64, 16), O.raytrans_table(64)) == 0.0
