@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — rendered rays/sec of the MatchNeRF hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one synthetic batch of BASELINE config[1]:
+``MatchNeRF.forward(batch, mode='test')`` for a 3-view 512x640 DTU-shaped scene with 64
+samples/ray — the GMFlow encoder on the 3 source views plus all 327,680 target rays
+(encoder INCLUDED in the timed region; render-only rate reported separately under
+``config``).  Inputs are resident in HBM when the timed region starts.  Arithmetic is fp32
+("f32": the 1e-4 RGB parity gate cannot be met in bf16).
+
+N > 1: one process per GPU (RCCL); every rank encodes the shared source views and renders a
+DIFFERENT target view (weak scaling: BASELINE config[3], "target views sharded across GPUs"),
+then one all_gather returns every rank's [327680,5] tile to all ranks.  value = all rays of
+all ranks / max-over-ranks time.
+
+Also printed in the same JSON line:
+  roofline     dominant kernel (fused decoder, f32 MFMA): algorithmic FLOPs per launch
+               (258,336 + 64*S per sample) / average launch duration measured
+               with events on the launch stream inside the timed region, vs 157.3 TFLOP/s.
+  cpu_baseline the CPU oracle (a port of the reference path, pinned to it by goldens) timed
+               on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+H, W, V, S, CHUNK = 512, 640, 3, 64, 4096
+CPU_RAYS = 1024      # rays of the bounded CPU-baseline sample
+CPU_THREADS_MAX = 16 # torch intra-op threads for the CPU baseline (more threads than this is
+                     # slower on the small tensors of this path: 256 threads measured 14x slower)
+F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+
+
+def flops_per_sample(s):
+    return 258336 + 64 * s
+
+
+def build_model(device):
+    from matchnerf_amd import options, synthetic as syn
+    from matchnerf_amd.models import models_dict
+    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt.device = str(device)
+    opt.n_src_views = V
+    opt.nerf.sample_intvs = S
+    opt.nerf.rand_rays_test = CHUNK
+    model = models_dict[opt.model](opt).to(device).eval()
+    weights = syn.seeded_state_dict(syn.state_dict_spec(n_src_views=V), 1)
+    model.load_state_dict(syn.to_torch(weights, device))
+    return opt, model, weights
+
+
+def make_batch(device, target_shift):
+    """Synthetic DTU-shaped scene; ``target_shift`` moves the target camera (one view per rank)."""
+    from matchnerf_amd import synthetic as syn
+    from matchnerf_amd.edict import EasyDict
+    sc = syn.make_scene(H, W, V, seed=0)
+    if target_shift:
+        ext = sc["extrinsics"].copy()
+        ext[0, -1, 0, 3] += 0.04 * target_shift  # slide the target along x (camera frame)
+        sc["extrinsics"] = ext
+    return sc, EasyDict({k: torch.from_numpy(v).to(device) for k, v in sc.items()})
+
+
+def cpu_baseline(weights, scene, n_threads):
+    """Oracle timed on the host: 1 encoder pass + 1 slice of CPU_RAYS rays, extrapolated to a
+    full frame (the reference's own loop structure, matchnerf.py:145-161).  Bounded sample:
+    ~10-30 s of CPU work."""
+    from matchnerf_amd import synthetic as syn
+    from oracle import matchnerf_oracle as O
+    torch.set_num_threads(n_threads)
+    cfg = O.OracleConfig(n_src_views=V, sample_intvs=S)
+    sd = syn.to_torch(weights)
+    b = {k: torch.from_numpy(v) for k, v in scene.items()}
+    imgs = b["images"][0, :V]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats = O.encode_pairs(cfg, sd, imgs)
+        t_enc = time.perf_counter() - t0
+        idx = torch.arange(100 * W, 100 * W + CPU_RAYS)
+        t0 = time.perf_counter()
+        O.render_rays(cfg, sd, idx, b["extrinsics"][0, -1, :3], b["intrinsics"][0, -1], b["near_fars"][0, -1],
+                      b["extrinsics"][0, :-1, :3], b["intrinsics"][0, :-1], b["near_fars"][0, :-1], imgs, feats)
+        t_chunk = time.perf_counter() - t0
+    n_chunks = H * W / CPU_RAYS
+    frame_s = t_enc + n_chunks * t_chunk
+    return dict(value=round(H * W / frame_s, 2), unit="rays/s", cores=n_threads, kind="port",
+                sample=f"oracle (torch-CPU port of the reference path): 1 encoder pass ({t_enc:.2f} s) + 1 slice of "
+                       f"{CPU_RAYS} rays ({t_chunk:.2f} s), extrapolated to a {H * W}-ray frame",
+                render_only_rays_per_s=round(CPU_RAYS / t_chunk, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from matchnerf_amd import dist as mdist
+    from matchnerf_amd import hip
+    rank, world, device = mdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    hip.load()
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode for the backbone convolutions
+
+    opt, model, weights = build_model(device)
+    scene, batch = make_batch(device, target_shift=rank)
+    n_rays = H * W
+
+    def step(timer=None):
+        model.kernel_timer = timer
+        with torch.no_grad():
+            out = model(batch, mode="test")
+        tile = torch.cat([out.rgb[0], out.depth[0], out.opacity[0]], -1)  # [HW,5]
+        full = mdist.gather_tiles(tile)                                    # RCCL all_gather (N>1)
+        return full
+
+    for _ in range(args.warmup):
+        step()
+    timer = hip.KernelTimer()
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        full = step(timer)
+    torch.cuda.synchronize()
+    mdist.barrier()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device)
+    assert full.shape == (world * n_rays, 5) and bool(torch.isfinite(full).all())
+
+    ksum = timer.summary()
+    model.kernel_timer = None
+    # encoder-only and render-only rates (outside the timed region, rank-local)
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            feats = model.get_img_feat(batch.images[:, :V], cur_n_src_views=V)
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - t1) / 3 * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n_rays * args.steps / elapsed
+        dec = ksum["decoder"]
+        flops_launch = dec["rays"] / dec["launches"] * S * flops_per_sample(S)
+        achieved = flops_launch / (dec["avg_ms"] * 1e-3) / 1e12
+        render_ms = (dec["total_ms"] + ksum["cost_volume"]["total_ms"]) / args.steps
+        line = {
+            "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
+                            "(327680 rays) per step incl. GMFlow encoder; fp32 parity mode",
+                "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(dec["rays"] / dec["launches"]),
+                "parallelism": f"target views x{world}" if world > 1 else "single GPU",
+                "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
+                "render_only_rays_per_s_per_gpu": round(n_rays / (render_ms * 1e-3), 1),
+                "cost_volume_ms_per_frame": round(ksum["cost_volume"]["total_ms"] / args.steps, 3),
+                "decoder_ms_per_frame": round(dec["total_ms"] / args.steps, 3),
+            },
+            "roofline": {"bound": "mfma", "kernel": "decoder_kernel<4> (fused MLP + ray transformer + compositing)",
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(dec["avg_ms"], 4),
+                         "flops_per_launch": flops_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, scene, min(os.cpu_count() or 1, CPU_THREADS_MAX))
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

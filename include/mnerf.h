@@ -106,6 +106,9 @@ typedef struct mnerf_decoder {
 
 int mnerf_abi_version(void);
 const char* mnerf_last_error(void);
+/* sizeof() of the argument structs as compiled (0 view, 1 rays, 2 scene, 3 decoder; -1 else):
+ * lets a foreign-language binding verify its struct mirrors before the first call. */
+int64_t mnerf_struct_size(int32_t which);
 
 /* a8-a10 — target rays, depth samples, world points and their (u,v,z) in one source view.
  * Replaces camera.get_center_and_ray (misc/camera.py:255-278), MatchNeRF.sample_depth

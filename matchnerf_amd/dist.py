@@ -1,0 +1,79 @@
+"""Multi-GPU sharding of the render path: one process per GPU, RCCL over xGMI.
+
+Rays of a frame — and whole target views — are independent given the (replicated) weights
+and source-view feature maps, so the path shards with NO collective inside
+the kernels.  Each rank re-runs the small encoder on the shared source views (0.65 TFLOP,
+cheaper than setting up a broadcast at 3 views), renders its own slice, and ONE collective
+returns the rendered tiles: ``all_gather_into_tensor`` of ``[rays_local, 5]`` fp32
+(rgb, depth, opacity) — 6.5 MB per 512x640 frame, latency-bound on xGMI.
+The reference has only ``nn.DataParallel`` (coach.py:83-85), which at batch_size 1
+degenerates to one GPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) -> (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    device = torch.device(f"cuda:{local}" if use_cuda else "cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous, balanced partition of range(n_items): -> (begin, count); the first
+    ``n_items % world`` ranks take one extra item."""
+    base, extra = divmod(n_items, world)
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)
+
+
+def shard_rows(height, width, rank, world):
+    """Row-tile partition of one frame -> (first_ray, n_rays) in row-major pixel order."""
+    r0, nr = shard_range(height, rank, world)
+    return r0 * width, nr * width
+
+
+def gather_tiles(local, counts=None):
+    """All ranks receive the concatenation of every rank's ``local`` [n_r, C] tile, in rank
+    order.  ``counts`` = per-rank row counts (needed when they differ: tiles are padded to the
+    largest and trimmed after the collective, so a single all_gather_into_tensor suffices)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    if counts is None:
+        counts = [local.shape[0]] * world
+    width = max(counts)
+    send = local
+    if local.shape[0] != width:
+        send = local.new_zeros((width,) + tuple(local.shape[1:]))
+        send[:local.shape[0]] = local
+    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, send.contiguous())
+    if all(c == width for c in counts):
+        return out
+    return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], 0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

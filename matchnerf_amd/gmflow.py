@@ -1,0 +1,233 @@
+"""GMFlow pair-wise feature encoder of MatchNeRF, MI355X-native host orchestration.
+
+Mirrors the parameter structure (and therefore the ``state_dict`` keys — SURVEY.md Appendix B)
+of /root/reference/models/gmflow/{gmflow,backbone,transformer,superres,position}.py, with a
+forward pass designed around what the render kernels consume:
+
+* tokens are channel-last ``[sequence, h*w, 128]`` from the backbone output onwards, so the
+  transformer's result *is* the pair-major channel-last feature map ``[P,2,h,w,128]`` that
+  ``mnerf_cost_volume`` samples (include/mnerf.h) — no NCHW round trip, no per-view
+  ``torch.cat`` regrouping (reference: matchnerf.py:192-205);
+* the window sine position tile depends only on the token position, so it is added once per
+  VIEW before pairs are formed (reference adds it per pair member, gmflow/utils.py:68-88);
+* the six swin self/cross attention layers call the flash-style f32-MFMA HIP kernel
+  ``mnerf_window_attention`` (K6): roll, window split/merge and the shift mask are index
+  arithmetic in the kernel, the [24,1280,1280] score tensor is never materialised
+  (reference: transformer.py:46-105);
+* convolutions / InstanceNorm / Linear / LayerNorm / GELU are PyTorch-ROCm library ops
+  (MIOpen, rocBLAS) — SURVEY.md §2 marks them "supporting, not a hand-kernel target".
+
+There is no CPU path: ``forward`` needs the HIP library and a GPU tensor.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+from .camera import pair_list
+
+
+class ResidualBlock(nn.Module):
+    """backbone.py:6-36 (InstanceNorm2d without affine => no parameters for the norms)."""
+
+    def __init__(self, in_planes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.stride = stride
+        if stride != 1 or in_planes != planes:
+            # index 0 carries the parameters; the InstanceNorm that follows it in the reference
+            # (nn.Sequential(conv, norm3)) has none and is applied functionally below
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        y = F.relu(F.instance_norm(self.conv1(x)))
+        y = F.relu(F.instance_norm(self.conv2(y)))
+        if self.downsample is not None:
+            x = F.instance_norm(self.downsample(x))
+        return F.relu(x + y)
+
+
+class CNNEncoder(nn.Module):
+    """backbone.py:39-122 with num_output_scales=1: stride-8, 128-channel features."""
+
+    def __init__(self, output_dim=128):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.layer1 = nn.Sequential(ResidualBlock(64, 64, 1), ResidualBlock(64, 64, 1))
+        self.layer2 = nn.Sequential(ResidualBlock(64, 96, 2), ResidualBlock(96, 96, 1))
+        self.layer3 = nn.Sequential(ResidualBlock(96, 128, 2), ResidualBlock(128, 128, 1))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = F.relu(F.instance_norm(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        return self.conv2(x)
+
+
+class TransformerLayer(nn.Module):
+    """transformer.py:108-185 (single head, swin windows)."""
+
+    def __init__(self, d_model=128, no_ffn=False, ffn_dim_expansion=4):
+        super().__init__()
+        self.no_ffn = no_ffn
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.norm1 = nn.LayerNorm(d_model)
+        if not no_ffn:
+            self.mlp = nn.Sequential(nn.Linear(2 * d_model, 2 * d_model * ffn_dim_expansion, bias=False), nn.GELU(),
+                                     nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
+            self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, source, target, h, w, splits, shifted):
+        q = self.q_proj(source)
+        k = self.k_proj(target)
+        v = self.v_proj(target)
+        msg = hip.window_attention(q, k, v, h, w, splits, shifted)
+        msg = self.norm1(self.merge(msg))
+        if not self.no_ffn:
+            msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))
+        return source + msg
+
+
+class TransformerBlock(nn.Module):
+    """transformer.py:188-247."""
+
+    def __init__(self, d_model=128, ffn_dim_expansion=4):
+        super().__init__()
+        self.self_attn = TransformerLayer(d_model, no_ffn=True, ffn_dim_expansion=ffn_dim_expansion)
+        self.cross_attn_ffn = TransformerLayer(d_model, no_ffn=False, ffn_dim_expansion=ffn_dim_expansion)
+
+
+class FeatureTransformer(nn.Module):
+    """transformer.py:250-339: both directions of every pair batched as [f0;f1] vs [f1;f0]."""
+
+    def __init__(self, num_layers=6, d_model=128, ffn_dim_expansion=4):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerBlock(d_model, ffn_dim_expansion) for _ in range(num_layers)])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, n_pairs, h, w, splits, wo_self_attn=False):
+        """src [2P, h*w, C] (first P = pair member a, last P = member b) -> same shape."""
+        tgt = torch.cat([src[n_pairs:], src[:n_pairs]], 0)
+        for i, blk in enumerate(self.layers):
+            shifted = (i % 2 == 1) and splits > 1
+            if not wo_self_attn:
+                src = blk.self_attn(src, src, h, w, splits, shifted)
+            src = blk.cross_attn_ffn(src, tgt, h, w, splits, shifted)
+            tgt = torch.cat([src[n_pairs:], src[:n_pairs]], 0)
+        return src
+
+
+class UpSampler(nn.Module):
+    """superres.py:5-38."""
+
+    def __init__(self, n_feat=128, upsample_factor=2):
+        super().__init__()
+        self.n_blocks = int(math.log2(upsample_factor))
+        self.conv_ls = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks)])
+        self.conv_l2rs = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks + 1)])
+
+    def forward(self, x):
+        right = self.conv_l2rs[0](x)
+        left = x
+        for i in range(self.n_blocks):
+            left = F.leaky_relu(self.conv_ls[i](F.interpolate(left, scale_factor=2.0, mode="nearest")), 0.2)
+            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + self.conv_l2rs[i + 1](left)
+        return right
+
+
+_SINE_CACHE = {}
+
+
+def sine_position_tokens(h, w, channels, device):
+    """DETR sine embedding of an (h,w) window (position.py:26-47) as tokens [h*w, C]."""
+    key = (h, w, channels, str(device))
+    if key not in _SINE_CACHE:
+        npf = channels // 2
+        y = (torch.arange(1, h + 1, dtype=torch.float32) / (h + 1e-6) * (2 * math.pi))[:, None].expand(h, w)
+        x = (torch.arange(1, w + 1, dtype=torch.float32) / (w + 1e-6) * (2 * math.pi))[None, :].expand(h, w)
+        i = torch.arange(npf, dtype=torch.float32)
+        dim_t = 10000.0 ** (2 * torch.div(i, 2, rounding_mode="trunc") / npf)
+
+        def emb(t):
+            a = t[..., None] / dim_t
+            return torch.stack([a[..., 0::2].sin(), a[..., 1::2].cos()], -1).flatten(-2)
+
+        _SINE_CACHE[key] = torch.cat([emb(y), emb(x)], -1).to(device)  # [h,w,C]
+    return _SINE_CACHE[key]
+
+
+class GMFlow(nn.Module):
+    """Constructor keeps the reference's keyword surface (gmflow.py:12-45); children are named
+    ``backbone`` / ``transformer`` / ``featup_net`` as ``restore_checkpoint`` and
+    ``load_gmflow_checkpoint`` expect (misc/utils.py:160-205)."""
+
+    def __init__(self, num_scales=1, upsample_factor=2, feature_channels=128, attention_type="swin",
+                 num_transformer_layers=6, ffn_dim_expansion=4, num_head=1, feature_upsampler="network",
+                 device=None, **kwargs):
+        super().__init__()
+        if num_scales != 1 or num_head != 1 or attention_type != "swin" or feature_channels != 128:
+            raise NotImplementedError("MatchNeRF instantiates GMFlow(num_scales=1, num_head=1, 'swin', 128 ch) "
+                                      "(models/matchnerf.py:21-26); other shapes are not built")
+        if feature_upsampler != "network":
+            raise NotImplementedError("keep_raw_feats requires the network up-sampler (gmflow.py:117)")
+        self.feature_channels = feature_channels
+        self.upsample_factor = upsample_factor
+        self.backbone = CNNEncoder(output_dim=feature_channels)
+        self.transformer = FeatureTransformer(num_transformer_layers, feature_channels, ffn_dim_expansion)
+        self.featup_net = UpSampler(feature_channels, upsample_factor)
+        self.register_buffer("_mean", torch.tensor([0.485, 0.456, 0.406]).reshape(1, 3, 1, 1), persistent=False)
+        self.register_buffer("_std", torch.tensor([0.229, 0.224, 0.225]).reshape(1, 3, 1, 1), persistent=False)
+
+    def forward(self, imgs, attn_splits_list=None, wo_self_attn=False, **kwargs):
+        """imgs [B,V,3,H,W] in [0,1] -> list over scales (1/8 raw, 1/4 up-sampled) of
+        pair-major channel-last maps [B, P, 2, h_s, w_s, 128] (gmflow.py:91-150)."""
+        b, v, c, hh, ww = imgs.shape
+        splits = attn_splits_list[0] if isinstance(attn_splits_list, (list, tuple)) else (attn_splits_list or 1)
+        x = imgs.reshape(b * v, c, hh, ww)
+        if hh == 756 and ww == 1008:  # IBRNet setting, gmflow.py:100-103
+            x = F.interpolate(x, size=(768, 1024), mode="bilinear", align_corners=True)
+        feat = self.backbone((x - self._mean) / self._std)                    # [BV,128,h,w]
+        _, ch, h, w = feat.shape
+        if h % splits or w % splits:
+            raise ValueError(f"feature map {h}x{w} is not divisible by attn_splits={splits}")
+        tok = feat.permute(0, 2, 3, 1)                                        # [BV,h,w,C] view
+        pe = sine_position_tokens(h // splits, w // splits, ch, feat.device).repeat(splits, splits, 1)
+        tok = (tok + pe).reshape(b, v, h * w, ch)
+        pairs = pair_list(v)
+        ia = torch.tensor([a for a, _ in pairs], device=feat.device)
+        ib = torch.tensor([bb for _, bb in pairs], device=feat.device)
+        p_n = len(pairs)
+        outs0, outs1 = [], []
+        for bi in range(b):
+            src = torch.cat([tok[bi, ia], tok[bi, ib]], 0).contiguous()       # [2P, hw, C]
+            src = self.transformer(src, p_n, h, w, splits, wo_self_attn)
+            outs0.append(torch.stack([src[:p_n], src[p_n:]], 1).reshape(p_n, 2, h, w, ch))
+            up = self.featup_net(src.reshape(2 * p_n, h, w, ch).permute(0, 3, 1, 2))  # [2P,C,2h,2w]
+            up = up.permute(0, 2, 3, 1)
+            outs1.append(torch.stack([up[:p_n], up[p_n:]], 1).contiguous())
+        return [torch.stack(outs0, 0).contiguous(), torch.stack(outs1, 0).contiguous()]
+
+
+def pair_major_to_view_chunks(feat_pm):
+    """[B,P,2,h,w,C] -> the reference's per-view layout [B,V,(V-1)*C,h,w] (matchnerf.py:192-205);
+    for callers that want ``get_img_feat``'s original return format."""
+    b, p_n = feat_pm.shape[:2]
+    v = int(round((1 + math.sqrt(1 + 8 * p_n)) / 2))
+    per_view = [[] for _ in range(v)]
+    for p, (a, bb) in enumerate(pair_list(v)):
+        per_view[a].append(feat_pm[:, p, 0])
+        per_view[bb].append(feat_pm[:, p, 1])
+    return torch.stack([torch.cat(chunks, -1) for chunks in per_view], 1).permute(0, 1, 4, 2, 3)

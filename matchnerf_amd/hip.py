@@ -18,7 +18,7 @@ SMALL_FIXED = 1360  # floats of the `small` parameter block before the ray-posen
 _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
-EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
+EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_window_attention")
 
@@ -61,6 +61,10 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be resident BEFORE this library is
+    # dlopen'ed so that both bind to ONE HIP runtime (device pointers and streams are shared).
+    # Loading /opt/rocm's copy first leaves the process with a runtime torch cannot use.
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise MnerfError(
             f"{_LIB_PATH} not found: build it with `python -m matchnerf_amd.csrc.build` "
@@ -74,6 +78,8 @@ def load():
     lib.mnerf_abi_version.argtypes = []
     lib.mnerf_last_error.restype = C.c_char_p
     lib.mnerf_last_error.argtypes = []
+    lib.mnerf_struct_size.restype = i64
+    lib.mnerf_struct_size.argtypes = [i32]
     lib.mnerf_ray_samples.restype = C.c_int
     lib.mnerf_ray_samples.argtypes = [C.POINTER(Rays), C.POINTER(View), fp, fp, fp, vp]
     lib.mnerf_composite.restype = C.c_int
@@ -93,6 +99,10 @@ def load():
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
+    for which, st in enumerate((View, Rays, Scene, Decoder)):
+        if lib.mnerf_struct_size(which) != C.sizeof(st):
+            raise MnerfError(f"struct {st.__name__}: library says {lib.mnerf_struct_size(which)} bytes, "
+                             f"ctypes mirror has {C.sizeof(st)}")
     _LIB = lib
     return lib
 
@@ -216,11 +226,54 @@ def decoder_chunk(dec, view0, rays, cond, want_samples=False, stream=None):
     return rgb, depth, opacity
 
 
-def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None):
-    """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place."""
+class KernelTimer:
+    """Per-kernel device timing with events recorded on the launch stream (bench.py roofline).
+    ``spans[name]`` collects (start_event, end_event, n_rays) triples; ``summary`` syncs once."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def span(self, name, n_rays):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.spans.setdefault(name, []).append((e0, e1, n_rays))
+        return e0, e1
+
+    def reset(self):
+        self.spans = {}
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, spans in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b, _ in spans]
+            out[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / max(len(ms), 1),
+                             rays=sum(n for _, _, n in spans))
+        return out
+
+
+def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None, timer=None):
+    """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place.
+    With ``timer`` the two kernels are enqueued through their own entry points (same work,
+    same stream) with events around each, so that per-kernel durations can be reported."""
     lib = load()
-    check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
-                                 _ptr(depth), _ptr(opacity), _stream_ptr(stream)), "mnerf_render_chunk")
+    if timer is None:
+        check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
+                                     _ptr(depth), _ptr(opacity), _stream_ptr(stream)), "mnerf_render_chunk")
+        return
+    import torch
+    st = stream or torch.cuda.current_stream()
+    a0, a1 = timer.span("cost_volume", rays.n_rays)
+    a0.record(st)
+    check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), dec.cond_stride, _ptr(workspace), _stream_ptr(st)),
+          "mnerf_cost_volume")
+    a1.record(st)
+    b0, b1 = timer.span("decoder", rays.n_rays)
+    b0.record(st)
+    check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(scene.views[0]), C.byref(rays), _ptr(workspace), _ptr(rgb),
+                                  _ptr(depth), _ptr(opacity), None, None, _stream_ptr(st)), "mnerf_decoder_chunk")
+    b1.record(st)
 
 
 def render_workspace_bytes(n_rays, n_samples, cond_stride):

@@ -1,0 +1,273 @@
+"""MatchNeRF — drop-in module for the reference's ``models.matchnerf.MatchNeRF``.
+
+Same constructor (``MatchNeRF(opts)``), same attributes (``feat_enc``, ``nerf_dec``,
+``nerf_setbg_opaque``, ``n_src_views``), same ``forward(batch, mode, render_video,
+render_path_mode)`` contract and the same ``state_dict`` keys as
+/root/reference/models/matchnerf.py:13-325 — but the per-ray hot path runs in hand-written
+HIP kernels for MI355X (``libmnerf_hip.so``, include/mnerf.h):
+
+    encoder        GMFlow with the K6 shifted-window attention kernel        (gmflow.py)
+    render chunk   K1+K2 cost volume -> K3+K4+K5 fused decoder/compositing   (mnerf_render_chunk)
+
+What the reference does per 4096-ray chunk in ~100 eager ops (full-image ray grid, six
+268 MB sampled-feature tensors, [R,4,S,S] attention scores ...) is two kernel launches here,
+fed by pair-major channel-last feature maps that stay resident in HBM for the whole frame.
+
+The HIP path is the ONLY path: there is no eager fallback.  Without the shared library or
+without a GPU, rendering raises ``hip.MnerfError`` / ``RuntimeError``.
+"""
+import numpy as np
+import torch
+
+from . import camera, hip
+from .cond_nerf import CondNeRF
+from .edict import EasyDict as edict
+from .gmflow import GMFlow, pair_major_to_view_chunks
+
+# rays per kernel launch when a full image is rendered.  The reference's
+# ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
+# chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
+MAX_RAYS_PER_LAUNCH = 65536
+
+
+class MatchNeRF(torch.nn.Module):
+    def __init__(self, opts):
+        super().__init__()
+        self.opts = opts
+        self.nerf_setbg_opaque = False
+        self.n_src_views = opts.n_src_views
+        if self.n_src_views > hip.MNERF_MAX_VIEWS:
+            raise NotImplementedError(f"n_src_views={self.n_src_views} > {hip.MNERF_MAX_VIEWS}")
+        self.feat_enc = GMFlow(feature_channels=128, num_scales=1, num_head=1, attention_type="swin",
+                               ffn_dim_expansion=4, feature_upsampler=opts.encoder.feature_upsampler,
+                               upsample_factor=opts.encoder.upsample_factor,
+                               num_transformer_layers=opts.encoder.num_transformer_layers,
+                               device=opts.device).to(opts.device)
+        self.nerf_dec = CondNeRF(opts).to(opts.device)
+        if getattr(opts.encoder, "feature_sample_local_radius", 0):
+            raise NotImplementedError("encoder.feature_sample_local_radius > 0 (gmflow/utils.py:136-162) is not "
+                                      "built; every shipped config uses 0 (base.yaml:27)")
+        self._ws = None
+        self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
+
+    # ------------------------------------------------------------------ forward (matchnerf.py:32-73)
+    def forward(self, batch, mode=None, render_video=False, render_path_mode="interpolate"):
+        if mode == "train" and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "mode='train' under autograd needs the backward kernels of the HIP path "
+                "(SURVEY.md §8f, next); run under torch.no_grad() to evaluate the random-ray path")
+        ref_images = batch.images[:, :self.n_src_views]
+        ref_feats_list = self.get_img_feat(ref_images, attn_splits_list=self.opts.encoder.attn_splits_list,
+                                           cur_n_src_views=self.n_src_views)
+        tgt_pose, ref_poses = self.extract_poses(batch)
+        batch_size, _, _, img_h, img_w = ref_images.shape
+
+        if render_video:
+            assert mode in ["test", "val"], f"Do NOT render video in mode {mode}, change to either 'test' or 'val'."
+            poses_paths = self.get_video_rendering_path(tgt_pose, ref_poses, render_path_mode,
+                                                        self.opts.nerf.video_n_frames, batch)
+        else:
+            poses_paths = [tgt_pose]
+
+        mode_rand_rays = getattr(self.opts.nerf, f"rand_rays_{mode}", 0)
+        collected = {}
+        for cur_tgt_pose in poses_paths:
+            if mode_rand_rays and mode in ["train", "test-optim"]:
+                batch.ray_idx = torch.randperm(img_h * img_w, device=ref_images.device)[:mode_rand_rays // batch_size]
+                ret = self.render(self.opts, cur_tgt_pose, ray_idx=batch.ray_idx, mode=mode, ref_poses=ref_poses,
+                                  ref_images=ref_images, ref_feats_list=ref_feats_list)
+            elif mode_rand_rays:
+                ret = self.render_by_slices(self.opts, cur_tgt_pose, mode=mode, ref_poses=ref_poses,
+                                            ref_images=ref_images, ref_feats_list=ref_feats_list)
+            else:
+                ret = self.render(self.opts, cur_tgt_pose, mode=mode, ref_poses=ref_poses, ref_images=ref_images,
+                                  ref_feats_list=ref_feats_list)
+            for k, v in ret.items():
+                collected.setdefault(k, []).append(v.detach().cpu() if render_video else v)
+        for k, v in collected.items():
+            batch[k] = torch.cat(v, dim=0)
+        return batch
+
+    def extract_poses(self, batch):
+        """matchnerf.py:75-86: target = LAST view, sources = all the others."""
+        tgt_pose = dict(extrinsics=batch.extrinsics[:, -1, :3, :], intrinsics=batch.intrinsics[:, -1],
+                        near_fars=batch.near_fars[:, -1])
+        ref_poses = dict(extrinsics=batch.extrinsics[:, :-1, :3, :], intrinsics=batch.intrinsics[:, :-1],
+                         near_fars=batch.near_fars[:, :-1])
+        return tgt_pose, ref_poses
+
+    # ------------------------------------------------------------------ encoder (matchnerf.py:183-207)
+    def get_img_feat(self, imgs, attn_splits_list=None, cur_n_src_views=3):
+        """-> list over scales of pair-major channel-last maps [B,P,2,h,w,128]
+        (``gmflow.pair_major_to_view_chunks`` converts to the reference's [B,V,(V-1)*128,h,w])."""
+        if attn_splits_list is None:
+            attn_splits_list = self.opts.encoder.attn_splits_list
+        return self.feat_enc(imgs=imgs[:, :cur_n_src_views], attn_splits_list=attn_splits_list,
+                             wo_self_attn=self.opts.encoder.wo_self_attn)
+
+    # ------------------------------------------------------------------ C-ABI argument structs
+    def _scene(self, b, ref_poses_host, ref_feats_list, images_cl):
+        sc = hip.Scene()
+        sc.n_views, sc.n_scales = self.n_src_views, len(ref_feats_list)
+        groups = self.opts.encoder.cos_n_group
+        groups = [groups] if isinstance(groups, int) else list(groups)
+        assert len(groups) == len(ref_feats_list), "cos_n_group needs one entry per feature scale"
+        for s, f in enumerate(ref_feats_list):
+            sc.fh[s], sc.fw[s] = f.shape[3], f.shape[4]
+            sc.n_group[s] = groups[s]
+            sc.feat[s] = f[b].data_ptr()
+        sc.images = images_cl[b].data_ptr()
+        ex, it, nf = ref_poses_host
+        for v in range(self.n_src_views):
+            sc.views[v] = hip.make_view(ex[b, v], it[b, v], nf[b, v, 0], nf[b, v, 1])
+        return sc
+
+    def _decoder(self, n_samples, device):
+        ws, small, cond_stride = self.nerf_dec.packed(n_samples, device)
+        d = hip.Decoder()
+        d.wstream, d.wstream_floats, d.small_ = ws.data_ptr(), ws.numel(), small.data_ptr()
+        d.n_views, d.cond_dim, d.cond_stride = self.n_src_views, self.nerf_dec.cond_dim, cond_stride
+        d.L_3D = self.nerf_dec.L_3D
+        dec, nerf = self.opts.decoder, self.opts.nerf
+        d.raytrans_posenc, d.raytrans_elu = int(bool(dec.raytrans_posenc)), int(dec.raytrans_act == "ELU")
+        d.density_maskfill, d.wo_render_interval = int(bool(dec.density_maskfill)), int(bool(nerf.wo_render_interval))
+        d.setbg_opaque = int(bool(self.nerf_setbg_opaque))
+        return d
+
+    def _workspace(self, n_floats, device):
+        if self._ws is None or self._ws.numel() < n_floats or self._ws.device != device:
+            self._ws = torch.empty(n_floats, device=device)
+        return self._ws
+
+    @staticmethod
+    def _host(t):
+        return t.detach().float().cpu().numpy()
+
+    # ------------------------------------------------------------------ render (matchnerf.py:88-143)
+    def render(self, opt, tgt_pose=None, ray_idx=None, mode=None, ref_poses=None, ref_images=None,
+               ref_feats_list=None):
+        """Rays of one target pose -> edict(rgb [B,N,3], depth [B,N,1], opacity [B,N,1]).
+        ``ray_idx`` (LongTensor [N], shared by the batch) selects pixels; None = full image."""
+        if tgt_pose is None:
+            raise Exception("Must provide tgt_pose.")
+        if not ref_images.is_cuda:
+            raise RuntimeError("MatchNeRF.render: the HIP render path needs CUDA tensors (no CPU fallback)")
+        batch_size, _, _, img_h, img_w = ref_images.shape
+        device = ref_images.device
+        n_samples = int(opt.nerf.sample_intvs)
+        legacy = bool(opt.nerf.legacy_coord)
+        n_rays = img_h * img_w if ray_idx is None else int(ray_idx.numel())
+        idx32 = None if ray_idx is None else ray_idx.to(device=device, dtype=torch.int32).contiguous()
+        stratified = mode == "train" and bool(opt.nerf.sample_stratified)
+
+        # one small device->host copy per call for the camera matrices (kernel arguments)
+        ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
+                    self._host(ref_poses["near_fars"]))
+        tgt_ex, tgt_in, tgt_nf = (self._host(tgt_pose[k]) for k in ("extrinsics", "intrinsics", "near_fars"))
+        images_cl = torch.zeros(batch_size, self.n_src_views, img_h, img_w, 4, device=device)
+        images_cl[..., :3] = ref_images.permute(0, 1, 3, 4, 2)
+        dec = self._decoder(n_samples, device)
+        chunk = min(n_rays, MAX_RAYS_PER_LAUNCH)
+        ws = self._workspace(hip.render_workspace_bytes(chunk, n_samples, dec.cond_stride) // 4, device)
+
+        rgb = torch.empty(batch_size, n_rays, 3, device=device)
+        depth = torch.empty(batch_size, n_rays, 1, device=device)
+        opacity = torch.empty(batch_size, n_rays, 1, device=device)
+        for b in range(batch_size):
+            sc = self._scene(b, ref_host, ref_feats_list, images_cl)
+            kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
+            strat = torch.rand(n_rays, n_samples, device=device) if stratified else None
+            for c in range(0, n_rays, chunk):
+                m = min(chunk, n_rays - c)
+                rays = hip.make_rays(
+                    m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1], ray_begin=c, legacy=legacy,
+                    depth_inverse=(opt.nerf.depth.param == "inverse"),
+                    ray_idx_ptr=None if idx32 is None else idx32[c:].data_ptr(),
+                    strat_u_ptr=None if strat is None else strat[c:].data_ptr())
+                hip.render_chunk(sc, dec, rays, ws, rgb[b, c:c + m], depth[b, c:c + m], opacity[b, c:c + m],
+                                 timer=self.kernel_timer)
+        return edict(rgb=rgb, depth=depth, opacity=opacity)
+
+    def render_by_slices(self, opt, tgt_pose, mode=None, ref_poses=None, ref_images=None, ref_feats_list=None):
+        """matchnerf.py:145-161.  The reference loops over ``rand_rays_<mode>``-sized slices to
+        bound memory; the fused kernels have no such temporaries, so the full image is rendered
+        in launches of up to MAX_RAYS_PER_LAUNCH rays (identical results, see module docstring)."""
+        assert ref_images is not None, "Must provide the reference images for MatchNeRF."
+        return self.render(opt, tgt_pose, ray_idx=None, mode=mode, ref_poses=ref_poses, ref_images=ref_images,
+                           ref_feats_list=ref_feats_list)
+
+    # ------------------------------------------------------------------ API-compat helpers
+    def sample_depth(self, opt, batch_size, num_rays, near_far, legacy=False, mode="train"):
+        """matchnerf.py:163-181 (torch; the kernels evaluate the same expression in-register)."""
+        s = opt.nerf.sample_intvs
+        dev = near_far.device
+        depth_min, depth_max = near_far[:, :1], near_far[:, 1:]
+        if mode == "train" and opt.nerf.sample_stratified:
+            t = torch.rand(batch_size, num_rays, s, 1, device=dev)
+        else:
+            t = (0.0 if legacy else 0.5) * torch.ones(batch_size, num_rays, s, 1, device=dev)
+        t = t + torch.arange(s, device=dev)[None, None, :, None].float()
+        d = t / ((s - 1) if legacy else s) * (depth_max - depth_min).reshape(batch_size, 1, 1, 1) \
+            + depth_min.reshape(batch_size, 1, 1, 1)
+        return dict(metric=d, inverse=1 / (d + 1e-8))[opt.nerf.depth.param]
+
+    def query_cond_info(self, point_samples, ref_poses, ref_images, ref_feats_list, tgt_pose=None, ray_idx=None):
+        """matchnerf.py:209-293 through the K1+K2 kernel.  The kernel rebuilds the sample points
+        from the target pose, so ``tgt_pose`` (+ optional ``ray_idx``) replaces ``point_samples``
+        (kept in the signature for call compatibility; only its shape is used)."""
+        if tgt_pose is None:
+            raise NotImplementedError("query_cond_info needs tgt_pose: the HIP kernel regenerates the 3D samples")
+        b_n, n_rays, n_samples = point_samples.shape[:3]
+        _, v, _, img_h, img_w = ref_images.shape
+        device = ref_images.device
+        ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
+                    self._host(ref_poses["near_fars"]))
+        images_cl = torch.zeros(b_n, v, img_h, img_w, 4, device=device)
+        images_cl[..., :3] = ref_images.permute(0, 1, 3, 4, 2)
+        dc = self.nerf_dec.cond_dim
+        stride = ((dc + 1 + 7) // 8) * 8
+        sum_g = dc - 4 * v
+        out = torch.empty(b_n, n_rays * n_samples, stride, device=device)
+        idx32 = None if ray_idx is None else ray_idx.to(device=device, dtype=torch.int32).contiguous()
+        for b in range(b_n):
+            sc = self._scene(b, ref_host, ref_feats_list, images_cl)
+            kinv, c2w = camera.target_ray_consts(self._host(tgt_pose["extrinsics"])[b], self._host(tgt_pose["intrinsics"])[b],
+                                                 bool(self.opts.nerf.legacy_coord))
+            nf = self._host(tgt_pose["near_fars"])[b]
+            rays = hip.make_rays(n_rays, n_samples, img_h, img_w, kinv, c2w, nf[0], nf[1],
+                                 legacy=bool(self.opts.nerf.legacy_coord),
+                                 depth_inverse=(self.opts.nerf.depth.param == "inverse"),
+                                 ray_idx_ptr=None if idx32 is None else idx32.data_ptr())
+            hip.cost_volume(sc, rays, stride, out=out[b])
+        out = out.reshape(b_n, n_rays, n_samples, stride)
+        return dict(feat_info=out[..., :sum_g], color_info=out[..., sum_g:sum_g + 3 * v],
+                    mask_info=out[..., sum_g + 3 * v:dc])
+
+    def get_img_feat_view_chunks(self, imgs):
+        """``get_img_feat`` in the reference's return format [B,V,(V-1)*128,h,w] per scale."""
+        return [pair_major_to_view_chunks(f) for f in self.get_img_feat(imgs, cur_n_src_views=self.n_src_views)]
+
+    # ------------------------------------------------------------------ video paths (matchnerf.py:295-325)
+    def get_video_rendering_path(self, tgt_pose, ref_poses, mode, n_frames=30, batch=None):
+        from . import video
+        device = tgt_pose["extrinsics"].device
+        per_batch = []
+        for bi, src in enumerate(ref_poses["extrinsics"]):
+            if mode == "interpolate":
+                sq = torch.eye(4).repeat(src.shape[0], 1, 1)
+                sq[:, :3] = src.detach().cpu()
+                c2ws = sq.double().inverse()[:, :3].float().numpy()
+                path = video.interpolate_render_path(c2ws, n_frames)
+            elif mode == "spiral":
+                assert batch is not None, "Must provide all c2ws and near_far for getting spiral rendering path."
+                c2ws_all = batch["c2ws_all"][bi].detach().cpu().numpy()
+                nf = tgt_pose["near_fars"][bi].detach().cpu().numpy().tolist()
+                path = video.spiral_render_path(c2ws_all, nf, rads_scale=getattr(self.opts.nerf, "video_rads_scale", 0.1),
+                                                n_views=n_frames)
+            else:
+                raise Exception(f"Unknown video rendering path mode {mode}")
+            per_batch.append(torch.tensor(np.asarray(path)).inverse()[:, :3].to(torch.float32).to(device))
+        paths = torch.stack(per_batch, 0)
+        # the reference indexes frames 0..n_frames-1 of the path (matchnerf.py:319-323)
+        return [dict(extrinsics=paths[:, i], intrinsics=tgt_pose["intrinsics"].clone().detach(),
+                     near_fars=tgt_pose["near_fars"].clone().detach()) for i in range(n_frames)]

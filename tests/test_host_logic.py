@@ -1,0 +1,104 @@
+"""CPU-only checks of the host side: state_dict layout, registry, video paths, ABI exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from matchnerf_amd import hip, options, synthetic as syn, video
+from matchnerf_amd.edict import EasyDict
+
+
+def _opts(**over):
+    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt.device = "cpu"
+    for k, v in over.items():
+        node = opt
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return opt
+
+
+def test_state_dict_keys_and_shapes_match_reference_layout():
+    """153 tensors, same names / order / shapes as the reference module
+    (the spec itself is asserted equal to the reference's state_dict in tools/gen_golden.py)."""
+    from matchnerf_amd.models import models_dict
+    for v in (3, 4):
+        model = models_dict["matchnerf"](_opts(n_src_views=v))
+        sd = model.state_dict()
+        spec = syn.state_dict_spec(n_src_views=v)
+        assert list(sd.keys()) == list(spec.keys())
+        for k, t in sd.items():
+            assert tuple(t.shape) == spec[k], k
+        assert [n for n, _ in model.named_children()] == ["feat_enc", "nerf_dec"]
+        assert [n for n, _ in model.feat_enc.named_children()] == ["backbone", "transformer", "featup_net"]
+        model.load_state_dict(syn.to_torch(syn.seeded_state_dict(spec, 1)), strict=True)
+
+
+def test_checkpoint_roundtrip_per_child(tmp_path):
+    """misc/utils.py:183-205 semantics: {model: state_dict} restored per top-level child, strict."""
+    from matchnerf_amd import checkpoint
+    from matchnerf_amd.models import models_dict
+    m1 = models_dict["matchnerf"](_opts())
+    m1.load_state_dict(syn.to_torch(syn.seeded_state_dict(syn.state_dict_spec(), 5)))
+    path = checkpoint.save_checkpoint(str(tmp_path), dict(model=m1.state_dict(), epoch=3, iter=7), ep=3, it=7)
+    m2 = models_dict["matchnerf"](_opts())
+    ep, it = checkpoint.restore_checkpoint(m2, path, "cpu")
+    assert (ep, it) == (None, None)
+    for (k1, a), (k2, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(a, b)
+
+
+def test_unsupported_architectures_fail_loudly():
+    from matchnerf_amd.models import models_dict
+    with pytest.raises(NotImplementedError):
+        models_dict["matchnerf"](_opts(**{"decoder.net_width": 256}))
+    with pytest.raises(NotImplementedError):
+        models_dict["matchnerf"](_opts(**{"decoder.posenc.L_view": 4}))
+
+
+def test_render_refuses_cpu_tensors():
+    from matchnerf_amd.models import models_dict
+    model = models_dict["matchnerf"](_opts())
+    sc = syn.make_scene(32, 32, 3)
+    batch = EasyDict({k: torch.from_numpy(v) for k, v in sc.items()})
+    with pytest.raises((RuntimeError, hip.MnerfError)):
+        with torch.no_grad():
+            model(batch, mode="test")
+
+
+def test_video_paths_match_reference(golden):
+    g = golden("video_paths")
+    assert np.allclose(video.interpolate_render_path(g["c2ws"], 8), g["interpolate"], atol=1e-6)
+    assert np.allclose(video.spiral_render_path(g["c2ws"], [2.0, 6.0], rads_scale=0.3, n_views=8), g["spiral"], atol=1e-6)
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports exactly what include/mnerf.h declares."""
+    lib = hip.load()
+    assert lib.mnerf_abi_version() == hip.MNERF_ABI_VERSION
+    header = open(os.path.join(REPO, "include", "mnerf.h")).read()
+    declared = sorted(set(re.findall(r"\b(mnerf_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mnerf_last_error() is not None
+    # host-only entry points are callable without a GPU
+    assert lib.mnerf_render_workspace_bytes(4096, 64, 24) == 4096 * 64 * 24 * 4
+    from matchnerf_amd import cond_nerf as CN
+    for cs, L in ((24, 10), (56, 10), (24, 6)):
+        assert lib.mnerf_decoder_wstream_floats(cs, L) == CN.decoder_schedule(cs, L)[1]
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors of the by-value structs have the sizes the C side was compiled with."""
+    lib = hip.load()
+    for which, st in enumerate((hip.View, hip.Rays, hip.Scene, hip.Decoder)):
+        assert lib.mnerf_struct_size(which) == ctypes.sizeof(st), st.__name__
+    assert lib.mnerf_struct_size(99) == -1
+    assert ctypes.sizeof(hip.View) == 23 * 4

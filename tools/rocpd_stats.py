@@ -1,0 +1,34 @@
+"""Summarise a rocprofv3 (ROCm 7.x) rocpd sqlite database into a per-kernel stats table,
+the same content `rocprofv3 --stats` prints as kernel_stats.csv in older releases.
+
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db > profiles/r1_kernel_stats.md
+"""
+import sqlite3
+import sys
+
+
+def main(path, top=40):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    for name, s, e in rows:
+        d = (e - s) / 1e3  # ns -> us
+        a = agg.setdefault(name, [0, 0.0, 1e30, 0.0])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    print(f"# kernel stats from {path.split('/')[-1]}: {len(rows)} dispatches, {total / 1e3:.3f} ms total GPU kernel time\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        short = name if len(name) < 110 else name[:107] + "..."
+        print(f"| `{short}` | {a[0]} | {a[1] / 1e3:.3f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | {a[3]:.1f} | {100 * a[1] / total:.2f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
