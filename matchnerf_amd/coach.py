@@ -1,0 +1,118 @@
+"""Thin orchestration counterpart of the reference's Coach for INFERENCE (coach.py:27-146,
+368-529): build the network from the registry, restore a checkpoint per child, iterate test
+batches, call the hot path, report PSNR.  The training loop, TensorBoard, SSIM/LPIPS and the
+on-disk datasets are callers / data formats outside the hot path — a dataset is
+anything that yields batches with the reference's contract (images, extrinsics, intrinsics,
+near_fars[, depth, scene, view_ids]); ``synthetic`` is built in so the tool runs offline."""
+import os
+
+import numpy as np
+import torch
+
+from . import checkpoint, metrics, synthetic
+from .edict import EasyDict as edict
+from .models import models_dict
+
+
+class SyntheticScenes:
+    """Seeded stand-in for a dataset (no DTU/LLFF/Blender data offline)."""
+
+    def __init__(self, name, cfg, n_src_views):
+        self.name = name
+        w, h = cfg.get("img_wh", [64, 64])
+        self.kw = dict(height=h, width=w, n_src_views=n_src_views, wide=(name == "blender"),
+                       near_far=(2.0, 6.0) if name == "blender" else (2.125, 4.525))
+        n = cfg.get("max_len", -1)
+        self.n = 2 if n in (None, -1) else n
+
+    def get_name(self):
+        return self.name
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        for i in range(self.n):
+            sc = synthetic.make_scene(seed=100 + i, **self.kw)
+            batch = {k: torch.from_numpy(v) for k, v in sc.items()}
+            batch["scene"] = [f"synthetic{i}"]
+            batch["view_ids"] = torch.arange(self.kw["n_src_views"] + 1)[None]
+            yield batch
+
+
+class Coach:
+    def __init__(self, opts):
+        self.opts = opts
+        self.n_src_views = opts.n_src_views
+        self.device = opts.device
+
+    def build_networks(self):
+        self.model = models_dict[self.opts.model](self.opts).to(self.opts.device)  # coach.py:77
+
+    def restore_checkpoint(self):
+        path = self.opts.load
+        if path and os.path.isfile(path):
+            checkpoint.restore_checkpoint(self.model, path, self.opts.device)
+        else:
+            print(f"[coach] checkpoint {path!r} not found: using seeded random weights (offline run)")
+            spec = synthetic.state_dict_spec(n_src_views=self.n_src_views)
+            self.model.load_state_dict(synthetic.to_torch(synthetic.seeded_state_dict(spec, 1), self.opts.device))
+
+    def load_dataset(self, splits=("test",), loaders=None):
+        """``loaders``: optional list of iterables of batches (objects with get_name()); otherwise
+        every ``data_test`` entry is served by the synthetic generator at that entry's img_wh."""
+        if loaders is not None:
+            self.test_loaders = list(loaders)
+            return
+        self.test_loaders = [SyntheticScenes(name, cfg, self.n_src_views)
+                             for name, cfg in self.opts.data_test.items() if cfg is not None]
+
+    @torch.no_grad()
+    def test_model(self, save_images=False, **kwargs):
+        """coach.py:368-453, PSNR only -> {dataset: {image_id: psnr}}."""
+        self.model.eval()
+        out_root = os.path.join(self.opts.output_path, "test")
+        os.makedirs(out_root, exist_ok=True)
+        report = {}
+        for loader in self.test_loaders:
+            name = loader.get_name()
+            report[name] = {}
+            self.model.nerf_setbg_opaque = (name == "blender")  # coach.py:382-383
+            for bi, batch in enumerate(loader):
+                var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
+                gt_depth = var.pop("depth") if "depth" in var else None  # forward overwrites 'depth'
+                var = self.model(var, mode="test")
+                b, _, _, h, w = var.images.shape
+                pred = var.rgb.reshape(b, h, w, 3).cpu().numpy()
+                gt = var.images[:, -1].permute(0, 2, 3, 1).cpu().numpy()
+                for i in range(b):
+                    mask = None if gt_depth is None else (gt_depth[i].cpu().numpy() == 0)
+                    report[name][f"{name}_{bi:03d}_{i}"] = metrics.psnr(pred[i], gt[i], mask)
+                    if save_images:
+                        from PIL import Image
+                        vis = np.concatenate([pred[i], gt[i]], 1)
+                        Image.fromarray((vis.clip(0, 1) * 255).astype("uint8")).save(
+                            os.path.join(out_root, f"{name}_{bi:03d}_{i}.png"))
+            self.model.nerf_setbg_opaque = False
+            vals = list(report[name].values())
+            with open(os.path.join(out_root, f"0results_{name}.txt"), "w") as f:
+                for k, v in report[name].items():
+                    f.write(f"{k}: PSNR {v:.4f}\n")
+                f.write(f"mean PSNR {np.mean(vals):.4f}\n")
+            print(f"[coach] {name}: mean PSNR {np.mean(vals):.2f} over {len(vals)} images")
+        return report
+
+    @torch.no_grad()
+    def test_model_video(self, **kwargs):
+        """coach.py:455-529 without the encoders: returns {dataset: frames [F,H,W,3] uint8}."""
+        self.model.eval()
+        videos = {}
+        for loader in self.test_loaders:
+            mode = getattr(getattr(self.opts.data_test, loader.get_name(), {}), "render_path_mode", "interpolate")
+            for batch in loader:
+                var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
+                var = self.model(var, mode="test", render_video=True, render_path_mode=mode)
+                _, _, _, h, w = var.images.shape
+                videos[loader.get_name()] = (var.rgb.reshape(-1, h, w, 3).clamp(0, 1) * 255).to(torch.uint8).numpy()
+                break
+        return videos

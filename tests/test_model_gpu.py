@@ -142,3 +142,20 @@ def test_batch_of_two_equals_two_batches_of_one():
         for b in range(2):
             one = model(EasyDict({k: torch.from_numpy(v[b:b + 1]).cuda() for k, v in sc.items()}), mode="test")
             assert linf(both.rgb[b], one.rgb[0]) < 1e-6
+
+
+def test_coach_test_model_reports_psnr(tmp_path, monkeypatch):
+    """thin harness (reference: test.py + Coach.test_model): options -> model -> PSNR report"""
+    from matchnerf_amd.coach import Coach
+    monkeypatch.chdir(tmp_path)
+    cmd = options.parse_arguments(["--yaml=test", "--name=harness", "--nerf.sample_intvs=32",
+                                   "--data_test.llff=", "--data_test.blender=", "--data_test.tnt=",
+                                   "--data_test.dtu.img_wh=48,32", "--data_test.dtu.max_len=1"])
+    opt = options.set(cmd, verbose=False)
+    c = Coach(opt)
+    c.build_networks()
+    c.restore_checkpoint()
+    c.load_dataset()
+    rep = c.test_model()
+    assert list(rep) == ["dtu"] and len(rep["dtu"]) == 1
+    assert all(np.isfinite(v) and 0 < v < 60 for v in rep["dtu"].values())
