@@ -111,4 +111,30 @@ __device__ __forceinline__ void project(const mnerf_view& V, float px, float py,
   float span = V.far_ - V.near_;
   z = (q2 - V.near_) / span;
 }
+
+// sin(arg) (quarter = 0) or cos(arg) (quarter = 1) for the positional encoding, |arg| up to a
+// few thousand.  The argument is reduced in revolutions with a two-float 1/(2 pi) (product error
+// term recovered by FMA — which is why contraction must stay OFF here: fusing `th - rint(th)`
+// would count that term twice), cos is sin shifted by a quarter turn, and sin(2 pi r) on
+// [-1/4, 1/4] is a degree-9 odd minimax polynomial.  Max abs error 3.0e-7 over |arg| <= 2000
+// (tools/exp/sincos_poly.hip, measured on MI355X) versus 0.7e-7 for ocml sincosf at ~8x the
+// instruction count; v_sin_f32 / v_cos_f32 alone are only good to 8e-5.
+__device__ __forceinline__ float sin_quarter(float arg, int quarter) {
+  const float C_HI = 0.15915494309189535f;
+  const float C_LO = (float)(0.15915494309189535 - (double)0.15915494309189535f);
+  float th = arg * C_HI;
+  float tl = __builtin_fmaf(arg, C_LO, __builtin_fmaf(arg, C_HI, -th));
+  float r = th - rintf(th);
+  r = r + (tl + (quarter ? 0.25f : 0.0f));
+  r = r - rintf(r);
+  float a = fabsf(r);
+  r = (a > 0.25f) ? (copysignf(0.5f, r) - r) : r;
+  float x2 = r * r;
+  float p = 39.536705017089844f;
+  p = __builtin_fmaf(p, x2, -76.5497817993164f);
+  p = __builtin_fmaf(p, x2, 81.60100555419922f);
+  p = __builtin_fmaf(p, x2, -41.34165573120117f);
+  p = __builtin_fmaf(p, x2, 6.283185005187988f);
+  return p * r;
+}
 #pragma clang fp contract(fast)

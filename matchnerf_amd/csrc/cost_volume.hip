@@ -84,26 +84,48 @@ __device__ __forceinline__ float group_reduce(float v, int lanes_per_group) {
   }
 }
 
-__global__ __launch_bounds__(256) void cost_volume_kernel(mnerf_scene sc, mnerf_rays R,
+#ifndef CV_WAVES_PER_SIMD
+#define CV_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mnerf_scene sc, mnerf_rays R,
                                                           int cond_stride,
                                                           float* __restrict__ cond) {
   const int sub = threadIdx.x & 7;
-  const int slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-  const int n_slots = (gridDim.x * blockDim.x) >> 3;
+  const int slot_in_wg = threadIdx.x >> 3;  // 32 sample slots per workgroup
   const int S = R.n_samples;
-  const long long n_samples_total = (long long)R.n_rays * S;
   const int V = sc.n_views;
   const int P = V * (V - 1) / 2;
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
   const int sumG = sc.n_group[0] + (sc.n_scales > 1 ? sc.n_group[1] : 0);
   const float inv_pairs = 1.0f / (float)P;
 
-  // all lanes of a wave iterate the same number of times (shuffles need full slots)
-  const long long iters = (n_samples_total + n_slots - 1) / n_slots;
-  for (long long it = 0; it < iters; ++it) {
-    long long s_idx = it * n_slots + slot;
-    const bool live = s_idx < n_samples_total;
-    if (!live) s_idx = n_samples_total - 1;  // keep the lanes busy on a valid sample
+  // Work mapping.  Samples are cut into contiguous chunks, one per workgroup, and chunk ids are
+  // assigned XCD-major: the dispatcher places workgroup b on XCD b % 8 (observed, speed only),
+  // so XCD x walks chunks [x*cpx, (x+1)*cpx) = one compact band of the image.  Its L2 then
+  // holds just that band's epipolar texels instead of every resident workgroup sweeping the
+  // whole frame (a grid-stride mapping fetched 7 GB/frame past L2 for 95 MB of maps).
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;  // bijective remap also when nwg % 8 != 0
+  const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin;
+  // A workgroup iteration covers 32 ADJACENT RAYS at ONE depth index (slot = ray), then steps
+  // along the depth: neighbouring pixels project a fraction of a texel apart, so the 8 slots of
+  // a wave mostly ask for the same 128-byte lines in one load instruction and the lines are
+  // re-used again by the next depth steps (temporal L1 reuse).  One chunk = a run of 32-ray
+  // blocks; all lanes of a wave iterate the same number of times (shuffles need full slots).
+  const long long blocks_total = ((long long)R.n_rays + 31) / 32;   // 32-ray blocks
+  const long long bpc = (blocks_total + nwg - 1) / nwg;             // blocks per chunk
+  const long long b_begin = (long long)chunk * bpc;
+  long long b_end = b_begin + bpc;
+  if (b_end > blocks_total) b_end = blocks_total;
+
+  for (long long it = b_begin * S; it < b_end * S; ++it) {
+    const long long rb = it / S;
+    const int j_it = (int)(it - rb * S);
+    long long ray_ll = rb * 32 + slot_in_wg;
+    const bool live = ray_ll < R.n_rays;
+    if (!live) ray_ll = R.n_rays - 1;  // keep the lanes busy on a valid ray
+    long long s_idx = ray_ll * S + j_it;
     const int ray = (int)(s_idx / S);
     const int j = (int)(s_idx - (long long)ray * S);
     const RayGeom g = make_ray(R, ray);
@@ -221,7 +243,7 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   if (rays->n_rays == 0) return MNERF_OK;
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
   hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      *scene, *rays, cond_stride, cond);
   return mnerf_check_launch("mnerf_cost_volume");

@@ -16,7 +16,7 @@ MNERF_MAX_VIEWS = 16
 SMALL_FIXED = 1360  # floats of the `small` parameter block before the ray-posenc table
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
+_LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_render_workspace_bytes",

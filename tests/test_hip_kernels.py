@@ -164,7 +164,7 @@ def test_odd_sample_counts_match_oracle(hip):
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
     v = cfg.n_src_views
     pair_feats = [(f[:, 0].permute(0, 3, 1, 2).cpu(), f[:, 1].permute(0, 3, 1, 2).cpu()) for f in feats_gpu]
-    for S in (48, 100):
+    for S in (48, 100, 200):  # padded to 64 / 128 / 256 (the last one = 8-wave VALU-attention kernel)
         cfg.sample_intvs = S
         sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
         dec, keep = make_decoder_struct(cfg, sd)
