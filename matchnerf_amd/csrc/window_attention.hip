@@ -12,8 +12,8 @@
 // and the region mask are index arithmetic on the token id, and scores never leave registers.
 //
 // MFMA formulation (d = C = 128, one head).  A wave owns 32 queries (lane&31 = query n).
-//   S^T[key, n]  = sum_d K[key,d] Q[n,d]      : A = K tile (from LDS, row stride 129 floats so
-//                  the 32 lanes of a half-wave hit 32 distinct banks), B = Q (64 VGPRs/lane:
+//   S^T[key, n]  = sum_d K[key,d] Q[n,d]      : A = K tile (LDS image XOR-swizzled on the DMA
+//                  source side, read as conflict-free ds_read_b128), B = Q (64 VGPRs/lane:
 //                  half-wave hl holds d in [64hl, 64hl+64))
 //   O^T[d, n]   += sum_key V[key,d] P[n,key]  : A = V tile (natural row-major LDS image),
 //                  B = P — and P is *already* in B-operand layout: the C/D layout of S^T puts
@@ -21,13 +21,16 @@
 //                  what K-step r of the PV product needs.  No transpose, no LDS round trip.
 // Softmax statistics (running max / sum per query) are per-lane scalars; the two half-waves
 // of a query exchange them with one cross-half shuffle per tile.
+// K/V tiles (32 keys) are double-buffered in LDS by global_load_lds DMA: the copy of tile t+1
+// is in flight while tile t feeds 128 MFMAs per wave; one barrier per tile.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define WA_C 128
 #define WA_KT 32            // keys per tile
-#define WA_KSTRIDE 129      // padded K row (floats)
 
 struct WinGeom {
   int h, w, wh, ww, sh, sw, splits, Lw;
@@ -47,13 +50,53 @@ __device__ __forceinline__ int win_token(const WinGeom& G, int wy, int wx, int l
   return oy * G.w + ox;
 }
 
+// ---- LDS-DMA helpers (see decoder.hip: an asm global_load_lds is invisible to hipcc's
+// wait-count bookkeeping, so the prefetch of tile t+1 is not drained in front of tile t's reads)
+__device__ __forceinline__ void wa_glds16(const float* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+
+// One K/V tile = 32 keys x 128 channels of each matrix = 2 x 16 KiB, copied as 32 pieces of
+// 1 KiB (one wave instruction = 2 token rows).  V keeps its natural row-major image.  K is
+// swizzled on the SOURCE side: the 16-byte column group c4 of LDS row `key` holds channels
+// 4*(c4 ^ (key & 31)) .., so that the S^T operand read (32 lanes = 32 keys, same channel group)
+// hits 16 distinct 16-byte slots per ds_read_b128 lane group instead of one (row stride 512 B).
+template <int NQW>
+__device__ __forceinline__ void wa_stage_tile(const float* __restrict__ k, const float* __restrict__ v,
+                                              size_t seq_base, const WinGeom& G, int wy, int wx, int kt,
+                                              float* kbuf, float* vbuf, int wave, int lane) {
+  const int row_in_piece = lane >> 5, c4 = lane & 31;
+  const unsigned kb = (unsigned)(size_t)(__attribute__((address_space(3))) float*)kbuf;
+  const unsigned vb = (unsigned)(size_t)(__attribute__((address_space(3))) float*)vbuf;
+  for (int piece = wave; piece < 16; piece += NQW) {
+    const int key = piece * 2 + row_in_piece;
+    int li = kt * WA_KT + key;
+    if (li >= G.Lw) li = G.Lw - 1;
+    int reg_unused;
+    const int tok = win_token(G, wy, wx, li, reg_unused);
+    const size_t row = seq_base + (size_t)tok * WA_C;
+    wa_glds16(k + row + ((c4 ^ (key & 31)) << 2), __builtin_amdgcn_readfirstlane(kb + (unsigned)piece * 1024u));
+    wa_glds16(v + row + (c4 << 2), __builtin_amdgcn_readfirstlane(vb + (unsigned)piece * 1024u));
+  }
+}
+
 template <int NQW>
 __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, WinGeom G, int shifted, float scale) {
-  constexpr int NT = NQW * 64;
-  __shared__ __attribute__((aligned(16))) float kS[WA_KT * WA_KSTRIDE];
-  __shared__ __attribute__((aligned(16))) float vS[WA_KT * WA_C];
+  // double-buffered K and V tiles: [2][32 keys][128] each = 64 KiB per workgroup
+  extern __shared__ __attribute__((aligned(16))) float wa_smem[];
+#define WA_KBUF(i) (wa_smem + (i) * (WA_KT * WA_C))
+#define WA_VBUF(i) (wa_smem + (2 + (i)) * (WA_KT * WA_C))
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,7 +105,10 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
   const int wy = win / G.splits, wx = win - wy * G.splits;
   const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
 
-  // ---- this lane's query
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, 0, WA_KBUF(0), WA_VBUF(0), wave, lane);
+
+  // ---- this lane's query (half-wave hl holds channels [64 hl, 64 hl + 64))
   const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
   const bool q_ok = qi_raw < G.Lw;
   int q_region;
@@ -84,34 +130,26 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
   for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
   float m_run = -3.0e38f, l_run = 0.0f;
 
-  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (padded rows) and V (row-major) tiles: 32 keys x 128 ch
-    for (int idx = tid; idx < WA_KT * (WA_C / 4); idx += NT) {
-      const int key = idx >> 5, c4 = idx & 31;
-      int li = kt * WA_KT + key;
-      if (li >= G.Lw) li = G.Lw - 1;
-      int reg_unused;
-      const int tok = win_token(G, wy, wx, li, reg_unused);
-      const size_t off = seq_base + (size_t)tok * WA_C + c4 * 4;
-      const float4 kk = *reinterpret_cast<const float4*>(k + off);
-      const float4 vv = *reinterpret_cast<const float4*>(v + off);
-      float* kd = kS + key * WA_KSTRIDE + c4 * 4;
-      kd[0] = kk.x;
-      kd[1] = kk.y;
-      kd[2] = kk.z;
-      kd[3] = kk.w;
-      *reinterpret_cast<float4*>(vS + key * WA_C + c4 * 4) = vv;
-    }
-    __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
-    // ---- S^T = K Q^T  (64 K-steps over d)
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < n_tiles)  // DMA of the next tile overlaps this tile's 128 MFMAs
+      wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, kt + 1, WA_KBUF(cur ^ 1), WA_VBUF(cur ^ 1), wave, lane);
+
+    // ---- S^T = K Q^T  (64 K-steps over d; one swizzled ds_read_b128 feeds 4 steps)
     f32x16 s = (f32x16)(0.0f);
     {
-      const float* ka = kS + n * WA_KSTRIDE + hl * 64;
+      const float* krow = WA_KBUF(cur) + n * WA_C;
 #pragma unroll
-      for (int t = 0; t < 64; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[t], qreg[t], s, 0, 0, 0);
+      for (int q4 = 0; q4 < 16; ++q4) {
+        const float4 ka = *reinterpret_cast<const float4*>(krow + (((hl * 16 + q4) ^ n) << 2));
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.x, qreg[4 * q4 + 0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.y, qreg[4 * q4 + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.z, qreg[4 * q4 + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka.w, qreg[4 * q4 + 3], s, 0, 0, 0);
+      }
     }
     // ---- scale, masks, online softmax
     float tmax = -3.0e38f;
@@ -131,11 +169,11 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __expf(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = expf(s[r] - m_new);
+      const float p = __expf(s[r] - m_new);
       s[r] = p;
       psum += p;
     }
@@ -150,12 +188,14 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
-      const float* va = vS + key * WA_C + n;
+      const float* va = WA_VBUF(cur) + key * WA_C + n;
       o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s[r], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s[r], o[1], 0, 0, 0);
       o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[64], s[r], o[2], 0, 0, 0);
       o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[96], s[r], o[3], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile landed (this wave's pieces)
+    __syncthreads();                                   // ... all waves' pieces; current tile consumed
   }
   // ---- normalise and store: register quad (4g..4g+3) of block m = channels m*32+8g+4hl+{0..3}
   if (q_ok) {
@@ -198,12 +238,21 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   const float scale = 1.0f / sqrtf((float)WA_C);
   hipStream_t st = (hipStream_t)stream;
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * num_splits * num_splits * batch;
-  if (wgs4 >= 512) {
+  const size_t lds = 4 * WA_KT * WA_C * sizeof(float);  // 64 KiB: K and V tiles, double buffered
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)window_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  int min4 = 200;  // use 128-query workgroups once they (nearly) fill the 256 CUs
+  if (const char* e = getenv("MNERF_WA_MIN4")) min4 = atoi(e);
+  if (wgs4 >= min4) {
     dim3 grid((G.Lw + 127) / 128, num_splits * num_splits, batch);
-    hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), 0, st, q, k, v, out, G, do_shift, scale);
+    hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
   } else {
     dim3 grid((G.Lw + 63) / 64, num_splits * num_splits, batch);
-    hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), 0, st, q, k, v, out, G, do_shift, scale);
+    hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
   }
   return mnerf_check_launch("mnerf_window_attention");
 }
