@@ -22,9 +22,11 @@ input feature the lower / upper half-wave feeds at that step:
 * a bias is one more column multiplied by the constant 1 operand.
 
 Stages in consumption order (steps x output blocks):
-FiLM(stride/2 x4) L0(3L+2 x4) L1..L4(65 x4) L5-enc(3L+2 x4) L5-h(64 x4) alpha(65 x1)
-feature(65 x4) views(66 x2) rgb(33 x1); each stage is cut into segments of at most 33 KiB,
-each segment padded to a multiple of 256 floats (1 KiB DMA pieces).
+FiLM(stride/2 x4) L0(3L+2 x4) L1..L4(65 x4) L5-enc(3L+2 x4) L5-h(64 x4) feature(65 x4)
+views(66 x2) rgb(33 x1) alpha(65 x1) and a "tail" = [qkv(8 x2) | fc(8 x1) | out_alpha.0(9 x1) |
+out_alpha.2(9 x1)] — the ray-transformer projections and the density head, which stay resident
+in LDS across the attention phase.  Each stage is cut into segments of at most 33 KiB, each
+segment padded to a multiple of 256 floats (1 KiB DMA pieces); the tail is one segment.
 """
 import math
 
@@ -33,7 +35,10 @@ import torch
 import torch.nn as nn
 
 SEG_CAP_FLOATS = 33 * 256
-SMALL_FIXED = 1360
+SMALL_FIXED = 32  # floats of the `small` block before the ray-posenc table: LayerNorm weight | bias
+# sub-stages of the tail segment: name -> (float offset in segment, K-steps, output blocks)
+TAIL_LAYOUT = {"qkv": (0, 8, 2), "fco": (1024, 8, 1), "oa0": (1536, 9, 1), "oa2": (2112, 9, 1)}
+TAIL_FLOATS = 2688
 
 
 # ----------------------------------------------------------------------------- schedule
@@ -41,9 +46,9 @@ SMALL_FIXED = 1360
 
 def decoder_stages(cond_stride, L_3D):
     fs, es = cond_stride // 2, 3 * L_3D + 2
-    names = ["film", "l0", "l1", "l2", "l3", "l4", "l5e", "l5h", "alpha", "feature", "views", "rgb"]
-    steps = [fs, es, 65, 65, 65, 65, es, 64, 65, 65, 66, 33]
-    nmb = [4, 4, 4, 4, 4, 4, 4, 4, 1, 4, 2, 1]
+    names = ["film", "l0", "l1", "l2", "l3", "l4", "l5e", "l5h", "feature", "views", "rgb", "alpha"]
+    steps = [fs, es, 65, 65, 65, 65, es, 64, 65, 66, 33, 65]
+    nmb = [4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 1]
     return list(zip(names, steps, nmb))
 
 
@@ -63,6 +68,9 @@ def decoder_schedule(cond_stride, L_3D):
             segs.append((name, first, steps, m, off, fl))
             off += fl
             first += steps
+    fl = ((TAIL_FLOATS + 255) // 256) * 256
+    segs.append(("tail", 0, 0, 0, off, fl))
+    off += fl
     return segs, off
 
 
@@ -151,8 +159,25 @@ def pack_wstream(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_de
         frags[f"l{i}"] = _fragments(g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias"),
                                     h_lo + [BIAS], h_hi + [ZERO], 4)
     segs, total = decoder_schedule(cond_stride, L_3D)
+    # tail: ray-transformer projections [w_qs; w_ks; w_vs] (48 rows), fc, out_alpha_linear.{0,2}
+    a_lo, a_hi = _reg_order(1)
+    a_lo, a_hi = a_lo[:8], a_hi[:8]                       # 16 inputs held in registers 0..7 of one block
+    wqkv = np.concatenate([g("ray_attention.w_qs.weight"), g("ray_attention.w_ks.weight"),
+                           g("ray_attention.w_vs.weight")], 0)
+    tail = {
+        "qkv": _fragments(wqkv, None, a_lo, a_hi, 2),
+        "fco": _fragments(g("ray_attention.fc.weight"), None, list(range(8)), list(range(8, 16)), 1),
+        "oa0": _fragments(g("out_alpha_linear.0.weight"), g("out_alpha_linear.0.bias"), a_lo + [BIAS], a_hi + [ZERO], 1),
+        "oa2": _fragments(g("out_alpha_linear.2.weight"), g("out_alpha_linear.2.bias"), a_lo + [BIAS], a_hi + [ZERO], 1),
+    }
     out = np.zeros(total, np.float32)
     for name, first, steps, m, off, _ in segs:
+        if name == "tail":
+            for sub, (sub_off, t, nm) in TAIL_LAYOUT.items():
+                a = tail[sub]
+                assert a.shape == (t, 64, nm), (sub, a.shape)
+                out[off + sub_off:off + sub_off + a.size] = a.reshape(-1)
+            continue
         a = frags[name][first:first + steps]
         assert a.shape == (steps, 64, m), (name, a.shape, steps, m)
         out[off:off + a.size] = a.reshape(-1)
@@ -171,26 +196,16 @@ def raytrans_table(n_samples, d_hid=16):
 
 
 def pack_small(sd, n_samples, raytrans_posenc, prefix="nerf_dec."):
-    """Ray-transformer + density-head parameters:
-    [0:256) w_qs  [256:512) w_ks  [512:768) w_vs  [768:1024) fc   (row-major [out][in])
-    [1024:1040) ln.weight [1040:1056) ln.bias [1056:1312) out_alpha.0.weight [1312:1328) .0.bias
-    [1328:1344) out_alpha.2.weight [1344] .2.bias, zero pad to 1360, then the [S,16] posenc table."""
+    """Parameters that are not matrix operands: [0:16) LayerNorm weight, [16:32) LayerNorm bias of
+    the ray transformer, then the [S,16] sinusoid table when ``raytrans_posenc``."""
 
     def g(name):
         v = sd[prefix + name]
         return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32).reshape(-1)
 
     out = np.zeros(SMALL_FIXED + (n_samples * 16 if raytrans_posenc else 0), np.float32)
-    out[0:256] = g("ray_attention.w_qs.weight")
-    out[256:512] = g("ray_attention.w_ks.weight")
-    out[512:768] = g("ray_attention.w_vs.weight")
-    out[768:1024] = g("ray_attention.fc.weight")
-    out[1024:1040] = g("ray_attention.layer_norm.weight")
-    out[1040:1056] = g("ray_attention.layer_norm.bias")
-    out[1056:1312] = g("out_alpha_linear.0.weight")
-    out[1312:1328] = g("out_alpha_linear.0.bias")
-    out[1328:1344] = g("out_alpha_linear.2.weight")
-    out[1344] = g("out_alpha_linear.2.bias")[0]
+    out[0:16] = g("ray_attention.layer_norm.weight")
+    out[16:32] = g("ray_attention.layer_norm.bias")
     if raytrans_posenc:
         out[SMALL_FIXED:] = raytrans_table(n_samples).reshape(-1)
     return out

@@ -42,7 +42,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SEG_CAP_FLOATS (33 * 256)  // one LDS weight buffer: 33 KiB
 #define MAX_SEGS 40
-#define SMALL_FIXED 1360  // floats of `small` before the optional ray-posenc table
+#define SMALL_FIXED 32    // floats of `small` (LayerNorm weight | bias) before the ray-posenc table
+// tail segment (resident across the attention phase): float offsets of its sub-stages
+#define TAIL_QKV 0
+#define TAIL_FCO 1024
+#define TAIL_OA0 1536
+#define TAIL_OA2 2112
+#define TAIL_FLOATS 2688
 
 #ifdef MNERF_TIMELINE
 // debug build (tools/exp/timeline.py): per-wave s_memtime stamps at phase boundaries
@@ -152,6 +158,24 @@ __device__ __forceinline__ void steps_from_regs<4>(f32x16 (&acc)[4], const float
     cur = nxt;
   }
 }
+// 16 pipelined K-steps against 4 M-blocks fed from one 16-register block
+__device__ __forceinline__ void steps16_from_regs(f32x16 (&acc)[4], const float* seg, int step0, int lane,
+                                                  const f32x16& e) {
+  const float4* a4 = reinterpret_cast<const float4*>(seg) + step0 * 64 + lane;
+  float4 cur = a4[0];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float4 nxt = a4[(r + 1) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = mfma(cur.x, e[r], acc[0]);
+    acc[1] = mfma(cur.y, e[r], acc[1]);
+    acc[2] = mfma(cur.z, e[r], acc[2]);
+    acc[3] = mfma(cur.w, e[r], acc[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+}
+
 template <>
 __device__ __forceinline__ void steps_from_regs<2>(f32x16 (&acc)[2], const float* seg, int step0,
                                                    int lane, const f32x16& h0, const f32x16& h1) {
@@ -192,21 +216,29 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 
+// 16 consecutive positional-encoding operands (steps t0 .. t0+15) evaluated into registers, so
+// that the MFMA loop that consumes them is the same software-pipelined loop as a hidden layer
+__device__ __forceinline__ f32x16 enc_block16(int t0, int L3, int hl, float x, float y, float z,
+                                              float freq_mul) {
+  f32x16 e;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = enc_operand(t0 + i, L3, hl, x, y, z, freq_mul);
+  return e;
+}
+
 template <int NW, int SP>
 struct Smem {
   static constexpr int TILE = NW * 32;
   static constexpr int W_FLOATS = 2 * SEG_CAP_FLOATS;
-  static constexpr int A_FLOATS = TILE * 16;
   static constexpr int RS_FLOATS = TILE * 4;
-  // Ray-attention scratch lives on top of the (by then idle) weight double buffer.
+  static constexpr int LN_FLOATS = 64;
+  // Ray-attention scratch lives in the weight buffer that does NOT hold the resident tail segment.
   //   MFMA form (SP <= 128): K [rays][4][SP][4], V^T [rays][4][4][SP], Q [TILE][16], O [TILE][16]
   //   VALU form (SP  = 256): K|V interleaved [rays][4][SP][8]
-  // followed by a copy of the small parameter block.
   static constexpr bool MFMA_ATT = SP <= 128;
   static constexpr int KV_FLOATS = MFMA_ATT ? TILE * 64 : TILE * 32;
-  static constexpr int ATT_FLOATS = KV_FLOATS + SMALL_FIXED;
-  static constexpr bool ATT_ALIASED = ATT_FLOATS <= W_FLOATS;
-  static constexpr int TOTAL_FLOATS = W_FLOATS + A_FLOATS + RS_FLOATS + (ATT_ALIASED ? 0 : ATT_FLOATS);
+  static_assert(KV_FLOATS <= SEG_CAP_FLOATS, "attention scratch must fit one weight buffer");
+  static constexpr int TOTAL_FLOATS = W_FLOATS + RS_FLOATS + LN_FLOATS;
 };
 
 template <int NW, int SP>
@@ -220,15 +252,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wbuf0 = smem;
   float* wbuf1 = smem + SEG_CAP_FLOATS;
-  float* a_lds = smem + SM::W_FLOATS;                 // [TILE][16]  alpha features
-  float* rs_lds = a_lds + SM::A_FLOATS;               // [TILE][4]   rgb.xyz, sigma.w
-  float* att = SM::ATT_ALIASED ? smem : (rs_lds + SM::RS_FLOATS);
-  float* kv_lds = att;                                // VALU form: [rays][4 heads][Sp][8] (k0..3, v0..3)
-  float* k_lds = att;                                 // MFMA form
-  float* vt_lds = att + TILE * 16;
-  float* q_lds = att + TILE * 32;
-  float* o_lds = att + TILE * 48;
-  float* sm_lds = att + SM::KV_FLOATS;                // copy of small[0:SMALL_FIXED]
+  float* rs_lds = smem + SM::W_FLOATS;                // [TILE][4]   rgb.xyz, sigma.w
+  float* ln_lds = rs_lds + SM::RS_FLOATS;             // LayerNorm weight[16] | bias[16]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -264,6 +289,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     if (sch.stagger_mode == 11) { if (!slot_odd) __builtin_amdgcn_s_setprio(3); }
     if (sch.stagger_mode == 12) { if (slot_odd) { __builtin_amdgcn_s_setprio(3); for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127); } }
   }
+
+  if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
+  __syncthreads();
 
 #ifdef MNERF_TIMELINE
   int tl_tile = -1;
@@ -361,7 +389,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     f32x16 acc[4], h[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
-    {
+    if (sch.enc_steps == 32) {  // L_3D = 10 (every shipped config): one segment, register-fed
+      const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
+      const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+      SEG_BEGIN();
+      steps_from_regs<4>(acc, CUR_BUF, 0, lane, e0, e1);
+      SEG_END();
+    } else {
       int done = 0;
       while (done < sch.enc_steps) {
         const int ns = sch.seg_steps[seg];
@@ -400,7 +434,18 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // ------------------------------------------------------------ layer 5: [enc, h] -> 128
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
-    {
+    if (sch.enc_steps == 32) {  // register-fed in two halves of 16 (film + h + acc are live here)
+      SEG_BEGIN();
+      {
+        const f32x16 e = enc_block16(0, L3, hl, x, y, z, freq_mul);
+        steps16_from_regs(acc, CUR_BUF, 0, lane, e);
+      }
+      {
+        const f32x16 e = enc_block16(16, L3, hl, x, y, z, freq_mul);
+        steps16_from_regs(acc, CUR_BUF, 16, lane, e);
+      }
+      SEG_END();
+    } else {
       int done = 0;
       while (done < sch.enc_steps) {
         const int ns = sch.seg_steps[seg];
@@ -424,35 +469,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * film[m][r], 0.0f);
 
     TL_STAMP(5);
-    // ------------------------------------------------------------ alpha head: 128 -> 16
-    {
-      f32x16 al[1];
-      al[0] = (f32x16)(0.0f);
-      SEG_BEGIN();
-      const float* wseg = CUR_BUF;
-      steps_from_regs<1>(al, wseg, 0, lane, h[0], h[1]);
-      steps_from_regs<1>(al, wseg, 32, lane, h[2], h[3]);
-      step1(al[0], wseg, 64, lane, hl ? 0.0f : 1.0f);
-      // rows 0..15 <-> registers 0..7: feature o = (r&3) + 8*(r>>2) + 4*hl
-      float av[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        float t = al[0][r];
-        t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
-        av[r] = t;
-      }
-      if (D.raytrans_posenc) {
-        const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
-      }
-      float4* dst = reinterpret_cast<float4*>(a_lds + s_local * 16);
-      dst[hl] = make_float4(av[0], av[1], av[2], av[3]);          // features 0-3 | 4-7
-      dst[2 + hl] = make_float4(av[4], av[5], av[6], av[7]);      // features 8-11 | 12-15
-      SEG_END();
-    }
-
-    TL_STAMP(6);
     // ------------------------------------------------------------ feature_linear: 128 -> 128
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     step4(acc, CUR_BUF, 32, lane, hl ? 0.0f : 1.0f);
     SEG_END();
 
-    TL_STAMP(7);
+    TL_STAMP(6);
     // ------------------------------------------------------------ views_linear: [feat, dir] -> 64
     f32x16 hv[2];
     hv[0] = (f32x16)(0.0f);
@@ -483,12 +499,12 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) hv[m][r] = fmaxf(hv[m][r], 0.0f);
 
-    TL_STAMP(8);
+    TL_STAMP(7);
     // ------------------------------------------------------------ rgb_linear: 64 -> 3, sigmoid
     {
       f32x16 c3[1];
       c3[0] = (f32x16)(0.0f);
-      SEG_BEGIN();  // no-op past the last segment
+      SEG_BEGIN();
       const float* wseg = CUR_BUF;
       steps_from_regs<1>(c3, wseg, 0, lane, hv[0], hv[1]);
       step1(c3[0], wseg, 32, lane, hl ? 0.0f : 1.0f);
@@ -505,68 +521,79 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           dbg_rgb_s[gs * 3 + 2] = cb;
         }
       }
-      SEG_END();  // all waves are done with the weight buffers (att may alias wbuf1)
+      SEG_END();
     }
+
+    TL_STAMP(8);
+    // ------------------------------------------------------------ alpha head: 128 -> 16 (last trunk stage:
+    // its activations stay in registers and feed the ray transformer's MFMA stages directly)
+    // rows 0..15 <-> registers 0..7: feature o = (r&3) + 8*(r>>2) + 4*hl
+    float av[8];
+    {
+      f32x16 al[1];
+      al[0] = (f32x16)(0.0f);
+      SEG_BEGIN();  // DMA of the tail segment
+      const float* wseg = CUR_BUF;
+      steps_from_regs<1>(al, wseg, 0, lane, h[0], h[1]);
+      steps_from_regs<1>(al, wseg, 32, lane, h[2], h[3]);
+      step1(al[0], wseg, 64, lane, hl ? 0.0f : 1.0f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float t = al[0][r];
+        t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+        av[r] = t;
+      }
+      if (D.raytrans_posenc) {
+        const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
+      }
+      SEG_END();
+    }
+
+    // ============================================================ ray transformer (K4)
+    // The tail segment [w_qs;w_ks;w_vs | fc | out_alpha.0 | out_alpha.2] stays resident in its
+    // weight buffer; the OTHER buffer (last read before the barrier above) is the K/V/Q/O scratch.
+    const float* tail = CUR_BUF;
+    float* att = NXT_BUF;
 #undef CUR_BUF
 #undef NXT_BUF
 #undef SEG_BEGIN
 #undef SEG_END
+    float* kv_lds = att;                // VALU form: [rays][4 heads][Sp][8] (k0..3, v0..3)
+    float* k_lds = att;                 // MFMA form
+    float* vt_lds = att + TILE * 16;
+    float* q_lds = att + TILE * 32;
+    float* o_lds = att + TILE * 48;
+    (void)kv_lds; (void)k_lds; (void)vt_lds; (void)q_lds; (void)o_lds;
 
-    TL_STAMP(9);
-    // ============================================================ ray transformer (K4)
-    for (int i = tid; i < SMALL_FIXED; i += NW * 64) sm_lds[i] = D.small_[i];
-    float a16[16];
-    {
-      const float4* src = reinterpret_cast<const float4*>(a_lds + s_local * 16);
+    // ---- q|k|v = [Wq;Wk;Wv] a : 8 K-steps x 2 M-blocks, operands straight from the alpha registers.
+    // Result rows: block 0 = q (regs 0..7) | k (regs 8..15), block 1 = v (regs 0..7); this lane
+    // holds heads {hl, 2+hl} of its sample (register quad hh <-> head hl + 2*hh).
+    f32x16 qkv[2];
+    qkv[0] = (f32x16)(0.0f);
+    qkv[1] = (f32x16)(0.0f);
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 t = src[q4];
-        a16[q4 * 4 + 0] = t.x;
-        a16[q4 * 4 + 1] = t.y;
-        a16[q4 * 4 + 2] = t.z;
-        a16[q4 * 4 + 3] = t.w;
-      }
-    }
-    __syncthreads();
+    for (int r = 0; r < 8; ++r) step2(qkv, tail + TAIL_QKV, r, lane, av[r]);
+    const float qs = q_valid ? 0.5f : 0.0f;  // temperature sqrt(d_k) = 2; masked query row -> uniform
 
-    float ov16[16];  // attention output of this lane's sample, all 4 heads (head-major)
+    float ofc[8];  // attention output features [8*hl, 8*hl+8) of this lane's sample (head-major)
     if constexpr (SM::MFMA_ATT) {
-      // ---- q/k/v projections (16 -> 16 each) of this lane's sample for its two heads
-      {
-        float qq[8], kk[8], vv[8];
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-          const int row = 8 * hl + idx;
-          const float4* wq = reinterpret_cast<const float4*>(sm_lds + row * 16);
-          const float4* wk = reinterpret_cast<const float4*>(sm_lds + 256 + row * 16);
-          const float4* wv = reinterpret_cast<const float4*>(sm_lds + 512 + row * 16);
-          float sq = 0.f, sk = 0.f, sv = 0.f;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 a = wq[q4], b = wk[q4], c = wv[q4];
-            sq += a.x * a16[q4 * 4] + a.y * a16[q4 * 4 + 1] + a.z * a16[q4 * 4 + 2] + a.w * a16[q4 * 4 + 3];
-            sk += b.x * a16[q4 * 4] + b.y * a16[q4 * 4 + 1] + b.z * a16[q4 * 4 + 2] + b.w * a16[q4 * 4 + 3];
-            sv += c.x * a16[q4 * 4] + c.y * a16[q4 * 4 + 1] + c.z * a16[q4 * 4 + 2] + c.w * a16[q4 * 4 + 3];
-          }
-          qq[idx] = q_valid ? sq * 0.5f : 0.0f;  // temperature sqrt(d_k) = 2; masked query row -> uniform
-          kk[idx] = sk;
-          vv[idx] = sv;
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int head = 2 * hl + hh;
-          *reinterpret_cast<float4*>(k_lds + ((ray_t * 4 + head) * Sp + jp) * 4) =
-              make_float4(kk[hh * 4], kk[hh * 4 + 1], kk[hh * 4 + 2], kk[hh * 4 + 3]);
-          float* vcol = vt_lds + (ray_t * 4 + head) * 4 * Sp + jp;
-          vcol[0] = vv[hh * 4];
-          vcol[Sp] = vv[hh * 4 + 1];
-          vcol[2 * Sp] = vv[hh * 4 + 2];
-          vcol[3 * Sp] = vv[hh * 4 + 3];
-          *reinterpret_cast<float4*>(q_lds + s_local * 16 + head * 4) =
-              make_float4(qq[hh * 4], qq[hh * 4 + 1], qq[hh * 4 + 2], qq[hh * 4 + 3]);
-        }
+      for (int hh = 0; hh < 2; ++hh) {
+        const int head = hl + 2 * hh;
+        *reinterpret_cast<float4*>(k_lds + ((ray_t * 4 + head) * Sp + jp) * 4) =
+            make_float4(qkv[0][8 + 4 * hh], qkv[0][9 + 4 * hh], qkv[0][10 + 4 * hh], qkv[0][11 + 4 * hh]);
+        float* vcol = vt_lds + (ray_t * 4 + head) * 4 * Sp + jp;
+        vcol[0] = qkv[1][4 * hh];
+        vcol[Sp] = qkv[1][4 * hh + 1];
+        vcol[2 * Sp] = qkv[1][4 * hh + 2];
+        vcol[3 * Sp] = qkv[1][4 * hh + 3];
+        *reinterpret_cast<float4*>(q_lds + s_local * 16 + head * 4) =
+            make_float4(qkv[0][4 * hh] * qs, qkv[0][4 * hh + 1] * qs, qkv[0][4 * hh + 2] * qs, qkv[0][4 * hh + 3] * qs);
       }
       __syncthreads();
+      TL_STAMP(9);
       TL_STAMP(10);
       // ---- attention proper on the matrix pipe: lane = query.  v_mfma_f32_4x4x1_16b runs 16
       // independent 4x4 outer products per instruction, D[r](lane) += A(lane 4*(l/4)+r) B(lane):
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         a_ray = idx >> 1;
         a_jq = chunk * 64 + lane;
       } else {
-        a_ray = wave * (64 / (2 * SP)) + 0;  // SP == 32: one ray per wave, head pairs in the half-waves
+        a_ray = wave;  // SP == 32: one ray per wave, the two head pairs in the two half-waves
         a_hp = lane >> 5;
         a_jq = lane & 31;
       }
@@ -643,52 +670,28 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       }
       __syncthreads();
       {
-        const float4* src = reinterpret_cast<const float4*>(o_lds + s_local * 16);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 t = src[q4];
-          ov16[q4 * 4 + 0] = t.x;
-          ov16[q4 * 4 + 1] = t.y;
-          ov16[q4 * 4 + 2] = t.z;
-          ov16[q4 * 4 + 3] = t.w;
-        }
+        const float4* src = reinterpret_cast<const float4*>(o_lds + s_local * 16 + 8 * hl);
+        const float4 t0 = src[0], t1 = src[1];
+        ofc[0] = t0.x; ofc[1] = t0.y; ofc[2] = t0.z; ofc[3] = t0.w;
+        ofc[4] = t1.x; ofc[5] = t1.y; ofc[6] = t1.z; ofc[7] = t1.w;
       }
     } else {
-      // ---- VALU form (S > 128): two lanes per sample, two heads each, K/V broadcast from LDS
-      float qv[8], ov[8];
-      {
-        float kk[8], vv[8];
+      // ---- VALU form (S > 128): two lanes per sample, heads {hl, 2+hl}, K/V broadcast from LDS
+      float ov[8];
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-          const int row = 8 * hl + idx;
-          const float4* wq = reinterpret_cast<const float4*>(sm_lds + row * 16);
-          const float4* wk = reinterpret_cast<const float4*>(sm_lds + 256 + row * 16);
-          const float4* wv = reinterpret_cast<const float4*>(sm_lds + 512 + row * 16);
-          float sq = 0.f, sk = 0.f, sv = 0.f;
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 a = wq[q4], b = wk[q4], c = wv[q4];
-            sq += a.x * a16[q4 * 4] + a.y * a16[q4 * 4 + 1] + a.z * a16[q4 * 4 + 2] + a.w * a16[q4 * 4 + 3];
-            sk += b.x * a16[q4 * 4] + b.y * a16[q4 * 4 + 1] + b.z * a16[q4 * 4 + 2] + b.w * a16[q4 * 4 + 3];
-            sv += c.x * a16[q4 * 4] + c.y * a16[q4 * 4 + 1] + c.z * a16[q4 * 4 + 2] + c.w * a16[q4 * 4 + 3];
-          }
-          qv[idx] = q_valid ? sq * 0.5f : 0.0f;
-          kk[idx] = sk;
-          vv[idx] = sv;
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          float4* dst = reinterpret_cast<float4*>(kv_lds + ((size_t)(ray_t * 4 + 2 * hl + hh) * Sp + jp) * 8);
-          dst[0] = make_float4(kk[hh * 4], kk[hh * 4 + 1], kk[hh * 4 + 2], kk[hh * 4 + 3]);
-          dst[1] = make_float4(vv[hh * 4], vv[hh * 4 + 1], vv[hh * 4 + 2], vv[hh * 4 + 3]);
-        }
+      for (int hh = 0; hh < 2; ++hh) {
+        float4* dst = reinterpret_cast<float4*>(kv_lds + ((size_t)(ray_t * 4 + hl + 2 * hh) * Sp + jp) * 8);
+        dst[0] = make_float4(qkv[0][8 + 4 * hh], qkv[0][9 + 4 * hh], qkv[0][10 + 4 * hh], qkv[0][11 + 4 * hh]);
+        dst[1] = make_float4(qkv[1][4 * hh], qkv[1][4 * hh + 1], qkv[1][4 * hh + 2], qkv[1][4 * hh + 3]);
       }
       __syncthreads();
+      TL_STAMP(9);
       TL_STAMP(10);
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const float4* base = reinterpret_cast<const float4*>(kv_lds + (size_t)(ray_t * 4 + 2 * hl + hh) * Sp * 8);
-        const float q0 = qv[hh * 4], q1 = qv[hh * 4 + 1], q2 = qv[hh * 4 + 2], q3 = qv[hh * 4 + 3];
+        const float4* base = reinterpret_cast<const float4*>(kv_lds + (size_t)(ray_t * 4 + hl + 2 * hh) * Sp * 8);
+        const float q0 = qkv[0][4 * hh] * qs, q1 = qkv[0][4 * hh + 1] * qs, q2 = qkv[0][4 * hh + 2] * qs,
+                    q3 = qkv[0][4 * hh + 3] * qs;
         float mx = -3.0e38f;
         for (int jj = 0; jj < S; ++jj) {
           const float4 k4 = base[jj * 2];
@@ -710,56 +713,64 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         ov[hh * 4 + 2] = o2 * il;
         ov[hh * 4 + 3] = o3 * il;
       }
+      // this lane has heads {hl, 2+hl}; the fc stage wants features [8 hl, 8 hl + 8) = heads {2hl, 2hl+1}
 #pragma unroll
-      for (int idx = 0; idx < 8; ++idx) {  // gather the partner half-wave's two heads
-        const float other = __shfl_xor(ov[idx], 32, 64);
-        ov16[idx] = hl ? other : ov[idx];
-        ov16[8 + idx] = hl ? ov[idx] : other;
+      for (int d = 0; d < 4; ++d) {
+        const float mine_lo = ov[d], mine_hi = ov[4 + d];
+        const float oth_lo = __shfl_xor(mine_lo, 32, 64), oth_hi = __shfl_xor(mine_hi, 32, 64);
+        // hl = 0: heads 0 (mine_lo), 1 (partner's lo);  hl = 1: heads 2 (partner's hi), 3 (mine_hi)
+        ofc[d] = hl ? oth_hi : mine_lo;
+        ofc[4 + d] = hl ? mine_hi : oth_lo;
       }
     }
+
     TL_STAMP(11);
-    // fc (16x16, no bias) + residual, LayerNorm(eps 1e-6)
-    float xr[16];
+    // ---- fc (16x16, no bias) as one more MFMA stage + residual + LayerNorm(eps 1e-6); the 16
+    // features of a sample are split over its two lanes exactly like the alpha registers.
+    float yv[8];
     {
-      float mean = 0.f;
+      f32x16 t1 = (f32x16)(0.0f);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const float4* wf = reinterpret_cast<const float4*>(sm_lds + 768 + c * 16);
-        float part = 0.f;
+      for (int t = 0; t < 8; ++t) step1(t1, tail + TAIL_FCO, t, lane, ofc[t]);
+      float xs = 0.f;
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 w = wf[q4];
-          part += w.x * ov16[q4 * 4] + w.y * ov16[q4 * 4 + 1] + w.z * ov16[q4 * 4 + 2] + w.w * ov16[q4 * 4 + 3];
-        }
-        xr[c] = part + a16[c];
-        mean += xr[c];
+      for (int r = 0; r < 8; ++r) {
+        yv[r] = t1[r] + av[r];
+        xs += yv[r];
       }
-      mean *= (1.0f / 16.0f);
+      xs += __shfl_xor(xs, 32, 64);
+      const float mean = xs * (1.0f / 16.0f);
       float var = 0.f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const float dlt = xr[c] - mean;
+      for (int r = 0; r < 8; ++r) {
+        const float dlt = yv[r] - mean;
         var += dlt * dlt;
       }
+      var += __shfl_xor(var, 32, 64);
       const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) xr[c] = (xr[c] - mean) * rstd * sm_lds[1024 + c] + sm_lds[1040 + c];
-    }
-    // out_alpha_linear: 16 -> 16 (act) -> 1 (ReLU)   (cond_nerf.py:33-36, 84)
-    float sigma = sm_lds[1344];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float4* w1 = reinterpret_cast<const float4*>(sm_lds + 1056 + c * 16);
-      float t = sm_lds[1312 + c];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 w = w1[q4];
-        t += w.x * xr[q4 * 4] + w.y * xr[q4 * 4 + 1] + w.z * xr[q4 * 4 + 2] + w.w * xr[q4 * 4 + 3];
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + 4 * hl;
+        yv[r] = (yv[r] - mean) * rstd * ln_lds[o] + ln_lds[16 + o];
       }
-      t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
-      sigma += sm_lds[1328 + c] * t;
     }
-    sigma = fmaxf(sigma, 0.0f);
+    // ---- out_alpha_linear: 16 -> 16 (act) -> 1 (ReLU) as two MFMA stages (cond_nerf.py:33-36, 84)
+    float sigma;
+    {
+      f32x16 t2 = (f32x16)(0.0f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) step1(t2, tail + TAIL_OA0, r, lane, yv[r]);
+      step1(t2, tail + TAIL_OA0, 8, lane, hl ? 0.0f : 1.0f);
+      f32x16 t3 = (f32x16)(0.0f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float t = t2[r];
+        t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+        step1(t3, tail + TAIL_OA2, r, lane, t);
+      }
+      step1(t3, tail + TAIL_OA2, 8, lane, hl ? 0.0f : 1.0f);
+      sigma = fmaxf(t3[0], 0.0f);  // output row 0 <-> register 0 of the lower half-wave
+    }
     if (D.density_maskfill && n_valid < 1.0f) sigma = 0.0f;
     if (hl == 0) {
       rs_lds[s_local * 4 + 3] = sigma;
@@ -826,7 +837,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       }
     }
     TL_STAMP(13);
-    // No barrier here: the next tile touches rs_lds / a_lds only after several segment barriers,
+    // No barrier here: the next tile touches rs_lds only after several segment barriers,
     // and every read of the attention scratch (aliased on the weight buffers that the next
     // tile's first DMA overwrites) completed before the barrier in front of the compositing.
     TL_STAMP(14);
@@ -840,8 +851,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 // a multiple of 256 floats.
 static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
   const int fs = D->cond_stride / 2, es = 3 * D->L_3D + 2;
-  const int T[12] = {fs, es, 65, 65, 65, 65, es, 64, 65, 65, 66, 33};
-  const int M[12] = {4, 4, 4, 4, 4, 4, 4, 4, 1, 4, 2, 1};
+  // film, l0, l1..l4, l5-enc, l5-h, feature, views, rgb, alpha (+ the resident tail segment)
+  const int T[12] = {fs, es, 65, 65, 65, 65, es, 64, 65, 66, 33, 65};
+  const int M[12] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 1, 1};
   int n = 0;
   long long off = 0;
   for (int st = 0; st < 12; ++st) {
@@ -859,6 +871,15 @@ static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
       off += fl;
       ++n;
     }
+  }
+  {  // tail: [w_qs;w_ks;w_vs | fc | out_alpha.0 | out_alpha.2]
+    if (n >= MAX_SEGS) return -1;
+    const int fl = ((TAIL_FLOATS + 255) / 256) * 256;
+    sch->seg_off[n] = (int)off;
+    sch->seg_floats[n] = fl;
+    sch->seg_steps[n] = 0;
+    off += fl;
+    ++n;
   }
   sch->n_seg = n;
 #ifdef MNERF_TIMELINE

@@ -13,7 +13,7 @@ import numpy as np
 
 MNERF_ABI_VERSION = 1
 MNERF_MAX_VIEWS = 16
-SMALL_FIXED = 1360  # floats of the `small` parameter block before the ray-posenc table
+SMALL_FIXED = 32  # floats of the `small` parameter block (LayerNorm weight|bias) before the ray-posenc table
 
 _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")

@@ -24,6 +24,16 @@ def emulate_stage(ws, segs, name, b_lo, b_hi):
     return y
 
 
+def emulate_tail(ws, segs, sub, b_lo, b_hi):
+    off = [s for s in segs if s[0] == "tail"][0][4]
+    sub_off, t, nmb = CN.TAIL_LAYOUT[sub]
+    a = ws[off + sub_off:off + sub_off + t * 64 * nmb].reshape(t, 64, nmb).astype(np.float64)
+    y = np.zeros((nmb * 32, b_lo.shape[1]))
+    for mb in range(nmb):
+        y[mb * 32:(mb + 1) * 32] = a[:, :32, mb].T @ b_lo + a[:, 32:, mb].T @ b_hi
+    return y
+
+
 def reg_order_operands(h, n_blocks):
     lo, hi = CN._reg_order(n_blocks)
     return h[lo], h[hi]
@@ -43,7 +53,7 @@ def enc_operands(x, L, legacy):
     return np.stack(lo), np.stack(hi)
 
 
-@pytest.mark.parametrize("name", ["c1_default", "v4", "nonlegacy"])
+@pytest.mark.parametrize("name", ["c1_default", "v4", "nonlegacy", "rect_wide"])
 def test_emulated_mfma_chain_matches_oracle(name):
     g, cfg, sd, batch = golden_case(name)
     n_rays = 8
@@ -85,16 +95,36 @@ def test_emulated_mfma_chain_matches_oracle(name):
     rgb = 1 / (1 + np.exp(-emulate_stage(ws, segs, "rgb", np.vstack([lo, one]), np.vstack([hi, zero]))[:3]))
     assert linf(rgb.T.reshape(n_rays, -1, 3), rgb_o) < 2e-6
 
-    # density branch through the oracle's own attention on the emulated alpha features
+    # density branch: q/k/v, fc and the density head through the packed TAIL segment, attention
+    # itself (softmax) in numpy, vs the oracle's sigma
     a_t = torch.from_numpy(a[:16].T.reshape(n_rays, -1, 16)).float()
     a_t = O._act(cfg.raytrans_act, a_t)
     if cfg.raytrans_posenc:
         a_t = a_t + torch.from_numpy(CN.raytrans_table(a_t.shape[1]))[None]
-    o = O.ray_attention(sd, a_t, (mask.sum(-1) > 1).float())
-    nd = "nerf_dec."
-    o = O._act(cfg.raytrans_act, o @ sd[nd + "out_alpha_linear.0.weight"].t() + sd[nd + "out_alpha_linear.0.bias"])
-    sig = torch.relu(o @ sd[nd + "out_alpha_linear.2.weight"].t() + sd[nd + "out_alpha_linear.2.bias"])[..., 0]
-    assert linf(sig, sigma_o) < 2e-6
+    av = a_t.reshape(n, 16).numpy().T.astype(np.float64)                       # [16, N]
+    lo16, hi16 = CN._reg_order(1)
+    lo16, hi16 = lo16[:8], hi16[:8]
+    qkv = emulate_tail(ws, segs, "qkv", av[lo16], av[hi16])                    # rows q|k|v|pad
+    assert np.abs(qkv[48:]).max() == 0.0
+    s_n = cfg.sample_intvs
+    valid = (mask.sum(-1) > 1).reshape(n).numpy()
+    q = (qkv[0:16] * 0.5 * valid[None]).T.reshape(n_rays, s_n, 4, 4).transpose(0, 2, 1, 3)
+    k = qkv[16:32].T.reshape(n_rays, s_n, 4, 4).transpose(0, 2, 1, 3)
+    v_ = qkv[32:48].T.reshape(n_rays, s_n, 4, 4).transpose(0, 2, 1, 3)
+    sc = q @ k.transpose(0, 1, 3, 2)
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    o = (p / p.sum(-1, keepdims=True)) @ v_                                     # [R,4,S,4]
+    o16 = o.transpose(0, 2, 1, 3).reshape(n, 16).T                              # head-major
+    x = emulate_tail(ws, segs, "fco", o16[:8], o16[8:])[:16] + av
+    small = CN.pack_small(sd, s_n, cfg.raytrans_posenc).astype(np.float64)
+    mu = x.mean(0)
+    x = (x - mu) / np.sqrt(((x - mu) ** 2).mean(0) + 1e-6) * small[0:16, None] + small[16:32, None]
+    z = emulate_tail(ws, segs, "oa0", np.vstack([x[lo16], one]), np.vstack([x[hi16], zero]))[:16]
+    z = np.where(z > 0, z, np.exp(z) - 1) if cfg.raytrans_act == "ELU" else np.maximum(z, 0)
+    sg = np.maximum(emulate_tail(ws, segs, "oa2", np.vstack([z[lo16], one]), np.vstack([z[hi16], zero]))[0], 0)
+    if cfg.density_maskfill:
+        sg = np.where(mask.sum(-1).reshape(n).numpy() < 1, 0.0, sg)
+    assert linf(sg.reshape(n_rays, s_n), sigma_o) < 2e-6
 
 
 def test_schedule_invariants():
@@ -107,18 +137,20 @@ def test_schedule_invariants():
             off += fl
         for name, t, m in CN.decoder_stages(cs, L):
             assert sum(s[2] for s in segs if s[0] == name) == t
+        assert [s[0] for s in segs if s[0] in ("feature", "views", "rgb", "alpha", "tail")][-4:] == ["views", "rgb", "alpha", "tail"]
         # stages fed from accumulator registers must split 32 | 32(+1) (static unrolling in the kernel)
         for name in ("l1", "l2", "l3", "l4", "feature"):
             assert [s[2] for s in segs if s[0] == name] == [32, 33]
         assert [s[2] for s in segs if s[0] == "l5h"] == [32, 32]
-        for name in ("alpha", "views", "rgb", "film"):
+        for name in ("alpha", "views", "rgb", "film", "tail"):
             assert len([s for s in segs if s[0] == name]) == 1
+        assert segs[-1][0] == "tail" and segs[-1][5] >= CN.TAIL_FLOATS
 
 
 def test_small_block_layout():
     g, cfg, sd, _ = golden_case("c1_default")
     s = CN.pack_small(sd, 64, True)
     assert s.size == CN.SMALL_FIXED + 64 * 16
-    assert np.array_equal(s[768:1024], sd["nerf_dec.ray_attention.fc.weight"].numpy().reshape(-1))
-    assert s[1344] == float(sd["nerf_dec.out_alpha_linear.2.bias"][0])
+    assert np.array_equal(s[0:16], sd["nerf_dec.ray_attention.layer_norm.weight"].numpy())
+    assert np.array_equal(s[16:32], sd["nerf_dec.ray_attention.layer_norm.bias"].numpy())
     assert linf(s[CN.SMALL_FIXED:].reshape(64, 16), O.raytrans_table(64)) == 0.0
