@@ -20,6 +20,9 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "MNERF_FORCE_DEVICE" in os.environ:  # dry runs of the N>1 path on a 1-GPU box (with gloo)
+        local = int(os.environ["MNERF_FORCE_DEVICE"])
+    backend = backend or os.environ.get("MNERF_DIST_BACKEND")
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local)
@@ -59,8 +62,14 @@ def gather_tiles(local, counts=None):
     if local.shape[0] != width:
         send = local.new_zeros((width,) + tuple(local.shape[1:]))
         send[:local.shape[0]] = local
-    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, send.contiguous())
+    if send.is_cuda and dist.get_backend() == "gloo":  # dry-run path: stage through the host
+        host = send.contiguous().cpu()
+        out_h = host.new_empty((world * width,) + tuple(host.shape[1:]))
+        dist.all_gather_into_tensor(out_h, host)
+        out = out_h.to(send.device)
+    else:
+        out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, send.contiguous())
     if all(c == width for c in counts):
         return out
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], 0)
@@ -74,6 +83,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    t = torch.tensor([float(value)], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
