@@ -43,6 +43,17 @@ CPU_THREADS_MAX = 16 # torch intra-op threads for the CPU baseline (more threads
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 
 
+def measured_traffic(launch_rays):
+    """HBM-side bytes per decoder launch from the committed rocprofv3 PMC passes (bench.py cannot
+    run the profiler itself); None when the launch size differs from the profiled one."""
+    try:
+        with open(os.path.join(REPO, "profiles", "decoder_traffic.json")) as f:
+            t = json.load(f)
+        return t["hbm_bytes_per_launch"] if t["launch_rays"] == launch_rays else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def flops_per_sample(s):
     return 258336 + 64 * s  # SURVEY.md §8(d)
 
@@ -178,7 +189,8 @@ def main():
             },
             "roofline": {"bound": "mfma", "kernel": "decoder_kernel<4> (fused MLP + ray transformer + compositing)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": measured_traffic(int(dec["rays"] / dec["launches"])),
                          "avg_launch_ms": round(dec["avg_ms"], 4),
                          "flops_per_launch": flops_launch},
         }
