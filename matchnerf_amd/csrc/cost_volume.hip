@@ -18,6 +18,8 @@
 // the CU's vector L1; the maps themselves (78.6 MB fp32 at 512x640x3 views) stay resident in
 // L2 / Infinity Cache.  Group reductions (dot, |a|^2, |b|^2 over 128/G channels) are in-lane
 // for G=8 and 1-3 xor-shuffle steps inside the slot for G=4,2,1.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 #define FEAT_C MNERF_FEAT_CH
@@ -205,6 +207,189 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
   }
 }
 
+// ============================================================================ v2: segment walk
+// Same arithmetic as cost_volume_kernel, different traversal.  PMC showed that kernel bound by
+// the bytes the texture path delivers to registers (~18 TB/s of taps, 53 % of L1 peak), not by
+// L2/HBM — and consecutive samples of a ray move only ~1/4 texel at 1/8 resolution (~1/2 at 1/4),
+// so most of those bytes are the same texels again.  Here a slot (8 lanes) WALKS a segment of
+// CVW_SEG consecutive samples of one ray; for each view pair and scale it keeps the current 2x2
+// texel quad of both maps in registers (2 x 4 taps x 16 channels per lane) and reloads a quad
+// only when its integer texel changes.  Projections are evaluated once per (sample, view) and
+// parked in LDS; the per-sample cosine sums over pairs accumulate in LDS.
+#ifndef CVW_SEG
+#define CVW_SEG 16
+#endif
+
+struct QuadCache {
+  float t00[16], t01[16], t10[16], t11[16];
+  int o00, o01, o10, o11;
+};
+
+__device__ __forceinline__ void quad_load(QuadCache& q, const float* __restrict__ map, const Bilin& b, int sub) {
+  const float4* p00 = reinterpret_cast<const float4*>(map + (size_t)b.o00 * FEAT_C) + sub * 4;
+  const float4* p01 = reinterpret_cast<const float4*>(map + (size_t)b.o01 * FEAT_C) + sub * 4;
+  const float4* p10 = reinterpret_cast<const float4*>(map + (size_t)b.o10 * FEAT_C) + sub * 4;
+  const float4* p11 = reinterpret_cast<const float4*>(map + (size_t)b.o11 * FEAT_C) + sub * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 a = p00[k], c = p01[k], d = p10[k], e = p11[k];
+    q.t00[4 * k] = a.x; q.t00[4 * k + 1] = a.y; q.t00[4 * k + 2] = a.z; q.t00[4 * k + 3] = a.w;
+    q.t01[4 * k] = c.x; q.t01[4 * k + 1] = c.y; q.t01[4 * k + 2] = c.z; q.t01[4 * k + 3] = c.w;
+    q.t10[4 * k] = d.x; q.t10[4 * k + 1] = d.y; q.t10[4 * k + 2] = d.z; q.t10[4 * k + 3] = d.w;
+    q.t11[4 * k] = e.x; q.t11[4 * k + 1] = e.y; q.t11[4 * k + 2] = e.z; q.t11[4 * k + 3] = e.w;
+  }
+  q.o00 = b.o00;
+  q.o01 = b.o01;
+  q.o10 = b.o10;
+  q.o11 = b.o11;
+}
+
+__device__ __forceinline__ bool quad_stale(const QuadCache& q, const Bilin& b) {
+  return (q.o00 != b.o00) | (q.o01 != b.o01) | (q.o10 != b.o10) | (q.o11 != b.o11);
+}
+
+__device__ __forceinline__ void quad_interp(const QuadCache& q, const Bilin& b, float (&out)[16]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c)  // same expression as sample16()
+    out[c] = q.t00[c] * b.w00 + q.t01[c] * b.w01 + q.t10[c] * b.w10 + q.t11[c] * b.w11;
+}
+
+__global__ __launch_bounds__(256, 2) void cost_volume_walk_kernel(mnerf_scene sc, mnerf_rays R,
+                                                                  int cond_stride,
+                                                                  float* __restrict__ cond) {
+  extern __shared__ __attribute__((aligned(16))) float cvw_smem[];
+  const int V = sc.n_views;
+  const int sub = threadIdx.x & 7;
+  const int slot = threadIdx.x >> 3;                                // 32 slots = 32 adjacent rays
+  float* uv_lds = cvw_smem + (size_t)slot * CVW_SEG * V * 2;       // [seg sample][view][u,v]
+  float* cs_lds = cvw_smem + 32 * CVW_SEG * V * 2 + slot * CVW_SEG * 16;  // [seg sample][<=16 cos sums]
+  const int S = R.n_samples;
+  const int P = V * (V - 1) / 2;
+  const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
+  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
+  const int sumG = G0 + G1;
+  const float inv_pairs = 1.0f / (float)P;
+  const int n_seg = (S + CVW_SEG - 1) / CVW_SEG;
+
+  // XCD-major contiguous runs of 32-ray blocks (see cost_volume_kernel)
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin;
+  const long long blocks_total = ((long long)R.n_rays + 31) / 32;
+  const long long bpc = (blocks_total + nwg - 1) / nwg;
+  const long long b_begin = (long long)chunk * bpc;
+  long long b_end = b_begin + bpc;
+  if (b_end > blocks_total) b_end = blocks_total;
+
+  for (long long it = b_begin * n_seg; it < b_end * n_seg; ++it) {
+    const long long rb = it / n_seg;
+    const int j0 = (int)(it - rb * n_seg) * CVW_SEG;
+    long long ray_ll = rb * 32 + slot;
+    const bool ray_live = ray_ll < R.n_rays;
+    if (!ray_live) ray_ll = R.n_rays - 1;
+    const int ray = (int)ray_ll;
+    const RayGeom g = make_ray(R, ray);
+
+    // ---- pass 1: projections, colours, masks.  Lane `sub` takes segment samples sub and sub+8.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int js = sub + 8 * half;
+      const int j = min(j0 + js, S - 1);
+      const bool live = ray_live && (j0 + js < S);
+      const float d = sample_depth(R, ray, j);
+      float px, py, pz;
+      ray_point(g, d, px, py, pz);
+      float* out = cond + ((size_t)ray * S + j) * cond_stride;
+      for (int v = 0; v < V; ++v) {
+        float u, w_, z;
+        project(sc.views[v], px, py, pz, wm1, hm1, u, w_, z);
+        uv_lds[(js * V + v) * 2 + 0] = u;
+        uv_lds[(js * V + v) * 2 + 1] = w_;
+        const Bilin b = bilin_setup(u, w_, R.height, R.width);
+        const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
+        const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+        const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
+        const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+        if (live) {
+          out[sumG + 3 * v + 0] = t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11;
+          out[sumG + 3 * v + 1] = t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11;
+          out[sumG + 3 * v + 2] = t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11;
+          out[sumG + 3 * V + v] = m;
+        }
+      }
+      if (live) {
+        const int dc = sumG + 4 * V;
+        out[dc] = 1.0f;
+        for (int c = dc + 1; c < cond_stride; ++c) out[c] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (CVW_SEG * 16) / 8; ++i) cs_lds[i * 8 + sub] = 0.0f;  // this slot's cosine sums
+    // slot-local LDS hand-off: the 8 lanes of a slot belong to one wave => wave-level ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- pass 2: walk the segment once per (pair, scale) with the two texel quads in registers
+    int p = 0;
+    for (int a = 0; a < V - 1; ++a) {
+      for (int b = a + 1; b < V; ++b, ++p) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s >= sc.n_scales) break;
+          const int fh = sc.fh[s], fw = sc.fw[s];
+          const size_t map_elems = (size_t)fh * fw * FEAT_C;
+          const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems;
+          const float* m1 = m0 + map_elems;
+          const int G = sc.n_group[s];
+          const int lpg = 8 / G;
+          const int goff = s ? G0 : 0;
+          QuadCache qa, qb;
+          qa.o00 = qa.o01 = qa.o10 = qa.o11 = -1;
+          qb.o00 = qb.o01 = qb.o10 = qb.o11 = -1;
+          for (int js = 0; js < CVW_SEG; ++js) {
+            const float ua = uv_lds[(js * V + a) * 2], va = uv_lds[(js * V + a) * 2 + 1];
+            const float ub = uv_lds[(js * V + b) * 2], vb = uv_lds[(js * V + b) * 2 + 1];
+            const Bilin ba = bilin_setup(ua, va, fh, fw);
+            const Bilin bb = bilin_setup(ub, vb, fh, fw);
+            if (quad_stale(qa, ba)) quad_load(qa, m0, ba, sub);
+            if (quad_stale(qb, bb)) quad_load(qb, m1, bb, sub);
+            float fa[16], fb[16];
+            quad_interp(qa, ba, fa);
+            quad_interp(qb, bb, fb);
+            float dot = 0.f, na = 0.f, nb = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              dot += fa[c] * fb[c];
+              na += fa[c] * fa[c];
+              nb += fb[c] * fb[c];
+            }
+            dot = group_reduce(dot, lpg);
+            na = group_reduce(na, lpg);
+            nb = group_reduce(nb, lpg);
+            const float da = fmaxf(sqrtf(na), 1e-8f), db = fmaxf(sqrtf(nb), 1e-8f);
+            if ((sub % lpg) == 0) cs_lds[js * 16 + goff + sub / lpg] += dot / (da * db);  // owner lane, pair order
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- write the averaged cosines: lane `sub` writes samples sub and sub+8
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int js = sub + 8 * half;
+      if (ray_live && (j0 + js < S)) {
+        float* out = cond + ((size_t)ray * S + j0 + js) * cond_stride;
+        for (int c = 0; c < sumG; ++c) out[c] = cs_lds[js * 16 + c] * inv_pairs;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds are rewritten by the next unit
+  }
+}
+
 static int check_scene(const mnerf_scene* sc, const mnerf_rays* rays, const char* who) {
   MNERF_REQUIRE(sc && rays, MNERF_E_NULL, "%s: NULL argument struct", who);
   MNERF_REQUIRE(sc->n_views >= 2 && sc->n_views <= MNERF_MAX_VIEWS, MNERF_E_RANGE,
@@ -244,7 +429,23 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
   if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
-  hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     *scene, *rays, cond_stride, cond);
+  int variant = 1;  // 1 = segment walk (register quad cache), 0 = one sample per slot iteration
+  if (const char* e = getenv("MNERF_CV_VARIANT")) variant = atoi(e);
+  if (sumG > 16) variant = 0;
+  if (variant == 1) {
+    const size_t lds = (size_t)(32 * CVW_SEG * scene->n_views * 2 + 32 * CVW_SEG * 16) * sizeof(float);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      (void)hipFuncSetAttribute((const void*)cost_volume_walk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lds_set = lds;
+    }
+    long long wgs = ((long long)rays->n_rays + 31) / 32;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(cost_volume_walk_kernel, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+                       *scene, *rays, cond_stride, cond);
+  } else {
+    hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       *scene, *rays, cond_stride, cond);
+  }
   return mnerf_check_launch("mnerf_cost_volume");
 }
