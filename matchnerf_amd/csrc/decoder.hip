@@ -293,6 +293,29 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
   __syncthreads();
 
+  // Per-tile global inputs of a lane: its half-wave's FiLM operands (cond row) and the sum of the
+  // visibility masks (cond_nerf.py:79-80).  (Fetching them one tile ahead was tried: the 33 extra
+  // loop-carried VGPRs cost more in spills than the hidden latency gained.)
+  float4 cpre[8];
+  float n_valid = 0.0f;
+  auto load_tile_inputs = [&](int t) {
+    const int s_l = wave * 32 + n;
+    const int r_t = s_l / Sp;
+    const int j_p = s_l - r_t * Sp;
+    int r = t * rays_per_tile + r_t;
+    if (r >= R.n_rays) r = R.n_rays - 1;
+    const size_t g_s = (size_t)r * S + (j_p < S ? j_p : (S - 1));
+    const float4* crow4 = reinterpret_cast<const float4*>(cond + g_s * CS + (size_t)hl * sch.film_steps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      cpre[i] = (4 * i < sch.film_steps) ? crow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* mrow = cond + g_s * CS + (D.cond_dim - D.n_views);
+    float nv = 0.0f;
+    for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
+    n_valid = nv;
+  };
+  bool seg0_in_flight = false;
+
 #ifdef MNERF_TIMELINE
   int tl_tile = -1;
   // record blocks [0,64) and their presumed CU partners [256,320)
@@ -331,24 +354,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     const float dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
     const float dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
 
-    // global loads of this tile issued first, so that their latency hides under the prologue:
-    // this half-wave's FiLM inputs and the visibility-mask sum (cond_nerf.py:79-80)
-    float4 cpre[8];
-    {
-      const float4* crow4 = reinterpret_cast<const float4*>(cond + gs * CS + (size_t)hl * sch.film_steps);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        cpre[i] = (4 * i < sch.film_steps) ? crow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float n_valid = 0.0f;
-    {
-      const float* mrow = cond + gs * CS + (D.cond_dim - D.n_views);
-      for (int v = 0; v < D.n_views; ++v) n_valid += mrow[v];
-    }
+    load_tile_inputs(tile);  // issued before the geometry below is consumed: latency overlaps it
     const bool q_valid = n_valid > 1.0f;
 
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
-    prefetch_segment<NW>(D.wstream, sch, 0, wbuf0, wave, lane);
+    if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0, wave, lane);
     segment_wait();
     __syncthreads();
 
@@ -631,24 +641,27 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           t = mfma4(kk.w, q4.w, t);
           sc[g] = t;
         }
-        float mx = -3.0e38f;
+        // four independent partial maxima / sums instead of one 64-long dependent chain
+        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
         for (int g = 0; g < SP / 4; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float v = (4 * g + r < S) ? sc[g][r] : -3.0e38f;  // padded key slots
             sc[g][r] = v;
-            mx = fmaxf(mx, v);
+            mx4[r] = fmaxf(mx4[r], v);
           }
-        float lsum = 0.f;
+        const float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        float ls4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < SP / 4; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __expf(sc[g][r] - mx);
             sc[g][r] = pr;
-            lsum += pr;
+            ls4[r] += pr;
           }
+        const float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
         const float* vb = vt_lds + ((a_ray * 4 + head) * 4 + (lane & 3)) * Sp;
         f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -777,6 +790,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       if (dbg_sigma && ray_ok && jp < S) dbg_sigma[gs] = sigma;
     }
     __syncthreads();
+    // every weight / scratch read of this tile is complete: start the DMA of the next tile's first
+    // weight segment now, under the compositing
+    {
+      const int next_tile = tile + (int)gridDim.x;
+      seg0_in_flight = next_tile < n_tiles;
+      if (seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0, wave, lane);
+    }
 
     TL_STAMP(12);
     // ============================================================ compositing (K5)
