@@ -52,10 +52,6 @@ class MatchNeRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward (matchnerf.py:32-73)
     def forward(self, batch, mode=None, render_video=False, render_path_mode="interpolate"):
-        if mode == "train" and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "mode='train' under autograd needs the backward kernels of the HIP path "
-                "(SURVEY.md §8f, next); run under torch.no_grad() to evaluate the random-ray path")
         ref_images = batch.images[:, :self.n_src_views]
         ref_feats_list = self.get_img_feat(ref_images, attn_splits_list=self.opts.encoder.attn_splits_list,
                                            cur_n_src_views=self.n_src_views)
@@ -106,16 +102,21 @@ class MatchNeRF(torch.nn.Module):
                              wo_self_attn=self.opts.encoder.wo_self_attn)
 
     # ------------------------------------------------------------------ C-ABI argument structs
-    def _scene(self, b, ref_poses_host, ref_feats_list, images_cl):
+    def _scene(self, b, ref_poses_host, ref_feats_list, images_cl, feats_b=None):
+        """``feats_b``: per-scale maps [P,2,h,w,128] of batch element b (default: slices of
+        ``ref_feats_list``)."""
+        if feats_b is None:
+            feats_b = [f[b] for f in ref_feats_list]
         sc = hip.Scene()
-        sc.n_views, sc.n_scales = self.n_src_views, len(ref_feats_list)
+        sc.n_views, sc.n_scales = self.n_src_views, len(feats_b)
         groups = self.opts.encoder.cos_n_group
         groups = [groups] if isinstance(groups, int) else list(groups)
-        assert len(groups) == len(ref_feats_list), "cos_n_group needs one entry per feature scale"
-        for s, f in enumerate(ref_feats_list):
-            sc.fh[s], sc.fw[s] = f.shape[3], f.shape[4]
+        assert len(groups) == len(feats_b), "cos_n_group needs one entry per feature scale"
+        for s, f in enumerate(feats_b):
+            assert f.is_contiguous()
+            sc.fh[s], sc.fw[s] = f.shape[2], f.shape[3]
             sc.n_group[s] = groups[s]
-            sc.feat[s] = f[b].data_ptr()
+            sc.feat[s] = f.data_ptr()
         sc.images = images_cl[b].data_ptr()
         ex, it, nf = ref_poses_host
         for v in range(self.n_src_views):
@@ -173,6 +174,11 @@ class MatchNeRF(torch.nn.Module):
         rgb = torch.empty(batch_size, n_rays, 3, device=device)
         depth = torch.empty(batch_size, n_rays, 1, device=device)
         opacity = torch.empty(batch_size, n_rays, 1, device=device)
+        needs_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in ref_feats_list) or
+                                                  any(p.requires_grad for p in self.nerf_dec.parameters()))
+        if needs_grad:
+            return self._render_with_grad(opt, ref_host, (tgt_ex, tgt_in, tgt_nf), ray_idx, stratified, ref_images,
+                                          ref_feats_list, images_cl, n_rays, n_samples, img_h, img_w)
         for b in range(batch_size):
             sc = self._scene(b, ref_host, ref_feats_list, images_cl)
             kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
@@ -187,6 +193,46 @@ class MatchNeRF(torch.nn.Module):
                 hip.render_chunk(sc, dec, rays, ws, rgb[b, c:c + m], depth[b, c:c + m], opacity[b, c:c + m],
                                  timer=self.kernel_timer)
         return edict(rgb=rgb, depth=depth, opacity=opacity)
+
+    def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,
+                          n_rays, n_samples, img_h, img_w):
+        """Training path: forward through the HIP kernels, backward through a torch re-evaluation
+        of the same ray chunk (matchnerf_amd/autograd.py)."""
+        from . import autograd as ag
+        device = ref_images.device
+        legacy = bool(opt.nerf.legacy_coord)
+        tgt_ex, tgt_in, tgt_nf = tgt_host
+        batch_size = ref_images.shape[0]
+        idx = torch.arange(n_rays, device=device) if ray_idx is None else ray_idx.to(device)
+        idx32 = idx.to(torch.int32).contiguous()
+        outs = []
+        for b in range(batch_size):
+            strat = torch.rand(n_rays, n_samples, device=device) if stratified else None
+            kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
+
+            def hip_render(feats, b=b, strat=strat, kinv=kinv, c2w=c2w):
+                dec = self._decoder(n_samples, device)
+                sc = self._scene(b, ref_host, None, images_cl, feats_b=[f.contiguous() for f in feats])
+                ws = self._workspace(hip.render_workspace_bytes(n_rays, n_samples, dec.cond_stride) // 4, device)
+                rays = hip.make_rays(n_rays, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1],
+                                     legacy=legacy, depth_inverse=(opt.nerf.depth.param == "inverse"),
+                                     ray_idx_ptr=idx32.data_ptr(),
+                                     strat_u_ptr=None if strat is None else strat.data_ptr())
+                o_rgb = torch.empty(n_rays, 3, device=device)
+                o_d = torch.empty(n_rays, 1, device=device)
+                o_o = torch.empty(n_rays, 1, device=device)
+                hip.render_chunk(sc, dec, rays, ws, o_rgb, o_d, o_o)
+                return o_rgb, o_d, o_o
+
+            def torch_render(feats, b=b, strat=strat):
+                ex, it, nf = ref_host
+                return ag.render_rays_torch(opt, self.nerf_dec, feats, ref_images[b], ex[b], it[b], nf[b], tgt_ex[b],
+                                            tgt_in[b], tgt_nf[b], idx, strat, img_h, img_w, bool(self.nerf_setbg_opaque))
+
+            outs.append(ag.render_rays(self, dict(hip_render=hip_render, torch_render=torch_render),
+                                       [f[b] for f in ref_feats_list]))
+        return edict(rgb=torch.stack([o[0] for o in outs], 0), depth=torch.stack([o[1] for o in outs], 0),
+                     opacity=torch.stack([o[2] for o in outs], 0))
 
     def render_by_slices(self, opt, tgt_pose, mode=None, ref_poses=None, ref_images=None, ref_feats_list=None):
         """matchnerf.py:145-161.  The reference loops over ``rand_rays_<mode>``-sized slices to

@@ -85,12 +85,46 @@ def test_random_ray_mode_matches_oracle():
     assert linf(out.rgb[0], ref[0]) < 1e-4 and linf(out.opacity[0], ref[2]) < 1e-4
 
 
-def test_train_mode_under_autograd_is_refused():
-    g, *_ = golden_case("c1_default")
+def test_train_mode_gradients_match_oracle_autograd():
+    """mode='train' under autograd: forward values from the HIP kernels, gradients from the torch
+    re-evaluation in matchnerf_amd/autograd.py — compared with autograd through the CPU oracle."""
+    g, cfg, sd, batch_cpu = golden_case("nonlegacy")
     opt, model = build_model(g["meta"])
-    opt.nerf.rand_rays_train = 64
-    with pytest.raises(NotImplementedError, match="backward"):
-        model(to_batch(g), mode="train")
+    model.train()
+    opt.nerf.rand_rays_train = 96
+    opt.nerf.sample_stratified = False
+    batch = to_batch(g)
+    torch.manual_seed(0)
+    out = model(batch, mode="train")
+    idx = out.ray_idx
+    gt = batch.images[:, -1].reshape(1, 3, -1).permute(0, 2, 1)[:, idx]
+    loss = ((out.rgb - gt) ** 2).mean() + 0.1 * out.opacity.mean()
+    loss.backward()
+
+    sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    v = cfg.n_src_views
+    feats = O.encode_pairs(cfg, sd_req, batch_cpu["images"][0, :v])
+    ref = O.render_rays(cfg, sd_req, idx.cpu(), *split_poses(batch_cpu), batch_cpu["images"][0, :v], feats)
+    gt_c = batch_cpu["images"][0, -1].reshape(3, -1).t()[idx.cpu()]
+    loss_ref = ((ref[0] - gt_c) ** 2).mean() + 0.1 * ref[2].mean()
+    loss_ref.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
+    params = dict(model.named_parameters())
+    checked, worst = 0, 0.0
+    for name in ("nerf_dec.pts_linears.0.weight", "nerf_dec.pts_bias.weight", "nerf_dec.rgb_linear.weight",
+                 "nerf_dec.ray_attention.w_qs.weight", "nerf_dec.out_alpha_linear.2.weight",
+                 "feat_enc.transformer.layers.5.cross_attn_ffn.mlp.2.weight",
+                 "feat_enc.transformer.layers.1.self_attn.q_proj.weight", "feat_enc.backbone.conv1.weight",
+                 "feat_enc.featup_net.conv_l2rs.1.weight"):
+        a, b = params[name].grad.cpu(), sd_req[name].grad
+        scale = float(b.abs().max()) + 1e-12
+        rel = float((a - b).abs().max()) / scale
+        print(f"grad {name}: max|ref| {scale:.3e} rel err {rel:.2e}")
+        worst = max(worst, rel)
+        checked += 1
+    # head parameters agree to ~1e-5; parameters upstream of the positional encoding / bilinear taps to
+    # < 1 % of the gradient's max (torch-GPU vs torch-CPU coordinates differ by ulps, amplified 2^9 x)
+    assert checked == 9 and worst < 2e-2, worst
 
 
 def test_stratified_depths_match_oracle():
