@@ -192,3 +192,31 @@ def test_argument_checks(hip):
     dec.wstream_floats -= 256
     with pytest.raises(hip.MnerfError, match="wstream"):
         hip.decoder_chunk(dec, sc.views[0], rays, torch.zeros(16 * 64, 24, device="cuda"))
+
+
+def test_render_chunk_is_graph_capturable(hip):
+    """include/mnerf.h promises enqueue-only entry points (no allocation, no sync): capture a render
+    chunk into a HIP graph on a side stream, replay it twice, compare with the eager launch."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    dec, keep = make_decoder_struct(cfg, sd)
+    n = 1024
+    rays = make_rays_struct(cfg, batch, n, ray_begin=512)
+    ws = torch.empty(hip.render_workspace_bytes(n, cfg.sample_intvs, dec.cond_stride) // 4, device="cuda")
+    out = [torch.zeros(n, 3, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
+    hip.render_chunk(sc, dec, rays, ws, *out)          # eager (also performs one-time attribute set-up)
+    torch.cuda.synchronize()
+    eager = [t.clone() for t in out]
+    for t in out:
+        t.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.render_chunk(sc, dec, rays, ws, *out)
+    for _ in range(2):
+        for t in out:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(out, eager):
+            assert torch.equal(a, b)
+    assert linf(out[0], g["rgb"][0, 512:512 + n]) < 1e-4
