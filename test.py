@@ -1,29 +1,31 @@
 #!/usr/bin/env python
-"""Counterpart of the reference's test.py (test.py:10-33):
+"""Inference entry point on the MI355X hot path (counterpart of the reference's test.py:10-33).
+
     python test.py --yaml=test --name=run --nerf.rand_rays_test=4096 --nerf.sample_intvs=64
-Runs the MI355X hot path over the configured test sets (synthetic stand-ins offline)."""
+
+Options use the reference's ``--a.b.c=value`` grammar and YAML inheritance; the configured
+test sets are served by seeded synthetic scenes when no dataset is on disk."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-
-from matchnerf_amd import options  # noqa: E402
-from matchnerf_amd.coach import Coach  # noqa: E402
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 
-def main():
-    opt_cmd = options.parse_arguments(sys.argv[1:])
-    opt = options.set(opt_cmd=opt_cmd)
+def run(argv):
+    from matchnerf_amd import options
+    from matchnerf_amd.coach import Coach
+
+    opt = options.set(opt_cmd=options.parse_arguments(argv))
     options.save_options_file(opt)
-    m = Coach(opt)
-    m.build_networks()
-    m.restore_checkpoint()
-    m.load_dataset(splits=["test"])
+    coach = Coach(opt)
+    coach.build_networks()
+    coach.restore_checkpoint()
+    coach.load_dataset(splits=["test"])
     if opt.nerf.render_video:
-        m.test_model_video()
-    else:
-        m.test_model(save_images=bool(getattr(opt, "separate_save", False)))
+        return coach.test_model_video()
+    return coach.test_model(save_images=bool(getattr(opt, "separate_save", False)))
 
 
 if __name__ == "__main__":
-    main()
+    run(sys.argv[1:])
