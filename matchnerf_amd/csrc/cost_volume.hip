@@ -208,64 +208,181 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
   }
 }
 
-// ============================================================================ v2: segment walk
+// ============================================================================ segment walk
 // Same arithmetic as cost_volume_kernel, different traversal.  PMC showed that kernel bound by
 // the bytes the texture path delivers to registers (~18 TB/s of taps, 53 % of L1 peak), not by
 // L2/HBM — and consecutive samples of a ray move only ~1/4 texel at 1/8 resolution (~1/2 at 1/4),
-// so most of those bytes are the same texels again.  Here a slot (8 lanes) WALKS a segment of
-// CVW_SEG consecutive samples of one ray; for each view pair and scale it keeps the current 2x2
-// texel quad of both maps in registers (2 x 4 taps x 16 channels per lane) and reloads a quad
-// only when its integer texel changes.  Projections are evaluated once per (sample, view) and
-// parked in LDS; the per-sample cosine sums over pairs accumulate in LDS.
-// Two instantiations: 16 channels per lane (8 lanes/sample, 2 waves/SIMD) and 8 channels per lane
-// (16 lanes/sample, half the quad registers, 3 waves/SIMD — measured 7 % faster, the default).
+// so most of those bytes are the same texels again.  Here a slot (16 or 8 lanes) WALKS a segment
+// of CVW_SEG consecutive samples of one ray; for each view pair and scale it keeps the current 2x2
+// texel quad of both maps in registers and reloads a quad only when its top-left texel changes.
+// Per-sample cosine sums over pairs accumulate in LDS.
+// The first walk kernel (19.7 ms/frame) turned out VALU-bound on its own bookkeeping: 96 % VALU
+// busy, ~360 VALU instructions per (sample, pair, scale) step of a wave against ~90 of
+// interpolation + dot products.  This version (12.9 ms/frame) keeps the traversal with a lean step:
+//  * the bilinear set-up (texel index, fractions, border flags) is evaluated once per
+//    (sample, view, scale) in pass 1 and parked in LDS as a 16-byte record, instead of once per
+//    pair in the inner loop; a quad is identified by its top-left texel alone (one compare);
+//  * interpolation and the three dot products run on channel PAIRS (v_pk_mul/v_pk_fma_f32: the
+//    dwordx4 loads already put consecutive channels in consecutive registers);
+//  * the group reductions are compile-time DPP butterflies (quad_perm / row_half_mirror /
+//    row_mirror) instead of ds_bpermute shuffles with a run-time width;
+//  * reload addresses are 32-bit byte offsets from the scalar map base;
+//  * owner lanes accumulate the per-pair cosines with LDS float atomics (program order per lane,
+//    so the sum over pairs keeps the reference's pair order).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// pass-1 record of one (sample, view, scale).  The four taps of a quad are kept in four register
+// sets named by the PARITY of the texel's row and column (E/O), not by their position in the quad:
+// when the walk crosses one texel boundary only the two sets of the leaving row/column change, the
+// other two are reused as they are — no register moves, half the tap traffic of reloading a quad
+// (the kernel was bound by the texture-address unit: TA busy 92 % with whole-quad reloads).
+// The record carries what the inner loop needs to find each set's texel: offsets from the top-left
+// texel (+1 / +w if that neighbour is inside the map) and the parities.
+struct TapRec {
+  int o00;     // top-left texel index y0*w + x0
+  float fx, fy;
+  int flags;   // bit0/1: x offset of the even/odd column set; bit2/3: row offset (x w) of the even/odd
+               // row set; bit4: x0 odd; bit5: y0 odd
+};
+
+__device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {  // bilin_setup()'s arithmetic
+  float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
+  float x = ((gx + 1.0f) * 0.5f) * (float)(w - 1);
+  float y = ((gy + 1.0f) * 0.5f) * (float)(h - 1);
+  x = fminf(fmaxf(x, 0.0f), (float)(w - 1));
+  y = fminf(fmaxf(y, 0.0f), (float)(h - 1));
+  const float x0f = floorf(x), y0f = floorf(y);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int dx = x0 + 1 <= w - 1 ? 1 : 0, dy = y0 + 1 <= h - 1 ? 1 : 0;
+  const int px = x0 & 1, py = y0 & 1;
+  TapRec r;
+  r.o00 = y0 * w + x0;
+  r.fx = x - x0f;
+  r.fy = y - y0f;
+  r.flags = (px & dx) | ((~px & dx) << 1) | ((py & dy) << 2) | ((~py & dy) << 3) | (px << 4) | (py << 5);
+  return r;
+}
+
 #ifndef CVW_SEG
 #define CVW_SEG 16
 #endif
-// CPL = channels per lane (16 -> 8 lanes per sample, 8 -> 16 lanes per sample)
+#define CVW_CS_MAX 16  // cosine sums per sample the walk kernel supports (sum of groups)
+#ifndef CVW_FAST_COS
+#define CVW_FAST_COS 0
+#endif
+#ifndef CVW_WAVES
+#define CVW_WAVES 4  // 128 VGPRs; LDS (40 KB/workgroup at 3 views) allows 4 workgroups per CU
+#endif
 
-template <int CPL>
-struct QuadCache {
-  float t00[CPL], t01[CPL], t10[CPL], t11[CPL];
-  int o00, o01, o10, o11;
+template <int CPL>  // CPL = channels per lane (8 -> 16 lanes per sample, 16 -> 8 lanes per sample)
+struct PairQuad {
+  v2f t[2][2][CPL / 2];  // [row parity][column parity][channel pair]
+  int idx[2][2];         // texel held by each set (-1: none)
 };
 
 template <int CPL>
-__device__ __forceinline__ void quad_load(QuadCache<CPL>& q, const float* __restrict__ map, const Bilin& b, int sub) {
-  const float4* p00 = reinterpret_cast<const float4*>(map + (size_t)b.o00 * FEAT_C) + sub * (CPL / 4);
-  const float4* p01 = reinterpret_cast<const float4*>(map + (size_t)b.o01 * FEAT_C) + sub * (CPL / 4);
-  const float4* p10 = reinterpret_cast<const float4*>(map + (size_t)b.o10 * FEAT_C) + sub * (CPL / 4);
-  const float4* p11 = reinterpret_cast<const float4*>(map + (size_t)b.o11 * FEAT_C) + sub * (CPL / 4);
+__device__ __forceinline__ void tap_load(v2f (&t)[CPL / 2], const float* __restrict__ map, int texel,
+                                         unsigned lane_bytes) {
+  const v4f* p = reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(map) +
+                                              ((unsigned)texel * (unsigned)(FEAT_C * 4) + lane_bytes));
 #pragma unroll
   for (int k = 0; k < CPL / 4; ++k) {
-    const float4 a = p00[k], c = p01[k], d = p10[k], e = p11[k];
-    q.t00[4 * k] = a.x; q.t00[4 * k + 1] = a.y; q.t00[4 * k + 2] = a.z; q.t00[4 * k + 3] = a.w;
-    q.t01[4 * k] = c.x; q.t01[4 * k + 1] = c.y; q.t01[4 * k + 2] = c.z; q.t01[4 * k + 3] = c.w;
-    q.t10[4 * k] = d.x; q.t10[4 * k + 1] = d.y; q.t10[4 * k + 2] = d.z; q.t10[4 * k + 3] = d.w;
-    q.t11[4 * k] = e.x; q.t11[4 * k + 1] = e.y; q.t11[4 * k + 2] = e.z; q.t11[4 * k + 3] = e.w;
+    const v4f a = p[k];
+    t[2 * k] = a.lo;
+    t[2 * k + 1] = a.hi;
   }
-  q.o00 = b.o00;
-  q.o01 = b.o01;
-  q.o10 = b.o10;
-  q.o11 = b.o11;
 }
 
+// bring the four parity sets up to date for this record; returns the four set weights
 template <int CPL>
-__device__ __forceinline__ bool quad_stale(const QuadCache<CPL>& q, const Bilin& b) {
-  return (q.o00 != b.o00) | (q.o01 != b.o01) | (q.o10 != b.o10) | (q.o11 != b.o11);
+__device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __restrict__ map, int w, const float4 rec,
+                                            unsigned lane_bytes, float (&wt)[2][2]) {
+  const int o00 = __float_as_int(rec.x), fl = __float_as_int(rec.w);
+  const int ex0 = fl & 1, ex1 = (fl >> 1) & 1;
+  const int ey0 = (fl & 4) ? w : 0, ey1 = (fl & 8) ? w : 0;
+  const int b0 = o00 + ey0, b1 = o00 + ey1;
+  const int i00 = b0 + ex0, i01 = b0 + ex1, i10 = b1 + ex0, i11 = b1 + ex1;
+  if (i00 != q.idx[0][0]) { tap_load<CPL>(q.t[0][0], map, i00, lane_bytes); q.idx[0][0] = i00; }
+  if (i01 != q.idx[0][1]) { tap_load<CPL>(q.t[0][1], map, i01, lane_bytes); q.idx[0][1] = i01; }
+  if (i10 != q.idx[1][0]) { tap_load<CPL>(q.t[1][0], map, i10, lane_bytes); q.idx[1][0] = i10; }
+  if (i11 != q.idx[1][1]) { tap_load<CPL>(q.t[1][1], map, i11, lane_bytes); q.idx[1][1] = i11; }
+  const float fx = rec.y, fy = rec.z, gx = 1.0f - fx, gy = 1.0f - fy;
+  const bool px = fl & 16, py = fl & 32;
+  const float wxE = px ? fx : gx, wxO = px ? gx : fx;  // the even column is x0 (weight 1-fx) iff x0 is even
+  const float wyE = py ? fy : gy, wyO = py ? gy : fy;
+  wt[0][0] = wxE * wyE;  // same products as bilin_setup(): (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx fy
+  wt[0][1] = wxO * wyE;
+  wt[1][0] = wxE * wyO;
+  wt[1][1] = wxO * wyO;
 }
 
-template <int CPL>
-__device__ __forceinline__ void quad_interp(const QuadCache<CPL>& q, const Bilin& b, float (&out)[CPL]) {
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+  return v + __int_as_float(t);
+}
+
+// all-reduce over LPG adjacent lanes (LPG | 16, aligned): same pairing tree as the xor butterfly
+template <int LPG>
+__device__ __forceinline__ float dpp_group_sum(float v) {
+  if (LPG >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (LPG >= 4) v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (LPG >= 8) v = dpp_add<0x141>(v);  // row_half_mirror
+  if (LPG >= 16) v = dpp_add<0x140>(v); // row_mirror
+  return v;
+}
+
+// one (pair, scale): walk the CVW_SEG samples of this slot's segment
+template <int CPL, int LPG>
+__device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const float* __restrict__ m1, int fw,
+                                          const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
+                                          int rec_stride, float* __restrict__ cs_owner, int cs_stride, bool owner,
+                                          unsigned lane_bytes) {
+  PairQuad<CPL> qa, qb;
 #pragma unroll
-  for (int c = 0; c < CPL; ++c)  // same expression as sample16()
-    out[c] = q.t00[c] * b.w00 + q.t01[c] * b.w01 + q.t10[c] * b.w10 + q.t11[c] * b.w11;
+  for (int i = 0; i < 4; ++i) qa.idx[i >> 1][i & 1] = qb.idx[i >> 1][i & 1] = -1;
+  for (int js = 0; js < CVW_SEG; ++js) {
+    float wa[2][2], wb[2][2];
+    quad_update<CPL>(qa, m0, fw, rec_a[js * rec_stride], lane_bytes, wa);
+    quad_update<CPL>(qb, m1, fw, rec_b[js * rec_stride], lane_bytes, wb);
+    const v2f A00 = {wa[0][0], wa[0][0]}, A01 = {wa[0][1], wa[0][1]}, A10 = {wa[1][0], wa[1][0]}, A11 = {wa[1][1], wa[1][1]};
+    const v2f B00 = {wb[0][0], wb[0][0]}, B01 = {wb[0][1], wb[0][1]}, B10 = {wb[1][0], wb[1][0]}, B11 = {wb[1][1], wb[1][1]};
+    v2f dot2 = {0.f, 0.f}, na2 = {0.f, 0.f}, nb2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CPL / 2; ++k) {
+      v2f fa = qa.t[0][0][k] * A00;
+      fa = __builtin_elementwise_fma(qa.t[0][1][k], A01, fa);
+      fa = __builtin_elementwise_fma(qa.t[1][0][k], A10, fa);
+      fa = __builtin_elementwise_fma(qa.t[1][1][k], A11, fa);
+      v2f fb = qb.t[0][0][k] * B00;
+      fb = __builtin_elementwise_fma(qb.t[0][1][k], B01, fb);
+      fb = __builtin_elementwise_fma(qb.t[1][0][k], B10, fb);
+      fb = __builtin_elementwise_fma(qb.t[1][1][k], B11, fb);
+      dot2 = __builtin_elementwise_fma(fa, fb, dot2);
+      na2 = __builtin_elementwise_fma(fa, fa, na2);
+      nb2 = __builtin_elementwise_fma(fb, fb, nb2);
+    }
+    const float dot = dpp_group_sum<LPG>(dot2.x + dot2.y);
+    const float na = dpp_group_sum<LPG>(na2.x + na2.y);
+    const float nb = dpp_group_sum<LPG>(nb2.x + nb2.y);
+#if CVW_FAST_COS
+    // 1-ulp hardware sqrt / rcp instead of the correctly rounded sequences (~45 VALU per step):
+    // |error| <= ~3 ulp of a cosine, 2e-7 absolute
+    const float da = fmaxf(__builtin_amdgcn_sqrtf(na), 1e-8f), db = fmaxf(__builtin_amdgcn_sqrtf(nb), 1e-8f);
+    const float c = dot * __builtin_amdgcn_rcpf(da * db);
+#else
+    const float da = fmaxf(sqrtf(na), 1e-8f), db = fmaxf(sqrtf(nb), 1e-8f);
+    const float c = dot / (da * db);
+#endif
+    if (owner) __hip_atomic_fetch_add(cs_owner + js * cs_stride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
 }
 
 template <int CPL>
-__global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_kernel(mnerf_scene sc, mnerf_rays R,
-                                                                  int cond_stride,
-                                                                  float* __restrict__ cond) {
+__global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_lean_kernel(mnerf_scene sc, mnerf_rays R,
+                                                                                   int cond_stride,
+                                                                                   float* __restrict__ cond) {
   constexpr int LPS = FEAT_C / CPL;     // lanes per sample slot (8 or 16)
   constexpr int NSLOT = 256 / LPS;      // ray slots per workgroup (32 or 16)
   constexpr int SPL = CVW_SEG / LPS > 0 ? CVW_SEG / LPS : 1;  // pass-1 samples per lane
@@ -273,17 +390,20 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
   const int V = sc.n_views;
   const int sub = threadIdx.x % LPS;
   const int slot = threadIdx.x / LPS;                               // NSLOT adjacent rays
-  float* uv_lds = cvw_smem + (size_t)slot * CVW_SEG * V * 2;       // [seg sample][view][u,v]
-  float* cs_lds = cvw_smem + NSLOT * CVW_SEG * V * 2 + slot * CVW_SEG * 16;  // [seg sample][<=16 cos sums]
+  const int rec_stride = V * 2;                                     // records per segment sample
+  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
+  const int sumG = G0 + G1;
+  const int cs_stride = (sumG + 3) & ~3;                            // cosine sums per segment sample in LDS
+  float4* rec_lds = reinterpret_cast<float4*>(cvw_smem) + (size_t)slot * CVW_SEG * rec_stride;  // [js][view][scale]
+  float* cs_lds = cvw_smem + (size_t)NSLOT * CVW_SEG * rec_stride * 4 + slot * CVW_SEG * cs_stride;  // [js][cos sums]
   const int S = R.n_samples;
   const int P = V * (V - 1) / 2;
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
-  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
-  const int sumG = G0 + G1;
   const float inv_pairs = 1.0f / (float)P;
   const int n_seg = (S + CVW_SEG - 1) / CVW_SEG;
+  const unsigned lane_bytes = (unsigned)sub * CPL * 4;
 
-  // XCD-major contiguous runs of 32-ray blocks (see cost_volume_kernel)
+  // XCD-major contiguous runs of ray blocks (see cost_volume_kernel)
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
   const int q8 = nwg >> 3, r8 = nwg & 7;
@@ -303,7 +423,7 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
     const int ray = (int)ray_ll;
     const RayGeom g = make_ray(R, ray);
 
-    // ---- pass 1: projections, colours, masks.  Lane `sub` takes segment samples sub, sub+LPS, ..
+    // ---- pass 1: projections, tap records, colours, masks.  Lane `sub` takes samples sub, sub+LPS, ..
 #pragma unroll
     for (int half = 0; half < SPL; ++half) {
       const int js = sub + LPS * half;
@@ -317,8 +437,12 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
       for (int v = 0; v < V; ++v) {
         float u, w_, z;
         project(sc.views[v], px, py, pz, wm1, hm1, u, w_, z);
-        uv_lds[(js * V + v) * 2 + 0] = u;
-        uv_lds[(js * V + v) * 2 + 1] = w_;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s >= sc.n_scales) break;
+          const TapRec t = tap_setup(u, w_, sc.fh[s], sc.fw[s]);
+          rec_lds[(js * V + v) * 2 + s] = make_float4(__int_as_float(t.o00), t.fx, t.fy, __int_as_float(t.flags));
+        }
         const Bilin b = bilin_setup(u, w_, R.height, R.width);
         const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
         const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
@@ -337,9 +461,8 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
         for (int c = dc + 1; c < cond_stride; ++c) out[c] = 0.0f;
       }
     }
-#pragma unroll
-    for (int i = 0; i < (CVW_SEG * 16) / LPS; ++i) cs_lds[i * LPS + sub] = 0.0f;  // this slot's cosine sums
-    // slot-local LDS hand-off: the 8 lanes of a slot belong to one wave => wave-level ordering
+    for (int i = sub; i < CVW_SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
+    // slot-local LDS hand-off: the lanes of a slot belong to one wave => wave-level ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -358,31 +481,16 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
           const int G = sc.n_group[s];
           const int lpg = LPS / G;  // lanes per channel group
           const int goff = s ? G0 : 0;
-          QuadCache<CPL> qa, qb;
-          qa.o00 = qa.o01 = qa.o10 = qa.o11 = -1;
-          qb.o00 = qb.o01 = qb.o10 = qb.o11 = -1;
-          for (int js = 0; js < CVW_SEG; ++js) {
-            const float ua = uv_lds[(js * V + a) * 2], va = uv_lds[(js * V + a) * 2 + 1];
-            const float ub = uv_lds[(js * V + b) * 2], vb = uv_lds[(js * V + b) * 2 + 1];
-            const Bilin ba = bilin_setup(ua, va, fh, fw);
-            const Bilin bb = bilin_setup(ub, vb, fh, fw);
-            if (quad_stale(qa, ba)) quad_load(qa, m0, ba, sub);
-            if (quad_stale(qb, bb)) quad_load(qb, m1, bb, sub);
-            float fa[CPL], fb[CPL];
-            quad_interp(qa, ba, fa);
-            quad_interp(qb, bb, fb);
-            float dot = 0.f, na = 0.f, nb = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-              dot += fa[c] * fb[c];
-              na += fa[c] * fa[c];
-              nb += fb[c] * fb[c];
-            }
-            dot = group_reduce(dot, lpg);
-            na = group_reduce(na, lpg);
-            nb = group_reduce(nb, lpg);
-            const float da = fmaxf(sqrtf(na), 1e-8f), db = fmaxf(sqrtf(nb), 1e-8f);
-            if ((sub % lpg) == 0) cs_lds[js * 16 + goff + sub / lpg] += dot / (da * db);  // owner lane, pair order
+          const float4* rec_a = rec_lds + a * 2 + s;
+          const float4* rec_b = rec_lds + b * 2 + s;
+          float* cs_owner = cs_lds + goff + sub / lpg;
+          const bool owner = (sub % lpg) == 0;
+          switch (lpg) {
+            case 1: lean_walk<CPL, 1>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
+            case 2: lean_walk<CPL, 2>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
+            case 4: lean_walk<CPL, 4>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
+            case 8: lean_walk<CPL, 8>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
+            default: lean_walk<CPL, 16>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
           }
         }
       }
@@ -396,10 +504,10 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : 3)) void cost_volume_walk_ker
       const int js = sub + LPS * half;
       if (js < CVW_SEG && ray_live && (j0 + js < S)) {
         float* out = cond + ((size_t)ray * S + j0 + js) * cond_stride;
-        for (int c = 0; c < sumG; ++c) out[c] = cs_lds[js * 16 + c] * inv_pairs;
+        for (int c = 0; c < sumG; ++c) out[c] = cs_lds[js * cs_stride + c] * inv_pairs;
       }
     }
-    __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds are rewritten by the next unit
+    __builtin_amdgcn_wave_barrier();  // cs_lds / rec_lds are rewritten by the next unit
   }
 }
 
@@ -442,29 +550,30 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
   if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
-  int variant = 2;  // 1 / 2 = segment walk (register quad cache), 8 / 16 lanes per sample; 0 = one sample per slot iteration
+  int variant = 3;  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = one sample per slot iteration
   if (const char* e = getenv("MNERF_CV_VARIANT")) variant = atoi(e);
-  if (sumG > 16) variant = 0;
-  if (variant == 1 || variant == 2) {
-    const int nslot = variant == 1 ? 32 : 16;
-    const size_t lds = (size_t)(nslot * CVW_SEG * scene->n_views * 2 + nslot * CVW_SEG * 16) * sizeof(float);
-    static size_t lds_set[3] = {0, 0, 0};
-    if (lds > lds_set[variant]) {
-      if (variant == 1)
-        (void)hipFuncSetAttribute((const void*)cost_volume_walk_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (sumG > CVW_CS_MAX) variant = 0;
+  if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
+    const int nslot = variant == 4 ? 32 : 16;
+    const size_t lds = (size_t)(nslot * CVW_SEG * scene->n_views * 2 * 4 + nslot * CVW_SEG * ((sumG + 3) & ~3)) * sizeof(float);
+    MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
+    static size_t lean_lds_set[2] = {0, 0};
+    if (lds > lean_lds_set[variant - 3]) {
+      if (variant == 4)
+        (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       else
-        (void)hipFuncSetAttribute((const void*)cost_volume_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      lds_set[variant] = lds;
+        (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lean_lds_set[variant - 3] = lds;
     }
     long long wgs = ((long long)rays->n_rays + nslot - 1) / nslot;
-    int cap = variant == 1 ? 2048 : 4096;
+    int cap = variant == 4 ? 2048 : 4096;
     if (const char* e = getenv("MNERF_CV_GRID")) cap = atoi(e);
     if (wgs > cap) wgs = cap;
-    if (variant == 1)
-      hipLaunchKernelGGL(cost_volume_walk_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+    if (variant == 4)
+      hipLaunchKernelGGL(cost_volume_lean_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                          *scene, *rays, cond_stride, cond);
     else
-      hipLaunchKernelGGL(cost_volume_walk_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+      hipLaunchKernelGGL(cost_volume_lean_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                          *scene, *rays, cond_stride, cond);
   } else {
     hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,

@@ -27,7 +27,7 @@ from .gmflow import GMFlow, pair_major_to_view_chunks
 # rays per kernel launch when a full image is rendered.  The reference's
 # ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
 # chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
-MAX_RAYS_PER_LAUNCH = 65536
+MAX_RAYS_PER_LAUNCH = int(__import__('os').environ.get('MNERF_MAX_RAYS', 65536))
 
 
 class MatchNeRF(torch.nn.Module):
