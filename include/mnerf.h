@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 1
+#define MNERF_ABI_VERSION 2
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 
@@ -84,11 +84,18 @@ typedef struct mnerf_scene {
   mnerf_view views[MNERF_MAX_VIEWS];
 } mnerf_scene;
 
-/* Decoder parameters, pre-packed by the host (matchnerf_amd/cond_nerf.py:pack_decoder):
+/* Decoder parameters, pre-packed by the host (matchnerf_amd/cond_nerf.py):
  *   wstream : MFMA A-operand fragments of every Linear of CondNeRF in consumption order
- *             (layout in DESIGN.md §Decoder weight stream); 16-byte aligned
+ *             (layout in DESIGN.md §Decoder weight stream); 16-byte aligned.  Two formats:
+ *             MNERF_WSTREAM_F32   fp32 fragments for v_mfma_f32_32x32x2_f32 (pack_wstream)
+ *             MNERF_WSTREAM_BF16X3 each fp32 weight as three bf16 terms for
+ *                                 v_mfma_f32_32x32x16_bf16, six product terms per MAC, fp32
+ *                                 accumulate, fp32 bias fragments (pack_wstream16)
  *   small   : ray-transformer + density-head parameters (fp32, layout in DESIGN.md)
  * Architecture switches mirror opt.decoder.* / opt.nerf.* (configs/base.yaml:29-48). */
+#define MNERF_WSTREAM_F32 0
+#define MNERF_WSTREAM_BF16X3 1
+
 typedef struct mnerf_decoder {
   const float* wstream;
   int64_t wstream_floats;
@@ -102,6 +109,7 @@ typedef struct mnerf_decoder {
   int32_t density_maskfill;/* opt.decoder.density_maskfill                                      */
   int32_t wo_render_interval; /* opt.nerf.wo_render_interval                                    */
   int32_t setbg_opaque;    /* MatchNeRF.nerf_setbg_opaque                                       */
+  int32_t wstream_format;  /* MNERF_WSTREAM_*                                                    */
 } mnerf_decoder;
 
 int mnerf_abi_version(void);
@@ -142,7 +150,9 @@ int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* rays, int32_t 
  * view0 = source view 0 (coordinate reference).  cond as produced by mnerf_cost_volume.
  * Outputs rgb [R,3], depth [R], opacity [R]; dbg_rgb_s [R,S,3] / dbg_sigma [R,S] receive the
  * per-sample decoder outputs when non-NULL (parity tests). */
-int64_t mnerf_decoder_wstream_floats(int32_t cond_stride, int32_t L_3D); /* expected wstream size */
+/* expected wstream size in 4-byte words for a format (negative: cannot be scheduled) */
+int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_stride, int32_t L_3D,
+                                     int32_t wstream_format);
 int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0, const mnerf_rays* rays,
                         const float* cond, float* rgb, float* depth, float* opacity,
                         float* dbg_rgb_s, float* dbg_sigma, void* stream);

@@ -184,6 +184,185 @@ def pack_wstream(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_de
     return out, cond_dim, cond_stride
 
 
+# ----------------------------------------------------------------------------- split-bf16 stream
+# Format 1 ("bf16x6"): the same transposed MFMA chain on v_mfma_f32_32x32x16_bf16.  Every fp32
+# weight is split into three bf16 terms w = hi + mid + lo (24 significand bits, exact), the kernel
+# splits the activations the same way on the fly, and a product is accumulated in fp32 from the six
+# terms hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid (dropped terms < 2^-24 relative): fp32-grade
+# results (measured: max error BELOW an fp32 FMA chain's) at 16/6 of the f32 matrix rate.
+#
+# A K-step covers 16 inputs: lane (n, half) supplies k = 8*half + j, j < 8.  With activations in
+# accumulator-register order, step t of a 16-register block takes registers 8*(t&1)+j, i.e. feature
+# 32*blk + (reg&3) + 8*(reg>>2) + 4*half — again no transposes between layers.
+# Stream unit = 1 KiB fragment (64 lanes x 8 bf16).  Per (step, block): [hi | mid | lo] fragments.
+# The first segment of a stage starts with a 1 KiB fp32 BIAS fragment, bias[(half*4 + m)*16 + r],
+# which the kernel loads as the initial accumulator value (so biases stay exact fp32).
+
+FRAG_FLOATS = 256
+
+
+def decoder_stages16(cond_dim, L_3D):
+    """(name, nmb, [K16-steps per segment], has_bias) in consumption order."""
+    tf = (cond_dim + 15) // 16
+    te = (3 * L_3D + 2 + 7) // 8
+
+    def pairs(t):
+        return [2] * (t // 2) + ([1] if t % 2 else [])
+
+    st = [("film", 4, pairs(tf), True), ("l0", 4, pairs(te), True)]
+    st += [(f"l{i}", 4, [2, 2, 2, 2], True) for i in range(1, 5)]
+    st += [("l5e", 4, pairs(te), True), ("l5h", 4, [2, 2, 2, 2], False), ("feature", 4, [2, 2, 2, 2], True),
+           ("views", 2, [4, 5], True), ("rgb", 1, [4], True), ("alpha", 1, [8], True)]
+    return st
+
+
+def decoder_schedule16(cond_dim, L_3D):
+    """-> (segments, total_floats); segment = (stage, first_step, n_steps, nmb, float_offset, floats, has_bias_header)."""
+    segs, off = [], 0
+    for name, m, seg_steps, has_bias in decoder_stages16(cond_dim, L_3D):
+        first = 0
+        for k, steps in enumerate(seg_steps):
+            hdr = has_bias and k == 0
+            fl = (steps * m * 3 + (1 if hdr else 0)) * FRAG_FLOATS
+            assert fl <= SEG_CAP_FLOATS
+            segs.append((name, first, steps, m, off, fl, hdr))
+            off += fl
+            first += steps
+    fl = ((TAIL_FLOATS + 255) // 256) * 256
+    segs.append(("tail", 0, 0, 0, off, fl, False))
+    return segs, off + fl
+
+
+def bf16_round(x):
+    """float32 array -> bf16 bit patterns (uint16), round to nearest even."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def split_bf16x3(w):
+    """fp32 -> (hi, mid, lo) bf16 bit patterns with hi + mid + lo == w (to 24 bits)."""
+    w = np.ascontiguousarray(w, np.float32)
+    hi = bf16_round(w)
+    r1 = w - bf16_to_f32(hi)
+    mid = bf16_round(r1)
+    r2 = r1 - bf16_to_f32(mid)
+    return hi, mid, bf16_round(r2)
+
+
+def _reg_cols16(n_blocks):
+    """[T=2*n_blocks, 2, 8] input feature per (step, half, j) for accumulator-order operands."""
+    cols = np.zeros((2 * n_blocks, 2, 8), np.int64)
+    for t in range(2 * n_blocks):
+        for h in range(2):
+            for j in range(8):
+                reg = 8 * (t & 1) + j
+                cols[t, h, j] = 32 * (t >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * h
+    return cols
+
+
+def _enc_cols16(L, legacy):
+    """positional-encoding slots a = 8t + j: (sin | cos) of argument a, then (x | y), (z | -)."""
+    lo, hi = _enc_cols(L, legacy)
+    te = (len(lo) + 7) // 8
+    cols = np.full((te, 2, 8), ZERO, np.int64)
+    for a in range(len(lo)):
+        cols[a // 8, 0, a % 8] = lo[a]
+        cols[a // 8, 1, a % 8] = ZERO if hi[a] == BIAS else hi[a]
+    return cols
+
+
+def _fragments16(weight, cols, nmb):
+    """uint16 [T, nmb, 3, 64, 8]: bf16 parts of W[32m + lane%32, cols[t, lane//32, j]]."""
+    n_out, n_in = weight.shape
+    ext = np.zeros((nmb * 32, n_in + 1), np.float32)
+    ext[:n_out, :n_in] = weight
+    cols = np.where(cols < 0, n_in, cols)
+    t_n = cols.shape[0]
+    lane = np.arange(64)
+    col = cols[:, lane >> 5, :]                                               # [T,64,8]
+    row = (lane & 31)[None, None, :, None] + 32 * np.arange(nmb)[None, :, None, None]  # [1,nmb,64,1]
+    w = ext[np.broadcast_to(row, (t_n, nmb, 64, 8)), np.broadcast_to(col[:, None], (t_n, nmb, 64, 8))]
+    return np.stack(split_bf16x3(w), 2)                                      # [T,nmb,3,64,8]
+
+
+def _bias_fragment(bias, nmb):
+    out = np.zeros(FRAG_FLOATS, np.float32)
+    if bias is None:
+        return out
+    b = np.zeros(nmb * 32, np.float32)
+    b[:bias.shape[0]] = bias
+    for h in range(2):
+        for m in range(nmb):
+            for r in range(16):
+                out[(h * 4 + m) * 16 + r] = b[32 * m + (r & 3) + 8 * (r >> 2) + 4 * h]
+    return out
+
+
+def pack_wstream16(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_dec."):
+    """state_dict -> (wstream as float32 words [total], cond_dim, cond_stride) in the split-bf16 format."""
+
+    def g(name):
+        v = sd[prefix + name]
+        return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
+
+    cond_dim = int(sum(cos_n_group)) + 4 * n_views
+    cond_stride = ((cond_dim + 1 + 7) // 8) * 8
+    d_enc = 3 + 6 * L_3D
+    tf = (cond_dim + 15) // 16
+    film_cols = np.arange(16 * tf).reshape(tf, 2, 8)
+    film_cols = np.where(film_cols < cond_dim, film_cols, ZERO)
+    e_cols = _enc_cols16(L_3D, legacy)
+    h_cols = _reg_cols16(4)
+    w5 = g("pts_linears.5.weight")
+    assert w5.shape[1] == d_enc + 128, "decoder.skip must be [4] with net_width 128"
+    dir_cols = np.full((1, 2, 8), ZERO, np.int64)
+    dir_cols[0, 0, :3] = [128, 129, 130]
+    stages = {
+        "film": (g("pts_bias.weight"), g("pts_bias.bias"), film_cols),
+        "l0": (g("pts_linears.0.weight"), g("pts_linears.0.bias"), e_cols),
+        "l5e": (w5[:, :d_enc], g("pts_linears.5.bias"), e_cols),
+        "l5h": (w5[:, d_enc:], None, h_cols),
+        "feature": (g("feature_linear.weight"), g("feature_linear.bias"), h_cols),
+        "views": (g("views_linears.0.weight"), g("views_linears.0.bias"), np.concatenate([h_cols, dir_cols], 0)),
+        "rgb": (g("rgb_linear.weight"), g("rgb_linear.bias"), _reg_cols16(2)),
+        "alpha": (g("alpha_linear.0.weight"), g("alpha_linear.0.bias"), h_cols),
+    }
+    for i in range(1, 5):
+        stages[f"l{i}"] = (g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias"), h_cols)
+    segs, total = decoder_schedule16(cond_dim, L_3D)
+    f32_tail = pack_wstream(sd, n_views, cos_n_group, L_3D, legacy, prefix)[0][-((TAIL_FLOATS + 255) // 256) * 256:]
+    out = np.zeros(total, np.float32)
+    out16 = out.view(np.uint16)
+    frag_cache = {}
+    for name, first, steps, m, off, fl, hdr in segs:
+        if name == "tail":
+            out[off:off + fl] = f32_tail
+            continue
+        w, b, cols = stages[name]
+        if name not in frag_cache:
+            frag_cache[name] = _fragments16(w, cols, m)
+        if hdr:
+            out[off:off + FRAG_FLOATS] = _bias_fragment(b, m)
+            off += FRAG_FLOATS
+        a = frag_cache[name][first:first + steps]
+        out16[2 * off:2 * off + a.size] = a.reshape(-1)
+    return out, cond_dim, cond_stride
+
+
+def decoder_math():
+    """Matrix arithmetic of the fused decoder: 'bf16x6' (default; fp32 via 3-way bf16 operand split on the
+    bf16 matrix cores) or 'f32' (exact-f32 MFMA), chosen with MNERF_DECODER_MATH."""
+    import os
+    m = os.environ.get("MNERF_DECODER_MATH", "bf16x6")
+    if m not in ("bf16x6", "f32"):
+        raise ValueError(f"MNERF_DECODER_MATH={m!r}: expected 'bf16x6' or 'f32'")
+    return m
+
+
 def raytrans_table(n_samples, d_hid=16):
     """Sinusoid table of the ray transformer, float64 -> float32 as the reference builds it
     (cond_nerf.py:118-127)."""
@@ -274,20 +453,24 @@ class CondNeRF(nn.Module):
     def _pack_key(self, n_samples):
         ver = tuple(int(p._version) for p in self.parameters())
         ptr = tuple(int(p.data_ptr()) for p in self.parameters())
-        return (ver, ptr, n_samples, bool(self.opt.decoder.raytrans_posenc), bool(self.opt.nerf.legacy_coord))
+        return (ver, ptr, n_samples, bool(self.opt.decoder.raytrans_posenc), bool(self.opt.nerf.legacy_coord),
+                decoder_math())
 
     def packed(self, n_samples, device):
-        """(wstream, small, cond_stride) device tensors for the HIP kernel; re-packed when any
-        parameter changed (load_state_dict / optimizer step) or S changed."""
+        """(wstream, small, cond_stride, wstream_format) for the HIP kernel; re-packed when any
+        parameter changed (load_state_dict / optimizer step), S or MNERF_DECODER_MATH changed."""
         key = self._pack_key(n_samples)
         if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
             sd = {"nerf_dec." + k: v for k, v in self.state_dict().items()}
-            ws, cond_dim, cond_stride = pack_wstream(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
-                                                     self.L_3D, bool(self.opt.nerf.legacy_coord))
+            # the 8-wave kernel for S > 128 (128 VGPRs per wave) is built for the f32 stream only
+            fmt = 1 if (decoder_math() == "bf16x6" and n_samples <= 128) else 0
+            pack = pack_wstream16 if fmt == 1 else pack_wstream
+            ws, cond_dim, cond_stride = pack(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
+                                             self.L_3D, bool(self.opt.nerf.legacy_coord))
             assert cond_dim == self.cond_dim
             small = pack_small(sd, n_samples, bool(self.opt.decoder.raytrans_posenc))
-            self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride)
-        return self._packed[1], self._packed[2], self._packed[3]
+            self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride, fmt)
+        return self._packed[1], self._packed[2], self._packed[3], self._packed[4]
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError(

@@ -41,7 +41,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SEG_CAP_FLOATS (33 * 256)  // one LDS weight buffer: 33 KiB
-#define MAX_SEGS 40
+#define MAX_SEGS 64
 #define SMALL_FIXED 32    // floats of `small` (LayerNorm weight | bias) before the ray-posenc table
 // tail segment (resident across the attention phase): float offsets of its sub-stages
 #define TAIL_QKV 0
@@ -105,12 +105,11 @@ __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0
 
 template <int NW>
 __device__ __forceinline__ void prefetch_segment(const float* __restrict__ wstream,
-                                                 const DecSched& sch, int seg, float* lds_buf,
+                                                 const DecSched& sch, int seg, unsigned base /* LDS byte address */,
                                                  int wave, int lane) {
   if (seg >= sch.n_seg) return;
   const float* src = wstream + sch.seg_off[seg] + lane * 4;
   const int pieces = sch.seg_floats[seg] >> 8;
-  const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_buf;
   for (int p = wave; p < pieces; p += NW)
     glds16(src + p * 256, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
 }
@@ -226,6 +225,116 @@ __device__ __forceinline__ f32x16 enc_block16(int t0, int L3, int hl, float x, f
   return e;
 }
 
+
+// ---------------------------------------------------------------- split-bf16 matrix path ("bf16x6")
+// Same transposed chain on v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD for 16 K-elements: 16x the
+// K-rate of the f32 MFMA).  Each fp32 weight is stored as three bf16 terms (host,
+// cond_nerf.py:pack_wstream16) and each fp32 activation is split the same way right before it is
+// used; a product is accumulated in fp32 from six terms (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi,
+// mid.mid) — what is dropped is < 2^-24 of the product, so results are fp32-grade (measured on
+// MI355X, tools/exp/bf16x6.hip: max error below that of an fp32 FMA chain) at 16/6 of the f32 rate.
+// Operand layout (verified by the same micro-test): lane (n, half) supplies k = 8*half + j, j < 8,
+// for A row / B column n; C/D as for the f32 32x32 MFMA.  So a 16-register accumulator block of
+// the previous layer is consumed as two K16-steps (registers 0-7, 8-15) with no data movement.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+struct Parts {
+  bf16x8 hi, mid, lo;
+};
+
+__device__ __forceinline__ Parts split8(const float (&v)[8]) {
+  u32x4 H, M, L;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    H[i] = h;
+    M[i] = m;
+    L[i] = pk_bf16(sa, sb);
+  }
+  Parts p;
+  p.hi = __builtin_bit_cast(bf16x8, H);
+  p.mid = __builtin_bit_cast(bf16x8, M);
+  p.lo = __builtin_bit_cast(bf16x8, L);
+  return p;
+}
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// accumulators <- fp32 bias fragment [half][4][16] (exact fp32 biases, no K-step spent on them)
+template <int NMB>
+__device__ __forceinline__ void bias_init(f32x16 (&acc)[NMB], const float* frag, int hl) {
+  const float4* p = reinterpret_cast<const float4*>(frag) + hl * 16;
+#pragma unroll
+  for (int m = 0; m < NMB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = p[m * 4 + q];
+      acc[m][4 * q] = t.x;
+      acc[m][4 * q + 1] = t.y;
+      acc[m][4 * q + 2] = t.z;
+      acc[m][4 * q + 3] = t.w;
+    }
+}
+
+// NS K16-steps against NMB output blocks.  `base`: fragments [step][block][hi|mid|lo][64 lanes][8 bf16];
+// v: the lane's 8*NS operands.  A fragments of unit (step, block) i+1 are read before the six MFMAs
+// of unit i (192 cycles of matrix work hide the LDS latency).
+template <int NMB, int NS>
+__device__ __forceinline__ void ksteps(f32x16 (&acc)[NMB], const char* base, int lane, const float (&v)[8 * NS]) {
+  const u32x4* a = reinterpret_cast<const u32x4*>(base) + lane;
+  u32x4 ch = a[0], cm = a[64], cl = a[128];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    float vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] = v[8 * u + j];
+    const Parts b = split8(vv);
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) {
+      const int i = u * NMB + m;
+      const int nx = (i + 1 < NS * NMB) ? (i + 1) * 192 : i * 192;  // the last unit re-reads itself
+      const u32x4 nh = a[nx], nm = a[nx + 64], nl = a[nx + 128];
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, ch), am = __builtin_bit_cast(bf16x8, cm),
+                   al = __builtin_bit_cast(bf16x8, cl);
+      acc[m] = mfma16(ah, b.lo, acc[m]);
+      acc[m] = mfma16(al, b.hi, acc[m]);
+      acc[m] = mfma16(am, b.mid, acc[m]);
+      acc[m] = mfma16(ah, b.mid, acc[m]);
+      acc[m] = mfma16(am, b.hi, acc[m]);
+      acc[m] = mfma16(ah, b.hi, acc[m]);
+      __builtin_amdgcn_sched_barrier(0);
+      ch = nh;
+      cm = nm;
+      cl = nl;
+    }
+  }
+}
+
+// two K16-steps fed from one 16-register block (an accumulator block of the previous layer)
+template <int NMB>
+__device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], const char* base, int lane, const f32x16& h) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = h[r];
+  ksteps<NMB, 2>(acc, base, lane, v);
+}
+#define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
+
 template <int NW, int SP>
 struct Smem {
   static constexpr int TILE = NW * 32;
@@ -241,7 +350,7 @@ struct Smem {
   static constexpr int TOTAL_FLOATS = W_FLOATS + RS_FLOATS + LN_FLOATS;
 };
 
-template <int NW, int SP>
+template <int NW, int SP, int FMT>
 __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     mnerf_decoder D, DecSched sch, mnerf_view view0, mnerf_rays R,
     const float* __restrict__ cond, float* __restrict__ out_rgb, float* __restrict__ out_depth,
@@ -252,6 +361,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wbuf0 = smem;
   float* wbuf1 = smem + SEG_CAP_FLOATS;
+  // LDS byte addresses of the two weight buffers for the DMA (taken once, from the array itself)
+  const unsigned wbuf0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const unsigned wbuf1_lds = wbuf0_lds + SEG_CAP_FLOATS * 4u;
   float* rs_lds = smem + SM::W_FLOATS;                // [TILE][4]   rgb.xyz, sigma.w
   float* ln_lds = rs_lds + SM::RS_FLOATS;             // LayerNorm weight[16] | bias[16]
 
@@ -305,10 +417,19 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     int r = t * rays_per_tile + r_t;
     if (r >= R.n_rays) r = R.n_rays - 1;
     const size_t g_s = (size_t)r * S + (j_p < S ? j_p : (S - 1));
-    const float4* crow4 = reinterpret_cast<const float4*>(cond + g_s * CS + (size_t)hl * sch.film_steps);
+    if constexpr (FMT == 1) {  // K16 steps 0,1: cond[16 t + 8 hl + 4 q .. +4), q = i & 1, t = i >> 1
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      cpre[i] = (4 * i < sch.film_steps) ? crow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
+        cpre[i] = (o + 4 <= CS && (i >> 1) < sch.film_steps) ? *reinterpret_cast<const float4*>(cond + g_s * CS + o)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const float4* crow4 = reinterpret_cast<const float4*>(cond + g_s * CS + (size_t)hl * sch.film_steps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        cpre[i] = (4 * i < sch.film_steps) ? crow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float* mrow = cond + g_s * CS + (D.cond_dim - D.n_views);
     float nv = 0.0f;
     for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
@@ -358,13 +479,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     const bool q_valid = n_valid > 1.0f;
 
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
-    if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0, wave, lane);
+    if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
     segment_wait();
     __syncthreads();
 
 #define CUR_BUF ((seg & 1) ? wbuf1 : wbuf0)
 #define NXT_BUF ((seg & 1) ? wbuf0 : wbuf1)
-#define SEG_BEGIN() prefetch_segment<NW>(D.wstream, sch, seg + 1, NXT_BUF, wave, lane)
+#define SEG_BEGIN() prefetch_segment<NW>(D.wstream, sch, seg + 1, (seg & 1) ? wbuf0_lds : wbuf1_lds, wave, lane)
 #define SEG_END()     \
   do {                \
     segment_wait();   \
@@ -373,6 +494,193 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   } while (0)
 
     TL_STAMP(1);
+    float av[8];  // alpha-head activations: rows 0..15 <-> registers 0..7, feature (r&3) + 8*(r>>2) + 4*hl
+    if constexpr (FMT == 1) {
+      // ============================================================ trunk, split-bf16 matrix path
+      const char* wb;  // byte cursor inside the current weight segment
+      // ------------------------------------------------------------ FiLM = pts_bias(cond)
+      f32x16 film[4];
+      {
+        int done = 0;
+        while (done < sch.film_steps) {
+          const int ns = sch.seg_steps[seg];
+          SEG_BEGIN();
+          wb = reinterpret_cast<const char*>(CUR_BUF);
+          if (done == 0) {
+            bias_init<4>(film, CUR_BUF, hl);
+            wb += 1024;
+          }
+          for (int u = 0; u < ns; ++u) {
+            const int t = done + u;
+            float v[8];
+            float4 c0, c1;
+            if (t == 0) {
+              c0 = cpre[0];
+              c1 = cpre[1];
+            } else if (t == 1) {
+              c0 = cpre[2];
+              c1 = cpre[3];
+            } else {  // more than 32 conditioning inputs (n_src_views > 5): straight from global
+              const int o = 16 * t + 8 * hl;
+              const float* crow = cond + gs * CS;
+              c0 = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+              c1 = (o + 8 <= CS) ? *reinterpret_cast<const float4*>(crow + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            ksteps<4, 1>(film, wb + u * 4 * K16_UNIT_BYTES, lane, v);
+          }
+          done += ns;
+          SEG_END();
+        }
+      }
+      TL_STAMP(2);
+      // ------------------------------------------------------------ positional-encoding stages (L0, L5)
+      f32x16 acc[4], h[4];
+      auto enc_stage = [&]() {  // acc <- bias + W_enc . enc(x)
+        if (sch.enc_steps == 4) {  // L_3D = 10: two segments of two K16-steps, register-fed
+          {
+            const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
+            SEG_BEGIN();
+            bias_init<4>(acc, CUR_BUF, hl);
+            kblock<4>(acc, reinterpret_cast<const char*>(CUR_BUF) + 1024, lane, e0);
+            SEG_END();
+          }
+          {
+            const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+            SEG_BEGIN();
+            kblock<4>(acc, reinterpret_cast<const char*>(CUR_BUF), lane, e1);
+            SEG_END();
+          }
+        } else {
+          int done = 0;
+          while (done < sch.enc_steps) {
+            const int ns = sch.seg_steps[seg];
+            SEG_BEGIN();
+            wb = reinterpret_cast<const char*>(CUR_BUF);
+            if (done == 0) {
+              bias_init<4>(acc, CUR_BUF, hl);
+              wb += 1024;
+            }
+            for (int u = 0; u < ns; ++u) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = enc_operand(8 * (done + u) + j, L3, hl, x, y, z, freq_mul);
+              ksteps<4, 1>(acc, wb + u * 4 * K16_UNIT_BYTES, lane, v);
+            }
+            done += ns;
+            SEG_END();
+          }
+        }
+      };
+      auto hidden_stage = [&](bool with_bias) {  // acc (+)= W . h : four segments, one per input block
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi) {
+          SEG_BEGIN();
+          wb = reinterpret_cast<const char*>(CUR_BUF);
+          if (sgi == 0 && with_bias) {
+            bias_init<4>(acc, CUR_BUF, hl);
+            wb += 1024;
+          }
+          kblock<4>(acc, wb, lane, h[sgi]);
+          SEG_END();
+        }
+      };
+      enc_stage();
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * film[m][r], 0.0f);
+      TL_STAMP(3);
+      // ------------------------------------------------------------ layers 1..4: 128 -> 128
+      for (int layer = 1; layer <= 4; ++layer) {
+        hidden_stage(true);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * film[m][r], 0.0f);
+      }
+      TL_STAMP(4);
+      // ------------------------------------------------------------ layer 5: [enc, h] -> 128
+      enc_stage();
+      hidden_stage(false);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * film[m][r], 0.0f);
+      TL_STAMP(5);
+      // ------------------------------------------------------------ feature_linear: 128 -> 128
+      hidden_stage(true);
+      TL_STAMP(6);
+      // ------------------------------------------------------------ views_linear: [feat, dir] -> 64
+      f32x16 hv[2];
+      {
+        SEG_BEGIN();
+        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
+        bias_init<2>(hv, CUR_BUF, hl);
+        kblock<2>(hv, wb, lane, acc[0]);
+        kblock<2>(hv, wb + 4 * K16_UNIT_BYTES, lane, acc[1]);
+        SEG_END();
+        SEG_BEGIN();
+        wb = reinterpret_cast<const char*>(CUR_BUF);
+        kblock<2>(hv, wb, lane, acc[2]);
+        kblock<2>(hv, wb + 4 * K16_UNIT_BYTES, lane, acc[3]);
+        const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        ksteps<2, 1>(hv, wb + 8 * K16_UNIT_BYTES, lane, v);
+        SEG_END();
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[m][r] = fmaxf(hv[m][r], 0.0f);
+      TL_STAMP(7);
+      // ------------------------------------------------------------ rgb_linear: 64 -> 3, sigmoid
+      {
+        f32x16 c3[1];
+        SEG_BEGIN();
+        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
+        bias_init<1>(c3, CUR_BUF, hl);
+        kblock<1>(c3, wb, lane, hv[0]);
+        kblock<1>(c3, wb + 2 * K16_UNIT_BYTES, lane, hv[1]);
+        if (hl == 0) {
+          const float cr = 1.0f / (1.0f + expf(-c3[0][0]));
+          const float cg = 1.0f / (1.0f + expf(-c3[0][1]));
+          const float cb = 1.0f / (1.0f + expf(-c3[0][2]));
+          rs_lds[s_local * 4 + 0] = cr;
+          rs_lds[s_local * 4 + 1] = cg;
+          rs_lds[s_local * 4 + 2] = cb;
+          if (dbg_rgb_s && ray_ok && jp < S) {
+            dbg_rgb_s[gs * 3 + 0] = cr;
+            dbg_rgb_s[gs * 3 + 1] = cg;
+            dbg_rgb_s[gs * 3 + 2] = cb;
+          }
+        }
+        SEG_END();
+      }
+      TL_STAMP(8);
+      // ------------------------------------------------------------ alpha head: 128 -> 16 (last trunk stage)
+      {
+        f32x16 al[1];
+        SEG_BEGIN();  // DMA of the tail segment
+        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
+        bias_init<1>(al, CUR_BUF, hl);
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi) kblock<1>(al, wb + sgi * 2 * K16_UNIT_BYTES, lane, h[sgi]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = al[0][r];
+          t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+          av[r] = t;
+        }
+        if (D.raytrans_posenc) {
+          const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
+        }
+        SEG_END();
+      }
+    } else {
+      // ============================================================ trunk, exact-f32 MFMA path
     // ------------------------------------------------------------ FiLM = pts_bias(cond)
     f32x16 film[4];
 #pragma unroll
@@ -538,7 +846,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // ------------------------------------------------------------ alpha head: 128 -> 16 (last trunk stage:
     // its activations stay in registers and feed the ray transformer's MFMA stages directly)
     // rows 0..15 <-> registers 0..7: feature o = (r&3) + 8*(r>>2) + 4*hl
-    float av[8];
     {
       f32x16 al[1];
       al[0] = (f32x16)(0.0f);
@@ -559,6 +866,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
       }
       SEG_END();
+    }
+
     }
 
     // ============================================================ ray transformer (K4)
@@ -795,7 +1104,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     {
       const int next_tile = tile + (int)gridDim.x;
       seg0_in_flight = next_tile < n_tiles;
-      if (seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0, wave, lane);
+      if (seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
     }
 
     TL_STAMP(12);
@@ -870,6 +1179,56 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 // the first ones get floor(T/nseg) steps, the last one the rest; every segment is padded to
 // a multiple of 256 floats.
 static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
+  if (D->wstream_format == MNERF_WSTREAM_BF16X3) {
+    // mirror of cond_nerf.py:decoder_schedule16 — stages (blocks, K16-steps per segment, bias header)
+    const int tf = (D->cond_dim + 15) / 16, te = (3 * D->L_3D + 2 + 7) / 8;
+    int n = 0;
+    long long off = 0;
+    auto add = [&](int nmb, int steps, bool hdr) -> bool {
+      if (n >= MAX_SEGS) return false;
+      const int fl = (steps * nmb * 3 + (hdr ? 1 : 0)) * 256;
+      if (fl > SEG_CAP_FLOATS) return false;
+      sch->seg_off[n] = (int)off;
+      sch->seg_floats[n] = fl;
+      sch->seg_steps[n] = steps;
+      off += fl;
+      ++n;
+      return true;
+    };
+    auto add_pairs = [&](int t) -> bool {  // stage of 4 blocks cut into segments of two K16-steps
+      for (int k = 0; k < t; k += 2)
+        if (!add(4, (t - k) >= 2 ? 2 : 1, k == 0)) return false;
+      return true;
+    };
+    bool ok = add_pairs(tf) && add_pairs(te);
+    for (int l = 1; l <= 4 && ok; ++l)
+      for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);
+    ok = ok && add_pairs(te);
+    for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, false);  // l5h
+    for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);  // feature
+    ok = ok && add(2, 4, true) && add(2, 5, false);             // views
+    ok = ok && add(1, 4, true);                                 // rgb
+    ok = ok && add(1, 8, true);                                 // alpha
+    if (!ok || n >= MAX_SEGS) return -1;
+    const int fl = ((TAIL_FLOATS + 255) / 256) * 256;
+    sch->seg_off[n] = (int)off;
+    sch->seg_floats[n] = fl;
+    sch->seg_steps[n] = 0;
+    off += fl;
+    ++n;
+    sch->n_seg = n;
+#ifdef MNERF_TIMELINE
+    sch->tl = nullptr;
+    if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+    sch->stagger_sleeps = 16;
+    if (const char* e = getenv("MNERF_DECODER_STAGGER")) sch->stagger_sleeps = atoi(e);
+    sch->stagger_mode = 0;
+    if (const char* e = getenv("MNERF_DECODER_STAGGER_MODE")) sch->stagger_mode = atoi(e);
+    sch->film_steps = tf;
+    sch->enc_steps = te;
+    return (int)off;
+  }
   const int fs = D->cond_stride / 2, es = 3 * D->L_3D + 2;
   // film, l0, l1..l4, l5-enc, l5-h, feature, views, rgb, alpha (+ the resident tail segment)
   const int T[12] = {fs, es, 65, 65, 65, 65, es, 64, 65, 66, 33, 65};
@@ -915,10 +1274,15 @@ static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
   return (int)off;
 }
 
-extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_stride, int32_t L_3D) {
+extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_stride, int32_t L_3D,
+                                                int32_t wstream_format) {
+  if (wstream_format != MNERF_WSTREAM_F32 && wstream_format != MNERF_WSTREAM_BF16X3) return -1;
+  if (L_3D < 0 || L_3D > 16 || cond_dim < 1 || cond_stride < cond_dim) return -1;
   mnerf_decoder d = {};
+  d.cond_dim = cond_dim;
   d.cond_stride = cond_stride;
   d.L_3D = L_3D;
+  d.wstream_format = wstream_format;
   DecSched s;
   return build_schedule(&d, &s);
 }
@@ -954,6 +1318,8 @@ extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* v
                 "mnerf_decoder_chunk: n_rays=%d S=%d", rays->n_rays, rays->n_samples);
   MNERF_REQUIRE(rays->legacy_coord == 0 || rays->n_samples >= 2, MNERF_E_RANGE,
                 "mnerf_decoder_chunk: legacy depth sampling needs S >= 2");
+  MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32 || dec->wstream_format == MNERF_WSTREAM_BF16X3,
+                MNERF_E_UNSUPPORTED, "mnerf_decoder_chunk: wstream_format=%d", dec->wstream_format);
   const int Sp = pick_padded_samples(rays->n_samples);
   MNERF_REQUIRE(Sp > 0, MNERF_E_UNSUPPORTED,
                 "mnerf_decoder_chunk: sample_intvs=%d > 256 is not supported by the fused kernel",
@@ -968,7 +1334,7 @@ extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* v
   hipStream_t st = (hipStream_t)stream;
   int resident = 512;  // persistent: 2 workgroups per CU x 256 CUs
   if (const char* e = getenv("MNERF_DECODER_GRID")) resident = atoi(e);
-#define MNERF_LAUNCH_DECODER(NW_, SP_)                                                               \
+#define MNERF_LAUNCH_DECODER(NW_, SP_, FMT_)                                                         \
   do {                                                                                               \
     const int rpt = (NW_ * 32) / SP_;                                                                \
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
@@ -976,19 +1342,31 @@ extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* v
     const size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                 \
     static bool attr_set = false;                                                                    \
     if (!attr_set) {                                                                                 \
-      (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_>,                               \
+      (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
       attr_set = true;                                                                               \
     }                                                                                                \
-    hipLaunchKernelGGL((decoder_kernel<NW_, SP_>), dim3(grid), dim3(NW_ * 64), lds, st, *dec, sch,   \
-                       *view0, *rays, cond, rgb, depth, opacity, dbg_rgb_s, dbg_sigma);              \
+    hipLaunchKernelGGL((decoder_kernel<NW_, SP_, FMT_>), dim3(grid), dim3(NW_ * 64), lds, st, *dec,  \
+                       sch, *view0, *rays, cond, rgb, depth, opacity, dbg_rgb_s, dbg_sigma);         \
+  } while (0)
+#define MNERF_LAUNCH_DECODER_FMT(NW_, SP_)                                   \
+  do {                                                                       \
+    if (dec->wstream_format == MNERF_WSTREAM_BF16X3)                         \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 1);                                     \
+    else                                                                     \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 0);                                     \
   } while (0)
   switch (Sp) {
-    case 32: MNERF_LAUNCH_DECODER(4, 32); break;
-    case 64: MNERF_LAUNCH_DECODER(4, 64); break;
-    case 128: MNERF_LAUNCH_DECODER(4, 128); break;
-    default: MNERF_LAUNCH_DECODER(8, 256); break;
+    case 32: MNERF_LAUNCH_DECODER_FMT(4, 32); break;
+    case 64: MNERF_LAUNCH_DECODER_FMT(4, 64); break;
+    case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
+    default:
+      MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32, MNERF_E_UNSUPPORTED,
+                    "mnerf_decoder_chunk: sample_intvs=%d > 128 needs the MNERF_WSTREAM_F32 weight stream", rays->n_samples);
+      MNERF_LAUNCH_DECODER(8, 256, 0);
+      break;
   }
+#undef MNERF_LAUNCH_DECODER_FMT
 #undef MNERF_LAUNCH_DECODER
   return mnerf_check_launch("mnerf_decoder_chunk");
 }

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 1
+MNERF_ABI_VERSION = 2
 MNERF_MAX_VIEWS = 16
 SMALL_FIXED = 32  # floats of the `small` parameter block (LayerNorm weight|bias) before the ray-posenc table
 
@@ -49,7 +49,10 @@ class Decoder(C.Structure):
                 ("n_views", C.c_int32), ("cond_dim", C.c_int32), ("cond_stride", C.c_int32),
                 ("L_3D", C.c_int32), ("raytrans_posenc", C.c_int32), ("raytrans_elu", C.c_int32),
                 ("density_maskfill", C.c_int32), ("wo_render_interval", C.c_int32),
-                ("setbg_opaque", C.c_int32)]
+                ("setbg_opaque", C.c_int32), ("wstream_format", C.c_int32)]
+
+
+WSTREAM_F32, WSTREAM_BF16X3 = 0, 1
 
 
 def lib_path():
@@ -87,7 +90,7 @@ def load():
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
     lib.mnerf_decoder_wstream_floats.restype = i64
-    lib.mnerf_decoder_wstream_floats.argtypes = [i32, i32]
+    lib.mnerf_decoder_wstream_floats.argtypes = [i32, i32, i32, i32]
     lib.mnerf_decoder_chunk.restype = C.c_int
     lib.mnerf_decoder_chunk.argtypes = [C.POINTER(Decoder), C.POINTER(View), C.POINTER(Rays), fp, fp, fp, fp, fp, fp, vp]
     lib.mnerf_render_workspace_bytes.restype = i64

@@ -27,7 +27,7 @@ from .gmflow import GMFlow, pair_major_to_view_chunks
 # rays per kernel launch when a full image is rendered.  The reference's
 # ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
 # chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
-MAX_RAYS_PER_LAUNCH = int(__import__('os').environ.get('MNERF_MAX_RAYS', 65536))
+MAX_RAYS_PER_LAUNCH = 65536
 
 
 class MatchNeRF(torch.nn.Module):
@@ -124,10 +124,11 @@ class MatchNeRF(torch.nn.Module):
         return sc
 
     def _decoder(self, n_samples, device):
-        ws, small, cond_stride = self.nerf_dec.packed(n_samples, device)
+        ws, small, cond_stride, wfmt = self.nerf_dec.packed(n_samples, device)
         d = hip.Decoder()
         d.wstream, d.wstream_floats, d.small_ = ws.data_ptr(), ws.numel(), small.data_ptr()
         d.n_views, d.cond_dim, d.cond_stride = self.n_src_views, self.nerf_dec.cond_dim, cond_stride
+        d.wstream_format = wfmt
         d.L_3D = self.nerf_dec.L_3D
         dec, nerf = self.opts.decoder, self.opts.nerf
         d.raytrans_posenc, d.raytrans_elu = int(bool(dec.raytrans_posenc)), int(dec.raytrans_act == "ELU")

@@ -91,8 +91,9 @@ def test_library_exports_every_declared_symbol():
     # host-only entry points are callable without a GPU
     assert lib.mnerf_render_workspace_bytes(4096, 64, 24) == 4096 * 64 * 24 * 4
     from matchnerf_amd import cond_nerf as CN
-    for cs, L in ((24, 10), (56, 10), (24, 6)):
-        assert lib.mnerf_decoder_wstream_floats(cs, L) == CN.decoder_schedule(cs, L)[1]
+    for cd, cs, L in ((22, 24, 10), (50, 56, 10), (22, 24, 6)):
+        assert lib.mnerf_decoder_wstream_floats(cd, cs, L, hip.WSTREAM_F32) == CN.decoder_schedule(cs, L)[1]
+        assert lib.mnerf_decoder_wstream_floats(cd, cs, L, hip.WSTREAM_BF16X3) == CN.decoder_schedule16(cd, L)[1]
 
 
 def test_struct_layouts_match_the_header():

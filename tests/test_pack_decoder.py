@@ -127,6 +127,128 @@ def test_emulated_mfma_chain_matches_oracle(name):
     assert linf(sg.reshape(n_rays, s_n), sigma_o) < 2e-6
 
 
+# ----------------------------------------------------------------------------- split-bf16 stream
+
+
+def _split3(x):
+    hi, mid, lo = CN.split_bf16x3(x.astype(np.float32))
+    return [CN.bf16_to_f32(p).astype(np.float64) for p in (hi, mid, lo)]
+
+
+def emulate_stage16(ws, segs, name, v, six_terms=True):
+    """v [T,2,8,N] operands (step, half-wave, j) -> Y [nmb*32, N]; emulates the kernel's arithmetic: bias
+    fragment as the initial accumulator, weights and activations as three bf16 terms, six product terms."""
+    parts = [s for s in segs if s[0] == name]
+    nmb = parts[0][3]
+    n = v.shape[-1]
+    y = np.zeros((nmb * 32, n), np.float64)
+    w16 = ws.view(np.uint16)
+    for _, first, steps, m, off, fl, hdr in parts:
+        if hdr:
+            bias = ws[off:off + CN.FRAG_FLOATS]
+            for h in range(2):
+                for mb in range(m):
+                    for r in range(16):
+                        row = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h
+                        y[row] += bias[(h * 4 + mb) * 16 + r]
+            off += CN.FRAG_FLOATS
+        a = w16[2 * off:2 * off + steps * m * 3 * 512].reshape(steps, m, 3, 64, 8)
+        ah, am, al = [CN.bf16_to_f32(a[:, :, p]).astype(np.float64) for p in range(3)]   # [steps,m,64,8]
+        vv = v[first:first + steps].astype(np.float32)
+        bh, bm, bl = _split3(vv)                                                         # [steps,2,8,N]
+        terms = [(ah, bh), (ah, bm), (am, bh), (ah, bl), (al, bh), (am, bm)] if six_terms else [(ah + am + al, bh + bm + bl)]
+        for wa, vb in terms:
+            for mb in range(m):
+                for h in range(2):
+                    # rows = lanes 32h..32h+31 of block mb; sum over (step, j)
+                    y[mb * 32:(mb + 1) * 32] += np.einsum("tlj,tjn->ln", wa[:, mb, 32 * h:32 * h + 32, :], vb[:, h])
+    return y
+
+
+def reg_operands16(h, n_blocks):
+    return h[CN._reg_cols16(n_blocks)]                                                   # [T,2,8,N]
+
+
+def enc_operands16(x, L, legacy):
+    lo, hi = enc_operands(x, L, legacy)
+    te = (lo.shape[0] + 7) // 8
+    v = np.zeros((te, 2, 8, x.shape[1]))
+    for a in range(lo.shape[0]):
+        v[a // 8, 0, a % 8] = lo[a]
+        v[a // 8, 1, a % 8] = hi[a]
+    return v
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4", "nonlegacy", "rect_wide"])
+def test_emulated_split_bf16_chain_matches_oracle(name):
+    g, cfg, sd, batch = golden_case(name)
+    n_rays = 8
+    x_ref = torch.from_numpy(g["x_ref"][:n_rays])
+    dir_ref = torch.from_numpy(g["dir_ref"][:n_rays])
+    cond = torch.from_numpy(g["cond"][:n_rays])
+    v = cfg.n_src_views
+    mask = cond[..., -v:]
+    with torch.no_grad():
+        rgb_o, sigma_o = O.decoder(cfg, sd, x_ref, dir_ref, cond, mask)
+    ws, cond_dim, cs = CN.pack_wstream16(sd, v, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    segs, total = CN.decoder_schedule16(cond_dim, cfg.L_3D)
+    assert ws.size == total
+    n = n_rays * cfg.sample_intvs
+    x = x_ref.reshape(n, 3).numpy().T.astype(np.float64)
+    tf = (cond_dim + 15) // 16
+    cpad = np.zeros((16 * tf, n))
+    cpad[:cond_dim] = cond.reshape(n, cond_dim).numpy().T
+    if cond_dim < 16 * tf:
+        cpad[cond_dim] = 1.0   # the cost-volume kernel's constant column: must meet zero weights
+    film = emulate_stage16(ws, segs, "film", cpad.reshape(tf, 2, 8, n))
+    e = enc_operands16(x, cfg.L_3D, cfg.legacy_coord)
+    h = np.maximum(emulate_stage16(ws, segs, "l0", e) * film, 0)
+    for i in range(1, 5):
+        h = np.maximum(emulate_stage16(ws, segs, f"l{i}", reg_operands16(h, 4)) * film, 0)
+    h = np.maximum((emulate_stage16(ws, segs, "l5e", e) + emulate_stage16(ws, segs, "l5h", reg_operands16(h, 4))) * film, 0)
+    a = emulate_stage16(ws, segs, "alpha", reg_operands16(h, 4))
+    assert np.abs(a[16:]).max() == 0.0
+    feat = emulate_stage16(ws, segs, "feature", reg_operands16(h, 4))
+    d = np.repeat(dir_ref.numpy().astype(np.float64), cfg.sample_intvs, 0).T
+    dv = np.zeros((1, 2, 8, n))
+    dv[0, 0, :3] = d
+    hv = np.maximum(emulate_stage16(ws, segs, "views", np.concatenate([reg_operands16(feat, 4), dv], 0)), 0)
+    rgb = 1 / (1 + np.exp(-emulate_stage16(ws, segs, "rgb", reg_operands16(hv, 2))[:3]))
+    assert linf(rgb.T.reshape(n_rays, -1, 3), rgb_o) < 2e-6
+    # the alpha-head activations feed the (unchanged, exact-f32) tail: compare them with the f32 stream's
+    ws32, _, cs32 = CN.pack_wstream(sd, v, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    segs32, _ = CN.decoder_schedule(cs32, cfg.L_3D)
+    tail_floats = segs[-1][5]
+    assert np.array_equal(ws[-tail_floats:], ws32[-tail_floats:])
+    # and the alpha activations themselves against the oracle's pre-attention features
+    lo, hi = reg_order_operands(h, 4)
+    one, zero = np.ones((1, n)), np.zeros((1, n))
+    a32 = emulate_stage(ws32, segs32, "alpha", np.vstack([lo, one]), np.vstack([hi, zero]))
+    assert np.abs(a - a32).max() < 2e-6 * max(1.0, np.abs(a32).max())
+
+
+def test_schedule16_invariants():
+    for cd, L in ((22, 10), (26, 10), (50, 10), (74, 10), (22, 6), (22, 0)):
+        segs, total = CN.decoder_schedule16(cd, L)
+        assert total % 256 == 0 and len(segs) <= 64
+        off = 0
+        for name, first, steps, m, o, fl, hdr in segs:
+            assert o == off and fl % 256 == 0 and fl <= CN.SEG_CAP_FLOATS
+            off += fl
+        assert off == total
+        assert [s[0] for s in segs][-4:] == ["views", "rgb", "alpha", "tail"]
+        for name in ("l1", "l2", "l3", "l4", "l5h", "feature"):
+            assert [s[2] for s in segs if s[0] == name] == [2, 2, 2, 2]
+
+
+def test_split_bf16x3_is_exact():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 4, 20000)).astype(np.float32)
+    hi, mid, lo = CN.split_bf16x3(x)
+    rec = CN.bf16_to_f32(hi).astype(np.float64) + CN.bf16_to_f32(mid) + CN.bf16_to_f32(lo)
+    assert np.max(np.abs(rec - x) / np.abs(x)) < 2.0 ** -23
+
+
 def test_schedule_invariants():
     for cs, L in ((24, 10), (32, 10), (56, 10), (64, 10), (24, 6), (24, 0)):
         segs, total = CN.decoder_schedule(cs, L)
