@@ -9,7 +9,10 @@ One "step" = one full pass of the hot path over one synthetic batch of BASELINE 
 samples/ray — the GMFlow encoder on the 3 source views plus all 327,680 target rays
 (encoder INCLUDED in the timed region; render-only rate reported separately under
 ``config``).  Inputs are resident in HBM when the timed region starts.  Arithmetic is fp32
-("f32": the 1e-4 RGB parity gate cannot be met in bf16).
+("f32": the 1e-4 RGB parity gate cannot be met in bf16): fp32 data, fp32
+accumulation everywhere; the decoder's matrix products run either on the exact-f32 MFMA
+(MNERF_DECODER_MATH=f32) or, by default, as fp32-grade products assembled from three bf16 terms
+per operand on the bf16 MFMA ("bf16x6", DESIGN.md §5: error not above an fp32 FMA chain's).
 
 N > 1: one process per GPU (RCCL); every rank encodes the shared source views and renders a
 DIFFERENT target view (weak scaling: BASELINE config[3], "target views sharded across GPUs"),
@@ -17,9 +20,11 @@ then one all_gather returns every rank's [327680,5] tile to all ranks.  value = 
 all ranks / max-over-ranks time.
 
 Also printed in the same JSON line:
-  roofline     dominant kernel (fused decoder, f32 MFMA): algorithmic FLOPs per launch
-               (258,336 + 64*S per sample) / average launch duration measured
-               with events on the launch stream inside the timed region, vs 157.3 TFLOP/s.
+  roofline     dominant kernel (fused decoder): FLOPs per launch / average launch duration measured
+               with events on the launch stream inside the timed region.  f32 math: algorithmic
+               FLOPs (258,336 + 64*S per sample) vs the 157.3 TFLOP/s f32-MFMA peak.
+               bf16x6 math: the matrix FLOPs actually issued (6 bf16 products per algorithmic MLP
+               MAC) vs the 2.5 PFLOP/s dense bf16 peak; the algorithmic rate is reported next to it.
   cpu_baseline the CPU oracle (a port of the reference path, pinned to it by goldens) timed
                on this host's cores on a bounded sample (rank 0, N=1 only).
 """
@@ -41,6 +46,8 @@ CPU_RAYS = 1024      # rays of the bounded CPU-baseline sample
 CPU_THREADS_MAX = 16 # torch intra-op threads for the CPU baseline (more threads than this is
                      # slower on the small tensors of this path: 256 threads measured 14x slower)
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (same table)
+MLP_FLOPS_PER_SAMPLE = 258336  # the MLP part of SURVEY.md §8(d): runs as 6 bf16 products per MAC in bf16x6 math
 
 
 def measured_traffic(launch_rays):
@@ -170,8 +177,16 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n_rays * args.steps / elapsed
         dec = ksum["decoder"]
-        flops_launch = dec["rays"] / dec["launches"] * S * flops_per_sample(S)
-        achieved = flops_launch / (dec["avg_ms"] * 1e-3) / 1e12
+        from matchnerf_amd.cond_nerf import decoder_math
+        math = decoder_math() if S <= 128 else "f32"
+        samples_launch = dec["rays"] / dec["launches"] * S
+        flops_launch = samples_launch * flops_per_sample(S)
+        algorithmic = flops_launch / (dec["avg_ms"] * 1e-3) / 1e12
+        if math == "bf16x6":
+            issued_launch = samples_launch * (6 * MLP_FLOPS_PER_SAMPLE + (flops_per_sample(S) - MLP_FLOPS_PER_SAMPLE))
+            achieved, peak = issued_launch / (dec["avg_ms"] * 1e-3) / 1e12, BF16_MFMA_PEAK_TFLOPS
+        else:
+            issued_launch, achieved, peak = flops_launch, algorithmic, F32_MFMA_PEAK_TFLOPS
         render_ms = (dec["total_ms"] + ksum["cost_volume"]["total_ms"]) / args.steps
         line = {
             "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
@@ -180,6 +195,7 @@ def main():
             "config": {
                 "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
                             "(327680 rays) per step incl. GMFlow encoder; fp32 parity mode",
+                "decoder_math": math,
                 "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(dec["rays"] / dec["launches"]),
                 "parallelism": f"target views x{world}" if world > 1 else "single GPU",
                 "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
@@ -188,8 +204,10 @@ def main():
                 "decoder_ms_per_frame": round(dec["total_ms"] / args.steps, 3),
             },
             "roofline": {"bound": "mfma", "kernel": "decoder_kernel<4> (fused MLP + ray transformer + compositing)",
-                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4),
+                         "math": math, "algorithmic_tflops": round(algorithmic, 2),
+                         "issued_flops_per_launch": issued_launch,
                          "traffic": measured_traffic(int(dec["rays"] / dec["launches"])),
                          "avg_launch_ms": round(dec["avg_ms"], 4),
                          "flops_per_launch": flops_launch},

@@ -117,10 +117,13 @@ def test_cost_volume_matches_reference(hip, name):
     assert bool(((m == 0) | (m == 1)).all())
 
 
+@pytest.mark.parametrize("math", ["bf16x6", "f32"])
 @pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
-def test_decoder_chunk_matches_reference(hip, name):
+def test_decoder_chunk_matches_reference(hip, name, math):
+    """Both matrix paths of the fused decoder (split-bf16 on the bf16 MFMA = the default, and the
+    exact-f32 MFMA) against the reference's own per-sample and per-ray outputs, same tolerances."""
     g, cfg, sd, batch, _, _ = _case_on_gpu(name)
-    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"])
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
     idx = torch.from_numpy(g["stage_rays"]).int().cuda()
     rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
     n, s, dc = g["cond"].shape
@@ -134,6 +137,33 @@ def test_decoder_chunk_matches_reference(hip, name):
     assert linf(rgb, g["rgb"][0, sel]) < 1e-4
     assert linf(opacity, g["opacity"][0, sel, 0]) < 1e-4
     assert linf(depth, g["depth"][0, sel, 0]) < 3e-4
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4"])
+def test_decoder_math_variants_agree(hip, name):
+    """bf16x6 (three bf16 terms per fp32 operand, six products, fp32 accumulate) is fp32-grade: it
+    agrees with the exact-f32 MFMA path far inside the parity tolerance, and is not further from
+    the reference than that path is."""
+    g, cfg, sd, batch, _, _ = _case_on_gpu(name)
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    n, s, dc = g["cond"].shape
+    view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                          float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+    out = {}
+    for math in ("bf16x6", "f32"):
+        dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
+        cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
+        out[math] = [t.cpu() for t in hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)]
+    d_rgb_s = linf(out["bf16x6"][3], out["f32"][3])
+    d_sigma = linf(out["bf16x6"][4], out["f32"][4])
+    d_rgb = linf(out["bf16x6"][0], out["f32"][0])
+    e16, e32 = linf(out["bf16x6"][3], g["rgb_samples"]), linf(out["f32"][3], g["rgb_samples"])
+    print(f"\n[{name}] bf16x6 vs f32-MFMA: rgb_s {d_rgb_s:.2e} sigma {d_sigma:.2e} rgb {d_rgb:.2e};"
+          f" vs reference rgb_s: bf16x6 {e16:.2e}, f32 {e32:.2e}")
+    assert d_rgb_s < 5e-6 and d_rgb < 1e-5
+    assert d_sigma < 1e-5 * max(1.0, float(out["f32"][4].abs().max()))
+    assert e16 < max(2.0 * e32, 2e-6)
 
 
 @pytest.mark.parametrize("name,chunk", [("c1_default", 1024), ("c1_default", 4096), ("rect_wide", 1000),

@@ -19,8 +19,8 @@ with torch.no_grad():
     model(batch, mode="test")
 torch.cuda.synchronize()
 t = tl.cpu().numpy().reshape(128, 4, 4, 20)  # [wg, tile, wave, point]
-names = ["prologue+seg0", "film", "L0", "L1-4", "L5", "alpha", "feature", "views", "rgb", "kv-setup", "attention",
-         "fc/LN/sigma", "composite", "end-barrier"]
+names = ["prologue+seg0", "film", "L0", "L1-4", "L5", "feature", "views", "rgb", "alpha+qkv+kv-setup", "-", "attention",
+         "fc/LN/sigma", "composite", "-"]
 d = np.diff(t[..., :15].astype(np.float64), axis=-1)  # [wg,tile,wave,14]
 valid = t[..., 14] > 0
 print("phase cycles (mean over waves / WGs / tiles 1..3), total per tile:")
