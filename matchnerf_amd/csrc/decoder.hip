@@ -450,6 +450,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_ID
 #endif
     TL_STAMP(0);
+#ifdef MNERF_TIMELINE
+    unsigned long long tl_dma_wait = 0, tl_bar_wait = 0;
+#endif
     // ------------------------------------------------------------ per-lane sample identity
     const int s_local = wave * 32 + n;
     const int ray_t = s_local / Sp;                 // ray within the tile
@@ -486,12 +489,26 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 #define CUR_BUF ((seg & 1) ? wbuf1 : wbuf0)
 #define NXT_BUF ((seg & 1) ? wbuf0 : wbuf1)
 #define SEG_BEGIN() prefetch_segment<NW>(D.wstream, sch, seg + 1, (seg & 1) ? wbuf0_lds : wbuf1_lds, wave, lane)
+#ifdef MNERF_TIMELINE
+#define SEG_END()                                                  \
+  do {                                                             \
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();   \
+    segment_wait();                                                \
+    const unsigned long long t1_ = __builtin_amdgcn_s_memtime();   \
+    __syncthreads();                                               \
+    const unsigned long long t2_ = __builtin_amdgcn_s_memtime();   \
+    tl_dma_wait += t1_ - t0_;                                      \
+    tl_bar_wait += t2_ - t1_;                                      \
+    ++seg;                                                         \
+  } while (0)
+#else
 #define SEG_END()     \
   do {                \
     segment_wait();   \
     __syncthreads();  \
     ++seg;            \
   } while (0)
+#endif
 
     TL_STAMP(1);
     float av[8];  // alpha-head activations: rows 0..15 <-> registers 0..7, feature (r&3) + 8*(r>>2) + 4*hl
@@ -873,6 +890,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // ============================================================ ray transformer (K4)
     // The tail segment [w_qs;w_ks;w_vs | fc | out_alpha.0 | out_alpha.2] stays resident in its
     // weight buffer; the OTHER buffer (last read before the barrier above) is the K/V/Q/O scratch.
+    TL_STAMP(17);
     const float* tail = CUR_BUF;
     float* att = NXT_BUF;
 #undef CUR_BUF
@@ -894,6 +912,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     qkv[1] = (f32x16)(0.0f);
 #pragma unroll
     for (int r = 0; r < 8; ++r) step2(qkv, tail + TAIL_QKV, r, lane, av[r]);
+    TL_STAMP(18);
     const float qs = q_valid ? 0.5f : 0.0f;  // temperature sqrt(d_k) = 2; masked query row -> uniform
 
     float ofc[8];  // attention output features [8*hl, 8*hl+8) of this lane's sample (head-major)
@@ -1166,6 +1185,12 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       }
     }
     TL_STAMP(13);
+#ifdef MNERF_TIMELINE
+    if (sch.tl && lane == 0 && tl_slot >= 0 && tl_tile < 4) {
+      sch.tl[(((size_t)tl_slot * 4 + tl_tile) * NW + wave) * TL_POINTS + 15] = tl_dma_wait;
+      sch.tl[(((size_t)tl_slot * 4 + tl_tile) * NW + wave) * TL_POINTS + 16] = tl_bar_wait;
+    }
+#endif
     // No barrier here: the next tile touches rs_lds only after several segment barriers,
     // and every read of the attention scratch (aliased on the weight buffers that the next
     // tile's first DMA overwrites) completed before the barrier in front of the compositing.

@@ -80,6 +80,51 @@ __device__ __forceinline__ void layer(f32x16 (&acc)[4], const f32x16 (&h)[4], co
         ch = nh; cm = nm; cl = nl;
       }
     }
+  } else if (MODE == 2 || MODE == 3) {
+    // split of step t+1 interleaved between the MFMAs of (t, block 0): MFMA, <=8 VALU, MFMA, ...
+    bf16x8 ch = a[0], cm = a[64], cl = a[128];
+    float v0[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v0[j] = h[0][j];
+    Parts b = split8(v0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      Parts bn = b;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int nx = (t * 4 + m + 1) * 3 * 64;
+        const bf16x8 nh = a[nx], nm = a[nx + 64], nl = a[nx + 128];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[m] = mm(ch, b.lo, acc[m]);
+        acc[m] = mm(cl, b.hi, acc[m]);
+        acc[m] = mm(cm, b.mid, acc[m]);
+        acc[m] = mm(ch, b.mid, acc[m]);
+        acc[m] = mm(cm, b.hi, acc[m]);
+        acc[m] = mm(ch, b.hi, acc[m]);
+        if (m == 0 && t < 7) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = h[(t + 1) >> 1][((t + 1) & 1) * 8 + j];
+          bn = split8(v);
+          {  // pin the split here (IR-level sinking would otherwise move it next to its first use)
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            u32x4_ H = __builtin_bit_cast(u32x4_, bn.hi), M = __builtin_bit_cast(u32x4_, bn.mid), L = __builtin_bit_cast(u32x4_, bn.lo);
+            asm volatile("" : "+v"(H), "+v"(M), "+v"(L));
+            bn.hi = __builtin_bit_cast(bf16x8, H); bn.mid = __builtin_bit_cast(bf16x8, M); bn.lo = __builtin_bit_cast(bf16x8, L);
+          }
+          if (MODE == 3) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+              __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // then up to 8 VALU
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ch = nh; cm = nm; cl = nl;
+      }
+      b = bn;
+    }
   } else {
     bf16x8 ch0 = a[0], cm0 = a[64], cl0 = a[128], ch1 = a[192], cm1 = a[256], cl1 = a[320];
 #pragma unroll
@@ -209,14 +254,18 @@ int main() {
   const int lds_rate = 76 * 1024;  // >= LAYER_BYTES + LAYER_PAD  // same LDS footprint as the decoder => 2 workgroups per CU
   hipFuncSetAttribute((const void*)rate_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
   hipFuncSetAttribute((const void*)rate_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
-  for (int mode = 0; mode < 2; ++mode)
+  hipFuncSetAttribute((const void*)rate_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+  hipFuncSetAttribute((const void*)rate_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+  for (int mode = 0; mode < 4; ++mode)
     for (int grid : {256, 512}) {
       const int iters = 2000;
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         if (mode == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
-        else hipLaunchKernelGGL(rate_kernel<1>, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+        else if (mode == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+        else if (mode == 2) hipLaunchKernelGGL(rate_kernel<2>, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+        else hipLaunchKernelGGL(rate_kernel<3>, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
         hipEventRecord(e1); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -28,6 +28,13 @@ dm = d[:, 1:, :, :][valid[:, 1:, :]].reshape(-1, 14)
 for n, v in zip(names, dm.mean(0)):
     print(f"  {n:16s} {v:10.0f}  ({100 * v / dm.sum(1).mean():5.1f} %)")
 print("  total            %10.0f cycles per tile" % dm.sum(1).mean())
+w = t[:, 1:, :, 15:17].astype(np.float64)[valid[:, 1:, :]].reshape(-1, 2)
+print("  inside the weight-segment hand-offs: wait for own DMA %.0f, wait at the barrier %.0f cycles per tile (%.1f %% / %.1f %%)"
+      % (w[:, 0].mean(), w[:, 1].mean(), 100 * w[:, 0].mean() / dm.sum(1).mean(), 100 * w[:, 1].mean() / dm.sum(1).mean()))
+sub = t[:, 1:, :, :].astype(np.float64)[valid[:, 1:, :]]
+print("  alpha stage (incl. tail DMA + barrier) %.0f | qkv projections %.0f | K/V/Q to LDS + barrier %.0f"
+      % ((sub[:, 17] - sub[:, 8]).mean(), (sub[:, 18] - sub[:, 17]).mean(), (sub[:, 9] - sub[:, 18]).mean()))
+print("  per wave barrier wait:", [int(v) for v in t[0, 1, :, 16]], " DMA wait:", [int(v) for v in t[0, 1, :, 15]])
 
 def where(h):
     h = int(h)
