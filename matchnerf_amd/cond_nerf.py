@@ -211,8 +211,10 @@ def decoder_stages16(cond_dim, L_3D):
 
     st = [("film", 4, pairs(tf), True), ("l0", 4, pairs(te), True)]
     st += [(f"l{i}", 4, [2, 2, 2, 2], True) for i in range(1, 5)]
-    st += [("l5e", 4, pairs(te), True), ("l5h", 4, [2, 2, 2, 2], False), ("feature", 4, [2, 2, 2, 2], True),
-           ("views", 2, [4, 5], True), ("rgb", 1, [4], True), ("alpha", 1, [8], True)]
+    # alpha right after the trunk: it and feature are the only consumers of the last hidden activations, which
+    # are then dead during views / rgb (its 16 outputs wait in 8 registers for the ray transformer)
+    st += [("l5e", 4, pairs(te), True), ("l5h", 4, [2, 2, 2, 2], False), ("alpha", 1, [8], True),
+           ("feature", 4, [2, 2, 2, 2], True), ("views", 2, [4, 5], True), ("rgb", 1, [4], True)]
     return st
 
 

@@ -625,6 +625,27 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * film[m][r], 0.0f);
+      // ------------------------------------------------------------ alpha head: 128 -> 16 (its activations wait in 8 registers for the ray transformer)
+      {
+        f32x16 al[1];
+        SEG_BEGIN();
+        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
+        bias_init<1>(al, CUR_BUF, hl);
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi) kblock<1>(al, wb + sgi * 2 * K16_UNIT_BYTES, lane, h[sgi]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = al[0][r];
+          t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+          av[r] = t;
+        }
+        if (D.raytrans_posenc) {
+          const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
+        }
+        SEG_END();
+      }
       TL_STAMP(5);
       // ------------------------------------------------------------ feature_linear: 128 -> 128
       hidden_stage(true);
@@ -675,27 +696,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         SEG_END();
       }
       TL_STAMP(8);
-      // ------------------------------------------------------------ alpha head: 128 -> 16 (last trunk stage)
-      {
-        f32x16 al[1];
-        SEG_BEGIN();  // DMA of the tail segment
-        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
-        bias_init<1>(al, CUR_BUF, hl);
-#pragma unroll
-        for (int sgi = 0; sgi < 4; ++sgi) kblock<1>(al, wb + sgi * 2 * K16_UNIT_BYTES, lane, h[sgi]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          float t = al[0][r];
-          t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
-          av[r] = t;
-        }
-        if (D.raytrans_posenc) {
-          const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
-        }
-        SEG_END();
-      }
     } else {
       // ============================================================ trunk, exact-f32 MFMA path
     // ------------------------------------------------------------ FiLM = pts_bias(cond)
@@ -1230,10 +1230,10 @@ static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
       for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);
     ok = ok && add_pairs(te);
     for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, false);  // l5h
+    ok = ok && add(1, 8, true);                                 // alpha
     for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);  // feature
     ok = ok && add(2, 4, true) && add(2, 5, false);             // views
     ok = ok && add(1, 4, true);                                 // rgb
-    ok = ok && add(1, 8, true);                                 // alpha
     if (!ok || n >= MAX_SEGS) return -1;
     const int fl = ((TAIL_FLOATS + 255) / 256) * 256;
     sch->seg_off[n] = (int)off;

@@ -236,7 +236,9 @@ def test_schedule16_invariants():
             assert o == off and fl % 256 == 0 and fl <= CN.SEG_CAP_FLOATS
             off += fl
         assert off == total
-        assert [s[0] for s in segs][-4:] == ["views", "rgb", "alpha", "tail"]
+        assert [s[0] for s in segs][-4:] == ["views", "views", "rgb", "tail"]
+        names = [s[0] for s in segs]
+        assert names.index("alpha") == max(i for i, n in enumerate(names) if n == "l5h") + 1
         for name in ("l1", "l2", "l3", "l4", "l5h", "feature"):
             assert [s[2] for s in segs if s[0] == name] == [2, 2, 2, 2]
 
