@@ -173,11 +173,33 @@ def main():
         torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - t1) / 3 * 1e3
 
+    # secondary figure (N=1, outside the timed region): the same frame with the decoder's matrix products on
+    # the exact-f32 MFMA instead of the default split-bf16 path, and the largest RGB difference between the two
+    exact_f32 = None
+    from matchnerf_amd.cond_nerf import decoder_math
+    if world == 1 and decoder_math() == "bf16x6" and S <= 128:
+        rgb_split = full[:, :3].clone()
+        os.environ["MNERF_DECODER_MATH"] = "f32"
+        try:
+            step()  # re-packs the weight stream
+            t32 = hip.KernelTimer()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                full32 = step(t32)
+            torch.cuda.synchronize()
+            ms32 = (time.perf_counter() - t1) / 2 * 1e3
+            exact_f32 = {"rays_per_s": round(n_rays / (ms32 * 1e-3), 1), "ms_per_step": round(ms32, 3),
+                         "decoder_ms_per_frame": round(t32.summary()["decoder"]["total_ms"] / 2, 3),
+                         "rgb_linf_vs_default_math": float((full32[:, :3] - rgb_split).abs().max())}
+        finally:
+            os.environ["MNERF_DECODER_MATH"] = "bf16x6"
+            model.kernel_timer = None
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n_rays * args.steps / elapsed
         dec = ksum["decoder"]
-        from matchnerf_amd.cond_nerf import decoder_math
         math = decoder_math() if S <= 128 else "f32"
         samples_launch = dec["rays"] / dec["launches"] * S
         flops_launch = samples_launch * flops_per_sample(S)
@@ -195,7 +217,10 @@ def main():
             "config": {
                 "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
                             "(327680 rays) per step incl. GMFlow encoder; fp32 parity mode",
-                "decoder_math": math,
+                "decoder_math": math if math == "f32" else
+                "bf16x6: fp32 operands as 3 bf16 terms, 6 products per MAC on the bf16 MFMA, fp32 accumulate "
+                "(error <= an fp32 FMA chain's; DESIGN.md section 4)",
+                "exact_f32_mfma_path": exact_f32,
                 "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(dec["rays"] / dec["launches"]),
                 "parallelism": f"target views x{world}" if world > 1 else "single GPU",
                 "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
