@@ -66,7 +66,7 @@ class MatchNeRF(torch.nn.Module):
             poses_paths = [tgt_pose]
 
         mode_rand_rays = getattr(self.opts.nerf, f"rand_rays_{mode}", 0)
-        collected = {}
+        collected, frames_done = {}, {}
         for cur_tgt_pose in poses_paths:
             if mode_rand_rays and mode in ["train", "test-optim"]:
                 batch.ray_idx = torch.randperm(img_h * img_w, device=ref_images.device)[:mode_rand_rays // batch_size]
@@ -78,10 +78,28 @@ class MatchNeRF(torch.nn.Module):
             else:
                 ret = self.render(self.opts, cur_tgt_pose, mode=mode, ref_poses=ref_poses, ref_images=ref_images,
                                   ref_feats_list=ref_feats_list)
-            for k, v in ret.items():
-                collected.setdefault(k, []).append(v.detach().cpu() if render_video else v)
-        for k, v in collected.items():
-            batch[k] = torch.cat(v, dim=0)
+            if render_video:
+                # Frames go to the host as the reference's do (matchnerf.py:62-70, per-frame .cpu()), but without a
+                # host sync per frame: one pinned buffer per output holds all frames, each frame is an async copy
+                # queued behind its own kernels, and the GPU starts the next pose while Python is still here.
+                for k, v in ret.items():
+                    v = v.detach()
+                    if k not in collected:
+                        collected[k] = torch.empty((len(poses_paths) * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype,
+                                                   pin_memory=True)
+                    lo = len(frames_done.setdefault(k, [])) * v.shape[0]
+                    collected[k][lo:lo + v.shape[0]].copy_(v, non_blocking=True)
+                    frames_done[k].append(v)  # keep the device tensor alive until the copy has run
+            else:
+                for k, v in ret.items():
+                    collected.setdefault(k, []).append(v)
+        if render_video:
+            torch.cuda.current_stream().synchronize()
+            for k, v in collected.items():
+                batch[k] = v
+        else:
+            for k, v in collected.items():
+                batch[k] = torch.cat(v, dim=0)
         return batch
 
     def extract_poses(self, batch):

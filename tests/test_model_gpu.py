@@ -163,7 +163,20 @@ def test_video_mode_renders_each_pose():
         out = model(batch, mode="test", render_video=True, render_path_mode="interpolate")
     h, w = g["images"].shape[-2:]
     assert out.rgb.shape == (6, h * w, 3) and out.rgb.device.type == "cpu"
+    assert out.depth.shape == (6, h * w, 1) and out.opacity.shape == (6, h * w, 1)
     assert torch.isfinite(out.rgb).all()
+    # frames are streamed to one pinned host buffer asynchronously: every frame must equal a synchronous
+    # single-pose render of the same pose
+    tgt, ref_poses = model.extract_poses(batch)
+    poses = model.get_video_rendering_path(tgt, ref_poses, "interpolate", 6, batch)
+    with torch.no_grad():
+        feats = model.get_img_feat(batch.images[:, :-1], cur_n_src_views=batch.images.shape[1] - 1)
+        for i in (0, 3, 5):
+            one = model.render(opt, poses[i], mode="test", ref_poses=ref_poses, ref_images=batch.images[:, :-1],
+                               ref_feats_list=feats)
+            # (the encoder runs again here: MIOpen's ulp-level run-to-run differences, cf. the batch-of-two test)
+            assert linf(out.rgb[i], one["rgb"][0]) < 2e-5
+    assert len({float(out.rgb[i].sum()) for i in range(6)}) == 6  # six different poses
 
 
 def test_batch_of_two_equals_two_batches_of_one():
