@@ -275,14 +275,20 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // accumulators <- fp32 bias fragment [half][4][16] (exact fp32 biases, no K-step spent on them)
+// LDS operands of the split-bf16 path are addressed by LDS byte offset through explicit address_space(3)
+// pointers made from integers.
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(3)))* lds_u32x4_cptr;
+typedef const v4f32 __attribute__((address_space(3)))* lds_v4f32_cptr;
+
 template <int NMB>
-__device__ __forceinline__ void bias_init(f32x16 (&acc)[NMB], const float* frag, int hl) {
-  const float4* p = reinterpret_cast<const float4*>(frag) + hl * 16;
+__device__ __forceinline__ void bias_init(f32x16 (&acc)[NMB], unsigned frag_lds, int hl) {
+  lds_v4f32_cptr p = (lds_v4f32_cptr)(size_t)frag_lds + hl * 16;
 #pragma unroll
   for (int m = 0; m < NMB; ++m)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 t = p[m * 4 + q];
+      const v4f32 t = p[m * 4 + q];
       acc[m][4 * q] = t.x;
       acc[m][4 * q + 1] = t.y;
       acc[m][4 * q + 2] = t.z;
@@ -294,8 +300,8 @@ __device__ __forceinline__ void bias_init(f32x16 (&acc)[NMB], const float* frag,
 // v: the lane's 8*NS operands.  A fragments of unit (step, block) i+1 are read before the six MFMAs
 // of unit i (192 cycles of matrix work hide the LDS latency).
 template <int NMB, int NS>
-__device__ __forceinline__ void ksteps(f32x16 (&acc)[NMB], const char* base, int lane, const float (&v)[8 * NS]) {
-  const u32x4* a = reinterpret_cast<const u32x4*>(base) + lane;
+__device__ __forceinline__ void ksteps(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const float (&v)[8 * NS]) {
+  lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
   u32x4 ch = a[0], cm = a[64], cl = a[128];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
@@ -327,11 +333,11 @@ __device__ __forceinline__ void ksteps(f32x16 (&acc)[NMB], const char* base, int
 
 // two K16-steps fed from one 16-register block (an accumulator block of the previous layer)
 template <int NMB>
-__device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], const char* base, int lane, const f32x16& h) {
+__device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const f32x16& h) {
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = h[r];
-  ksteps<NMB, 2>(acc, base, lane, v);
+  ksteps<NMB, 2>(acc, base_lds, lane, v);
 }
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
 
@@ -361,8 +367,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wbuf0 = smem;
   float* wbuf1 = smem + SEG_CAP_FLOATS;
-  // LDS byte addresses of the two weight buffers for the DMA (taken once, from the array itself)
-  const unsigned wbuf0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  // LDS byte addresses of the two weight buffers, for the DMA and for the split-bf16 operand reads.  (No
+  // generic->LDS pointer casts anywhere near the hot loops: they trip a gfx950 code-generation bug in hipcc
+  // 7.2 — "Illegal instruction detected: Operand has incorrect register class" on a V_CMP against
+  // src_shared_base — depending on unrelated code around them.)
+  const unsigned wbuf0_lds = __builtin_amdgcn_groupstaticsize();  // the dynamic array starts after the static LDS
   const unsigned wbuf1_lds = wbuf0_lds + SEG_CAP_FLOATS * 4u;
   float* rs_lds = smem + SM::W_FLOATS;                // [TILE][4]   rgb.xyz, sigma.w
   float* ln_lds = rs_lds + SM::RS_FLOATS;             // LayerNorm weight[16] | bias[16]
@@ -394,14 +403,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     if (late)
       for (int i = 0; i < sch.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
   }
-  if (sch.stagger_mode >= 10) {  // experiment: static priority split between the two co-resident WGs
-    const unsigned hw_id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11));
-    const bool slot_odd = __builtin_amdgcn_readfirstlane(hw_id & 1u) != 0;
-    if (sch.stagger_mode == 10) { if (slot_odd) __builtin_amdgcn_s_setprio(3); }
-    if (sch.stagger_mode == 11) { if (!slot_odd) __builtin_amdgcn_s_setprio(3); }
-    if (sch.stagger_mode == 12) { if (slot_odd) { __builtin_amdgcn_s_setprio(3); for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(127); } }
-  }
-
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
   __syncthreads();
 
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     float av[8];  // alpha-head activations: rows 0..15 <-> registers 0..7, feature (r&3) + 8*(r>>2) + 4*hl
     if constexpr (FMT == 1) {
       // ============================================================ trunk, split-bf16 matrix path
-      const char* wb;  // byte cursor inside the current weight segment
+      unsigned wb;  // LDS byte cursor inside the current weight segment
+#define CUR_LDS ((seg & 1) ? wbuf1_lds : wbuf0_lds)
       // ------------------------------------------------------------ FiLM = pts_bias(cond)
       f32x16 film[4];
       {
@@ -522,9 +524,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         while (done < sch.film_steps) {
           const int ns = sch.seg_steps[seg];
           SEG_BEGIN();
-          wb = reinterpret_cast<const char*>(CUR_BUF);
+          wb = CUR_LDS;
           if (done == 0) {
-            bias_init<4>(film, CUR_BUF, hl);
+            bias_init<4>(film, CUR_LDS, hl);
             wb += 1024;
           }
           for (int u = 0; u < ns; ++u) {
@@ -559,14 +561,14 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           {
             const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
             SEG_BEGIN();
-            bias_init<4>(acc, CUR_BUF, hl);
-            kblock<4>(acc, reinterpret_cast<const char*>(CUR_BUF) + 1024, lane, e0);
+            bias_init<4>(acc, CUR_LDS, hl);
+            kblock<4>(acc, CUR_LDS + 1024, lane, e0);
             SEG_END();
           }
           {
             const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
             SEG_BEGIN();
-            kblock<4>(acc, reinterpret_cast<const char*>(CUR_BUF), lane, e1);
+            kblock<4>(acc, CUR_LDS, lane, e1);
             SEG_END();
           }
         } else {
@@ -574,9 +576,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           while (done < sch.enc_steps) {
             const int ns = sch.seg_steps[seg];
             SEG_BEGIN();
-            wb = reinterpret_cast<const char*>(CUR_BUF);
+            wb = CUR_LDS;
             if (done == 0) {
-              bias_init<4>(acc, CUR_BUF, hl);
+              bias_init<4>(acc, CUR_LDS, hl);
               wb += 1024;
             }
             for (int u = 0; u < ns; ++u) {
@@ -594,9 +596,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 #pragma unroll
         for (int sgi = 0; sgi < 4; ++sgi) {
           SEG_BEGIN();
-          wb = reinterpret_cast<const char*>(CUR_BUF);
+          wb = CUR_LDS;
           if (sgi == 0 && with_bias) {
-            bias_init<4>(acc, CUR_BUF, hl);
+            bias_init<4>(acc, CUR_LDS, hl);
             wb += 1024;
           }
           kblock<4>(acc, wb, lane, h[sgi]);
@@ -629,8 +631,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       {
         f32x16 al[1];
         SEG_BEGIN();
-        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
-        bias_init<1>(al, CUR_BUF, hl);
+        wb = CUR_LDS + 1024;
+        bias_init<1>(al, CUR_LDS, hl);
 #pragma unroll
         for (int sgi = 0; sgi < 4; ++sgi) kblock<1>(al, wb + sgi * 2 * K16_UNIT_BYTES, lane, h[sgi]);
 #pragma unroll
@@ -654,13 +656,13 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       f32x16 hv[2];
       {
         SEG_BEGIN();
-        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
-        bias_init<2>(hv, CUR_BUF, hl);
+        wb = CUR_LDS + 1024;
+        bias_init<2>(hv, CUR_LDS, hl);
         kblock<2>(hv, wb, lane, acc[0]);
         kblock<2>(hv, wb + 4 * K16_UNIT_BYTES, lane, acc[1]);
         SEG_END();
         SEG_BEGIN();
-        wb = reinterpret_cast<const char*>(CUR_BUF);
+        wb = CUR_LDS;
         kblock<2>(hv, wb, lane, acc[2]);
         kblock<2>(hv, wb + 4 * K16_UNIT_BYTES, lane, acc[3]);
         const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -676,8 +678,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       {
         f32x16 c3[1];
         SEG_BEGIN();
-        wb = reinterpret_cast<const char*>(CUR_BUF) + 1024;
-        bias_init<1>(c3, CUR_BUF, hl);
+        wb = CUR_LDS + 1024;
+        bias_init<1>(c3, CUR_LDS, hl);
         kblock<1>(c3, wb, lane, hv[0]);
         kblock<1>(c3, wb + 2 * K16_UNIT_BYTES, lane, hv[1]);
         if (hl == 0) {
@@ -696,6 +698,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         SEG_END();
       }
       TL_STAMP(8);
+#undef CUR_LDS
     } else {
       // ============================================================ trunk, exact-f32 MFMA path
     // ------------------------------------------------------------ FiLM = pts_bias(cond)
