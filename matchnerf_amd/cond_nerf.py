@@ -3,7 +3,7 @@
 Host-side mirror of /root/reference/models/rfdecoder/cond_nerf.py:8-50 (+ nerf.py,
 ray_transformer.py): the module owns the same parameters under the same ``state_dict`` keys
 (binding for checkpoint drop-in), but it does not evaluate them with
-torch ops.  ``pack_decoder`` re-lays the weights out as the MFMA A-fragment stream consumed by
+torch ops.  ``pack_wstream16`` / ``pack_wstream`` re-lay the weights out as the MFMA A-fragment stream consumed by
 the fused HIP kernel (csrc/decoder.hip) and the evaluation itself happens in
 ``libmnerf_hip.so`` (``mnerf_decoder_chunk`` / ``mnerf_render_chunk``).
 

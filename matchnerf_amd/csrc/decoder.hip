@@ -1,5 +1,7 @@
 // K3+K4+K5 — conditional radiance MLP + per-ray transformer + alpha compositing as ONE
-// ray-chunk kernel for gfx950 (fp32, exact-f32 MFMA).
+// ray-chunk kernel for gfx950: fp32 data and accumulation; matrix products either on the exact-f32 MFMA
+// (FMT = 0) or as fp32-grade products of three bf16 terms per operand on the bf16 MFMA (FMT = 1, default;
+// see "split-bf16 matrix path" below).
 //
 // Replaces, per chunk of rays (paths relative to /root/reference):
 //   models/matchnerf.py:118-132        NDC warp w.r.t. source view 0, view-dir rotation
@@ -12,7 +14,7 @@
 // ray-attention K/V and per-sample (rgb,sigma) live in LDS, and only 5 floats per ray are
 // written to HBM.
 //
-// ---- MFMA formulation (the part that is specific to CDNA) --------------------------------
+// ---- MFMA formulation (the part that is specific to CDNA; described for FMT = 0) --------------
 // Every Linear is evaluated TRANSPOSED:  Y^T[out, sample] = W[out, in] . H^T[in, sample]
 // with v_mfma_f32_32x32x2_f32:  A = W tile (32 outs x 2 ins), B = H^T (2 ins x 32 samples).
 // A wave owns 32 samples (N = lane&31) and all 128 outputs (4 M-blocks -> 4 x 16 accumulator
@@ -21,13 +23,13 @@
 // K-steps are taken in the order "register r of block m": lower half-wave supplies input
 // feature f_lo(m,r), upper half supplies f_hi(m,r) = f_lo + 4.  Since a dot product does not
 // care about the order of its terms, the host packs each weight matrix with its columns
-// permuted to that order (matchnerf_amd/cond_nerf.py:pack_decoder), and the whole 6-layer
-// MLP + heads chains accumulator -> operand with NO transpose, shuffle or LDS round trip.
+// permuted to that order (matchnerf_amd/cond_nerf.py: pack_wstream, pack_wstream16), and the whole
+// 6-layer MLP + heads chains accumulator -> operand with NO transpose, shuffle or LDS round trip.
 // Biases ride along as one extra K-step whose B operand is the constant (1 | 0); the FiLM
 // multiplier (pts_bias(cond), cond_nerf.py:62) is itself computed by an MFMA stage and kept
 // in 64 VGPRs; the epilogue of a layer is one v_mul + v_max per accumulator register.
 //
-// Weights: 130k floats (521 KB) cannot live in LDS, so the packed A-fragment stream is cut
+// Weights: 130k floats (521 KB as fp32 fragments, 808 KB as three bf16 terms) cannot live in LDS, so the packed A-fragment stream is cut
 // into segments of <= 33 KiB that every wave consumes in the same order; segment i+1 is
 // DMA'd global->LDS (global_load_lds_dwordx4, no VGPRs) into the other half of a double
 // buffer while segment i feeds the MFMAs; one workgroup barrier per segment.
