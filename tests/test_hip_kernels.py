@@ -166,6 +166,42 @@ def test_decoder_math_variants_agree(hip, name):
     assert e16 < max(2.0 * e32, 2e-6)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_decoder_math_variants_agree_on_rescaled_weights(hip, seed):
+    """Robustness of the three-term bf16 split: every decoder tensor rescaled by a random factor in
+    [0.25, 4] (activations then span several orders of magnitude through the FiLM-modulated trunk);
+    the split-bf16 path must track the exact-f32 MFMA path to fp32 noise relative to the magnitudes
+    involved, for the per-sample colours and the unbounded density."""
+    g, cfg, sd, batch, _, _ = _case_on_gpu("c1_default")
+    rng = np.random.default_rng(seed)
+    sd2 = {k: (v * float(2.0 ** rng.uniform(-2, 2)) if k.startswith("nerf_dec.") and v.dtype.is_floating_point else v)
+           for k, v in sd.items()}
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    n, s, dc = g["cond"].shape
+    view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                          float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+    out = {}
+    for math in ("bf16x6", "f32"):
+        dec, keep = make_decoder_struct(cfg, sd2, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
+        cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
+        out[math] = [t.cpu() for t in hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)]
+    # judge both paths against the same network evaluated in float64 (the oracle is dtype-generic): with
+    # magnitudes blown up like this fp32 itself is only good to ~1e-5, and the split path must not be worse
+    with torch.no_grad():
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd2.items()}
+        cond64 = torch.from_numpy(g["cond"]).double()
+        rgb64, sig64 = O.decoder(cfg, sd64, torch.from_numpy(g["x_ref"]).double(), torch.from_numpy(g["dir_ref"]).double(),
+                                 cond64, cond64[..., -cfg.n_src_views:])
+    assert torch.isfinite(out["bf16x6"][3]).all() and torch.isfinite(out["bf16x6"][4]).all()
+    e_rgb = {m: linf(out[m][3].double(), rgb64) for m in out}
+    e_sig = {m: linf(out[m][4].double(), sig64) for m in out}
+    print(f"\n[seed {seed}] vs float64: rgb_s bf16x6 {e_rgb['bf16x6']:.2e} / f32 {e_rgb['f32']:.2e};"
+          f" sigma bf16x6 {e_sig['bf16x6']:.2e} / f32 {e_sig['f32']:.2e} (max sigma {float(sig64.abs().max()):.2e})")
+    assert e_rgb["bf16x6"] < 2.0 * e_rgb["f32"] + 1e-6
+    assert e_sig["bf16x6"] < 2.0 * e_sig["f32"] + 1e-6 * max(1.0, float(sig64.abs().max()))
+
+
 @pytest.mark.parametrize("name,chunk", [("c1_default", 1024), ("c1_default", 4096), ("rect_wide", 1000),
                                         ("nonlegacy", 1536), ("v4", 37)])
 def test_render_chunk_full_frame_matches_reference(hip, name, chunk):
