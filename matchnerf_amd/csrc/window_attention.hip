@@ -1,4 +1,5 @@
-// K6 — GMFlow single-head (shifted-)window attention, flash style, exact-f32 MFMA (gfx950).
+// K6 — GMFlow single-head (shifted-)window attention, flash style, on the matrix pipe (gfx950):
+// exact-f32 MFMA kernel and, by default, a split-bf16 variant (second half of this file).
 //
 // Replaces (paths relative to /root/reference/models/gmflow):
 //   transformer.py:8-16    single_head_full_attention   (num_splits == 1)
@@ -212,6 +213,194 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_kernel(
   }
 }
 
+// ============================================================================ split-bf16 variant
+// Same flash-style loop with the products on v_mfma_f32_32x32x16_bf16: every fp32 operand is split into
+// three bf16 terms and a product is accumulated in fp32 from six terms (decoder.hip, "split-bf16 matrix
+// path": fp32-grade results at 16/6 of the f32 matrix rate).  Q is split once per workgroup and kept in
+// 96 VGPRs; K and V fragments are split as they are read from the fp32 LDS tiles; P is split straight
+// out of the score accumulator, whose layout makes registers 8t..8t+7 the operands of K16-step t.
+// Operand layout: lane (n, half) supplies k = 8*half + j of a 16-wide K-step.
+//   S^T: K-step t covers channels 16t..16t+15          (A = K row of key n, B = Q of query n)
+//   O^T: K-step t covers the keys held by score registers 8t..8t+7, i.e. key(t, half, j) =
+//        ((8t+j)&3) + 8((8t+j)>>2) + 4*half            (A = V^T rows d = 32m + n, B = P)
+typedef __bf16 wa_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wa_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wa_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wa_u32x4 __attribute__((ext_vector_type(4)));
+
+struct WaParts {
+  wa_bf16x8 hi, mid, lo;
+};
+
+__device__ __forceinline__ unsigned wa_pk_bf16(float a, float b) {
+  const wa_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wa_bf16x2));
+}
+
+__device__ __forceinline__ WaParts wa_split8(const float (&v)[8]) {
+  wa_u32x4 H, M, L;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h = wa_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = wa_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    H[i] = h;
+    M[i] = m;
+    L[i] = wa_pk_bf16(sa, sb);
+  }
+  WaParts p;
+  p.hi = __builtin_bit_cast(wa_bf16x8, H);
+  p.mid = __builtin_bit_cast(wa_bf16x8, M);
+  p.lo = __builtin_bit_cast(wa_bf16x8, L);
+  return p;
+}
+
+__device__ __forceinline__ f32x16 wa_mfma16(wa_bf16x8 a, wa_bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// acc += A . B with both operands given as three bf16 terms (six product terms, small ones first)
+__device__ __forceinline__ f32x16 wa_mac6(const WaParts& a, const WaParts& b, f32x16 acc) {
+  acc = wa_mfma16(a.hi, b.lo, acc);
+  acc = wa_mfma16(a.lo, b.hi, acc);
+  acc = wa_mfma16(a.mid, b.mid, acc);
+  acc = wa_mfma16(a.hi, b.mid, acc);
+  acc = wa_mfma16(a.mid, b.hi, acc);
+  acc = wa_mfma16(a.hi, b.hi, acc);
+  return acc;
+}
+
+template <int NQW>
+__global__ __launch_bounds__(NQW * 64, 2) void window_attention_bf16_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ out, WinGeom G, int shifted, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float wa_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  const int win = blockIdx.y, b = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
+
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, 0, WA_KBUF(0), WA_VBUF(0), wave, lane);
+
+  // ---- this lane's query, split once: K-step t holds channels 16t + 8 hl + j
+  const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
+  const bool q_ok = qi_raw < G.Lw;
+  int q_region;
+  const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
+  WaParts qp[8];
+  {
+    const float4* src = reinterpret_cast<const float4*>(q + seq_base + (size_t)q_tok * WA_C + hl * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 a = src[4 * t], c = src[4 * t + 1];
+      const float qv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+      qp[t] = wa_split8(qv);
+    }
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
+  float m_run = -3.0e38f, l_run = 0.0f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < n_tiles)
+      wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, kt + 1, WA_KBUF(cur ^ 1), WA_VBUF(cur ^ 1), wave, lane);
+    // ---- S^T = K Q^T: 8 K16-steps over d, two accumulators so that consecutive MFMA groups are independent
+    f32x16 s0 = (f32x16)(0.0f), s1 = (f32x16)(0.0f);
+    {
+      const float* krow = WA_KBUF(cur) + n * WA_C;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c4 = 4 * t + 2 * hl;  // 16-byte column groups of channels 16t + 8hl .. + 7 (swizzled by the key)
+        const float4 a = *reinterpret_cast<const float4*>(krow + ((c4 ^ n) << 2));
+        const float4 c = *reinterpret_cast<const float4*>(krow + (((c4 + 1) ^ n) << 2));
+        const float kv[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        const WaParts kp = wa_split8(kv);
+        if (t & 1)
+          s1 = wa_mac6(kp, qp[t], s1);
+        else
+          s0 = wa_mac6(kp, qp[t], s0);
+      }
+    }
+    f32x16 s = s0 + s1;
+    // ---- scale, masks, online softmax (as in the f32 kernel)
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+      const int li = kt * WA_KT + key;
+      float sv = s[r] * scale;
+      if (shifted) {
+        int kreg;
+        (void)win_token(G, wy, wx, li < G.Lw ? li : (G.Lw - 1), kreg);
+        if (kreg != q_region) sv += -100.0f;
+      }
+      if (li >= G.Lw) sv = -3.0e38f;
+      s[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+    // ---- O^T += V^T P^T: 2 K16-steps over the tile's keys (score registers 8t..8t+7), 4 M-blocks over d
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+      const WaParts pp = wa_split8(pv);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * t + j;
+          const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+          vv[j] = WA_VBUF(cur)[key * WA_C + 32 * m + n];
+        }
+        o[m] = wa_mac6(wa_split8(vv), pp, o[m]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (q_ok) {
+    const float inv_l = 1.0f / l_run;
+    float* dst = out + seq_base + (size_t)q_tok * WA_C;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 t = make_float4(o[m][4 * g4] * inv_l, o[m][4 * g4 + 1] * inv_l,
+                                     o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
+        *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
+      }
+  }
+}
+
 extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                                       int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                                       int32_t shifted, void* stream) {
@@ -247,12 +436,26 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   }
   int min4 = 200;  // use 128-query workgroups once they (nearly) fill the 256 CUs
   if (const char* e = getenv("MNERF_WA_MIN4")) min4 = atoi(e);
+  bool split = true;  // split-bf16 products (default) or the exact-f32 MFMA (MNERF_WA_MATH=f32)
+  if (const char* e = getenv("MNERF_WA_MATH")) split = !(e[0] == 'f' && e[1] == '3' && e[2] == '2');
+  static bool attr16_set = false;
+  if (split && !attr16_set) {
+    (void)hipFuncSetAttribute((const void*)window_attention_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr16_set = true;
+  }
   if (wgs4 >= min4) {
     dim3 grid((G.Lw + 127) / 128, num_splits * num_splits, batch);
-    hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
+    if (split)
+      hipLaunchKernelGGL(window_attention_bf16_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
+    else
+      hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
   } else {
     dim3 grid((G.Lw + 63) / 64, num_splits * num_splits, batch);
-    hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
+    if (split)
+      hipLaunchKernelGGL(window_attention_bf16_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
+    else
+      hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
   }
   return mnerf_check_launch("mnerf_window_attention");
 }
