@@ -62,8 +62,11 @@ def test_window_attention_matches_reference(hip, golden, tag):
     assert linf(hip.window_attention(q, k, v, h, w, 1, False), g[f"{tag}_full"]) < 2e-5
 
 
-def test_window_attention_dtu_shape_matches_oracle(hip):
-    """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case."""
+@pytest.mark.parametrize("math", ["bf16x6", "f32"])
+def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
+    """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case, through both
+    matrix paths of the kernel (split-bf16 = default, exact-f32 MFMA)."""
+    monkeypatch.setenv("MNERF_WA_MATH", math)
     gen = torch.Generator().manual_seed(3)
     for (b, h, w, splits) in ((2, 64, 80, 2), (1, 50, 50, 2)):
         q, k, v = (torch.randn(b, h * w, 128, generator=gen) for _ in range(3))
