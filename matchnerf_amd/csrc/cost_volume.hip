@@ -337,8 +337,10 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
 template <int CPL, int LPG>
 __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const float* __restrict__ m1, int fw,
                                           const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
-                                          int rec_stride, float* __restrict__ cs_owner, int cs_stride, bool owner,
+                                          int rec_stride, float* __restrict__ cs_group, int cs_stride, int sub,
                                           unsigned lane_bytes) {
+  static_assert(CVW_SEG % LPG == 0, "segment length must be a multiple of the lanes per channel group");
+  float k_dot = 0.0f, k_na = 1.0f, k_nb = 1.0f;  // the (sample, group) triple this lane will turn into a cosine
   PairQuad<CPL> qa, qb;
 #pragma unroll
   for (int i = 0; i < 4; ++i) qa.idx[i >> 1][i & 1] = qb.idx[i >> 1][i & 1] = -1;
@@ -366,16 +368,28 @@ __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const fl
     const float dot = dpp_group_sum<LPG>(dot2.x + dot2.y);
     const float na = dpp_group_sum<LPG>(na2.x + na2.y);
     const float nb = dpp_group_sum<LPG>(nb2.x + nb2.y);
+    // After the all-reduce the LPG lanes of a channel group hold the same (dot, |a|^2, |b|^2), so evaluating the
+    // cosine (two IEEE square roots and a divide, ~45 VALU) in all of them is LPG-fold redundant.  Instead lane u
+    // of the group keeps the triple of sample js = jb + u, and the cosines of LPG samples are evaluated together
+    // once per LPG steps (CVW_SEG is a multiple of every LPG): every lane then owns one (sample, group) sum.
+    const int u = js & (LPG - 1);
+    if (LPG == 1 || (sub & (LPG - 1)) == u) {
+      k_dot = dot;
+      k_na = na;
+      k_nb = nb;
+    }
+    if (u == LPG - 1) {
 #if CVW_FAST_COS
-    // 1-ulp hardware sqrt / rcp instead of the correctly rounded sequences (~45 VALU per step):
-    // |error| <= ~3 ulp of a cosine, 2e-7 absolute
-    const float da = fmaxf(__builtin_amdgcn_sqrtf(na), 1e-8f), db = fmaxf(__builtin_amdgcn_sqrtf(nb), 1e-8f);
-    const float c = dot * __builtin_amdgcn_rcpf(da * db);
+      // 1-ulp hardware sqrt / rcp instead of the correctly rounded sequences: |error| <= ~3 ulp of a cosine
+      const float da = fmaxf(__builtin_amdgcn_sqrtf(k_na), 1e-8f), db = fmaxf(__builtin_amdgcn_sqrtf(k_nb), 1e-8f);
+      const float c = k_dot * __builtin_amdgcn_rcpf(da * db);
 #else
-    const float da = fmaxf(sqrtf(na), 1e-8f), db = fmaxf(sqrtf(nb), 1e-8f);
-    const float c = dot / (da * db);
+      const float da = fmaxf(sqrtf(k_na), 1e-8f), db = fmaxf(sqrtf(k_nb), 1e-8f);
+      const float c = k_dot / (da * db);
 #endif
-    if (owner) __hip_atomic_fetch_add(cs_owner + js * cs_stride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const int js_mine = js - (LPG - 1) + (sub & (LPG - 1));
+      __hip_atomic_fetch_add(cs_group + js_mine * cs_stride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
   }
 }
 
@@ -483,14 +497,13 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
           const int goff = s ? G0 : 0;
           const float4* rec_a = rec_lds + a * 2 + s;
           const float4* rec_b = rec_lds + b * 2 + s;
-          float* cs_owner = cs_lds + goff + sub / lpg;
-          const bool owner = (sub % lpg) == 0;
+          float* cs_group = cs_lds + goff + sub / lpg;  // this lane's channel group; it owns sample jb + sub % lpg
           switch (lpg) {
-            case 1: lean_walk<CPL, 1>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
-            case 2: lean_walk<CPL, 2>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
-            case 4: lean_walk<CPL, 4>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
-            case 8: lean_walk<CPL, 8>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
-            default: lean_walk<CPL, 16>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_owner, cs_stride, owner, lane_bytes); break;
+            case 1: lean_walk<CPL, 1>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
+            case 2: lean_walk<CPL, 2>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
+            case 4: lean_walk<CPL, 4>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
+            case 8: lean_walk<CPL, 8>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
+            default: lean_walk<CPL, 16>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
           }
         }
       }
