@@ -219,16 +219,20 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
 // The first walk kernel (19.7 ms/frame) turned out VALU-bound on its own bookkeeping: 96 % VALU
 // busy, ~360 VALU instructions per (sample, pair, scale) step of a wave against ~90 of
 // interpolation + dot products.  This version (12.9 ms/frame) keeps the traversal with a lean step:
-//  * the bilinear set-up (texel index, fractions, border flags) is evaluated once per
-//    (sample, view, scale) in pass 1 and parked in LDS as a 16-byte record, instead of once per
-//    pair in the inner loop; a quad is identified by its top-left texel alone (one compare);
+//  * nothing that is the same for the 16 lanes of a slot is evaluated per lane per step: the bilinear set-up
+//    and the parity-set bookkeeping of a (sample, view) are evaluated once per (pair, scale) walk by the
+//    lane whose index equals the sample's position in the segment and handed over as a 32-byte LDS record;
+//    the cosine of a (sample, group) is evaluated by one lane, LPG samples at a time;
 //  * interpolation and the three dot products run on channel PAIRS (v_pk_mul/v_pk_fma_f32: the
 //    dwordx4 loads already put consecutive channels in consecutive registers);
 //  * the group reductions are compile-time DPP butterflies (quad_perm / row_half_mirror /
 //    row_mirror) instead of ds_bpermute shuffles with a run-time width;
 //  * reload addresses are 32-bit byte offsets from the scalar map base;
-//  * owner lanes accumulate the per-pair cosines with LDS float atomics (program order per lane,
-//    so the sum over pairs keeps the reference's pair order).
+//  * the per-pair cosines accumulate with LDS float atomics (one fixed lane per (sample, group), program
+//    order per lane, so the sum over pairs keeps the reference's pair order).
+// Where it stands (PMC): 113 VALU instructions per step (from ~360), VALU 60 % busy, texture-address unit
+// 85 % busy — every reload is a wave instruction that costs the TA ~16 cycles however few lanes are active,
+// and a wave's four slots rarely cross a texel boundary in the same step.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -294,27 +298,33 @@ __device__ __forceinline__ void tap_load(v2f (&t)[CPL / 2], const float* __restr
   }
 }
 
-// bring the four parity sets up to date for this record; returns the four set weights
-template <int CPL>
-__device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __restrict__ map, int w, const float4 rec,
-                                            unsigned lane_bytes, float (&wt)[2][2]) {
-  const int o00 = __float_as_int(rec.x), fl = __float_as_int(rec.w);
+// Expanded walk record of one (sample, view) at the scale being walked: texel held by each parity set
+// {EE, EO, OE, OO} and that set's bilinear weight.  Everything in it is the same for the 16 lanes of a slot, so
+// it is evaluated ONCE per (pair, scale) walk by the lane whose index equals the sample's position in the
+// segment (52 VALU ops per step in every lane became ~6) and handed over through 32 bytes of LDS.
+__device__ __forceinline__ void tap_expand(const TapRec& t, int w, float4& idx, float4& wts) {
+  const int fl = t.flags;
   const int ex0 = fl & 1, ex1 = (fl >> 1) & 1;
   const int ey0 = (fl & 4) ? w : 0, ey1 = (fl & 8) ? w : 0;
-  const int b0 = o00 + ey0, b1 = o00 + ey1;
-  const int i00 = b0 + ex0, i01 = b0 + ex1, i10 = b1 + ex0, i11 = b1 + ex1;
+  const int b0 = t.o00 + ey0, b1 = t.o00 + ey1;
+  idx = make_float4(__int_as_float(b0 + ex0), __int_as_float(b0 + ex1), __int_as_float(b1 + ex0), __int_as_float(b1 + ex1));
+  const float fx = t.fx, fy = t.fy, gx = 1.0f - fx, gy = 1.0f - fy;
+  const bool px = fl & 16, py = fl & 32;
+  const float wxE = px ? fx : gx, wxO = px ? gx : fx;  // the even column is x0 (weight 1-fx) iff x0 is even
+  const float wyE = py ? fy : gy, wyO = py ? gy : fy;
+  // same products as bilin_setup(): (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx fy
+  wts = make_float4(wxE * wyE, wxO * wyE, wxE * wyO, wxO * wyO);
+}
+
+// bring the four parity sets up to date for this walk record
+template <int CPL>
+__device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __restrict__ map, const float4 ix,
+                                            unsigned lane_bytes) {
+  const int i00 = __float_as_int(ix.x), i01 = __float_as_int(ix.y), i10 = __float_as_int(ix.z), i11 = __float_as_int(ix.w);
   if (i00 != q.idx[0][0]) { tap_load<CPL>(q.t[0][0], map, i00, lane_bytes); q.idx[0][0] = i00; }
   if (i01 != q.idx[0][1]) { tap_load<CPL>(q.t[0][1], map, i01, lane_bytes); q.idx[0][1] = i01; }
   if (i10 != q.idx[1][0]) { tap_load<CPL>(q.t[1][0], map, i10, lane_bytes); q.idx[1][0] = i10; }
   if (i11 != q.idx[1][1]) { tap_load<CPL>(q.t[1][1], map, i11, lane_bytes); q.idx[1][1] = i11; }
-  const float fx = rec.y, fy = rec.z, gx = 1.0f - fx, gy = 1.0f - fy;
-  const bool px = fl & 16, py = fl & 32;
-  const float wxE = px ? fx : gx, wxO = px ? gx : fx;  // the even column is x0 (weight 1-fx) iff x0 is even
-  const float wyE = py ? fy : gy, wyO = py ? gy : fy;
-  wt[0][0] = wxE * wyE;  // same products as bilin_setup(): (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx fy
-  wt[0][1] = wxO * wyE;
-  wt[1][0] = wxE * wyO;
-  wt[1][1] = wxO * wyO;
 }
 
 template <int CTRL>
@@ -335,21 +345,20 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
 
 // one (pair, scale): walk the CVW_SEG samples of this slot's segment
 template <int CPL, int LPG>
-__device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const float* __restrict__ m1, int fw,
-                                          const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
-                                          int rec_stride, float* __restrict__ cs_group, int cs_stride, int sub,
-                                          unsigned lane_bytes) {
+__device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const float* __restrict__ m1,
+                                          const float4* __restrict__ wrec /* [js][view a|b][idx|weights] */,
+                                          float* __restrict__ cs_group, int cs_stride, int sub, unsigned lane_bytes) {
   static_assert(CVW_SEG % LPG == 0, "segment length must be a multiple of the lanes per channel group");
   float k_dot = 0.0f, k_na = 1.0f, k_nb = 1.0f;  // the (sample, group) triple this lane will turn into a cosine
   PairQuad<CPL> qa, qb;
 #pragma unroll
   for (int i = 0; i < 4; ++i) qa.idx[i >> 1][i & 1] = qb.idx[i >> 1][i & 1] = -1;
   for (int js = 0; js < CVW_SEG; ++js) {
-    float wa[2][2], wb[2][2];
-    quad_update<CPL>(qa, m0, fw, rec_a[js * rec_stride], lane_bytes, wa);
-    quad_update<CPL>(qb, m1, fw, rec_b[js * rec_stride], lane_bytes, wb);
-    const v2f A00 = {wa[0][0], wa[0][0]}, A01 = {wa[0][1], wa[0][1]}, A10 = {wa[1][0], wa[1][0]}, A11 = {wa[1][1], wa[1][1]};
-    const v2f B00 = {wb[0][0], wb[0][0]}, B01 = {wb[0][1], wb[0][1]}, B10 = {wb[1][0], wb[1][0]}, B11 = {wb[1][1], wb[1][1]};
+    const float4 wa = wrec[js * 4 + 1], wb = wrec[js * 4 + 3];
+    quad_update<CPL>(qa, m0, wrec[js * 4 + 0], lane_bytes);
+    quad_update<CPL>(qb, m1, wrec[js * 4 + 2], lane_bytes);
+    const v2f A00 = {wa.x, wa.x}, A01 = {wa.y, wa.y}, A10 = {wa.z, wa.z}, A11 = {wa.w, wa.w};
+    const v2f B00 = {wb.x, wb.x}, B01 = {wb.y, wb.y}, B10 = {wb.z, wb.z}, B11 = {wb.w, wb.w};
     v2f dot2 = {0.f, 0.f}, na2 = {0.f, 0.f}, nb2 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < CPL / 2; ++k) {
@@ -404,12 +413,13 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
   const int V = sc.n_views;
   const int sub = threadIdx.x % LPS;
   const int slot = threadIdx.x / LPS;                               // NSLOT adjacent rays
-  const int rec_stride = V * 2;                                     // records per segment sample
   const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
   const int sumG = G0 + G1;
   const int cs_stride = (sumG + 3) & ~3;                            // cosine sums per segment sample in LDS
-  float4* rec_lds = reinterpret_cast<float4*>(cvw_smem) + (size_t)slot * CVW_SEG * rec_stride;  // [js][view][scale]
-  float* cs_lds = cvw_smem + (size_t)NSLOT * CVW_SEG * rec_stride * 4 + slot * CVW_SEG * cs_stride;  // [js][cos sums]
+  // LDS per slot: projections [js][view](u,v) | walk records [js][view a|b][idx|weights] (float4) | cosine sums [js][cs]
+  float* uv_lds = cvw_smem + (size_t)slot * CVW_SEG * V * 2;
+  float4* wrec_lds = reinterpret_cast<float4*>(cvw_smem + (size_t)NSLOT * CVW_SEG * V * 2) + (size_t)slot * CVW_SEG * 4;
+  float* cs_lds = cvw_smem + (size_t)NSLOT * CVW_SEG * (V * 2 + 16) + slot * CVW_SEG * cs_stride;
   const int S = R.n_samples;
   const int P = V * (V - 1) / 2;
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
@@ -451,12 +461,8 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
       for (int v = 0; v < V; ++v) {
         float u, w_, z;
         project(sc.views[v], px, py, pz, wm1, hm1, u, w_, z);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s >= sc.n_scales) break;
-          const TapRec t = tap_setup(u, w_, sc.fh[s], sc.fw[s]);
-          rec_lds[(js * V + v) * 2 + s] = make_float4(__int_as_float(t.o00), t.fx, t.fy, __int_as_float(t.flags));
-        }
+        uv_lds[(js * V + v) * 2 + 0] = u;
+        uv_lds[(js * V + v) * 2 + 1] = w_;
         const Bilin b = bilin_setup(u, w_, R.height, R.width);
         const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
         const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
@@ -495,15 +501,33 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
           const int G = sc.n_group[s];
           const int lpg = LPS / G;  // lanes per channel group
           const int goff = s ? G0 : 0;
-          const float4* rec_a = rec_lds + a * 2 + s;
-          const float4* rec_b = rec_lds + b * 2 + s;
           float* cs_group = cs_lds + goff + sub / lpg;  // this lane's channel group; it owns sample jb + sub % lpg
+          // walk records of this (pair, scale): lane `sub` expands samples sub, sub+LPS, .. of views a and b
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous walk's reads of wrec_lds are done
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int half = 0; half < SPL; ++half) {
+            const int js = sub + LPS * half;
+            if (js >= CVW_SEG) break;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              const int vw = side ? b : a;
+              const TapRec t = tap_setup(uv_lds[(js * V + vw) * 2], uv_lds[(js * V + vw) * 2 + 1], fh, fw);
+              float4 ri, rw;
+              tap_expand(t, fw, ri, rw);
+              wrec_lds[(js * 2 + side) * 2] = ri;
+              wrec_lds[(js * 2 + side) * 2 + 1] = rw;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           switch (lpg) {
-            case 1: lean_walk<CPL, 1>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
-            case 2: lean_walk<CPL, 2>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
-            case 4: lean_walk<CPL, 4>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
-            case 8: lean_walk<CPL, 8>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
-            default: lean_walk<CPL, 16>(m0, m1, fw, rec_a, rec_b, rec_stride, cs_group, cs_stride, sub, lane_bytes); break;
+            case 1: lean_walk<CPL, 1>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
+            case 2: lean_walk<CPL, 2>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
+            case 4: lean_walk<CPL, 4>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
+            case 8: lean_walk<CPL, 8>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
+            default: lean_walk<CPL, 16>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
           }
         }
       }
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
         for (int c = 0; c < sumG; ++c) out[c] = cs_lds[js * cs_stride + c] * inv_pairs;
       }
     }
-    __builtin_amdgcn_wave_barrier();  // cs_lds / rec_lds are rewritten by the next unit
+    __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds / wrec_lds are rewritten by the next unit
   }
 }
 
@@ -568,7 +592,7 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   if (sumG > CVW_CS_MAX) variant = 0;
   if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
     const int nslot = variant == 4 ? 32 : 16;
-    const size_t lds = (size_t)(nslot * CVW_SEG * scene->n_views * 2 * 4 + nslot * CVW_SEG * ((sumG + 3) & ~3)) * sizeof(float);
+    const size_t lds = (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + ((sumG + 3) & ~3)) * sizeof(float);
     MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
     static size_t lean_lds_set[2] = {0, 0};
     if (lds > lean_lds_set[variant - 3]) {
