@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
 //  * the per-pair cosines accumulate with LDS float atomics (one fixed lane per (sample, group), program
 //    order per lane, so the sum over pairs keeps the reference's pair order).
 // Where it stands (PMC): 113 VALU instructions per step (from ~360), VALU 60 % busy, texture-address unit
-// 85 % busy — every reload is a wave instruction that costs the TA ~16 cycles however few lanes are active,
-// and a wave's four slots rarely cross a texel boundary in the same step.
+// 85 % busy: 8.8 tap-load instructions per wave-step, most of them with a quarter of the lanes active because
+// a wave's four slots rarely cross a texel boundary in the same step.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
