@@ -201,6 +201,56 @@ __global__ __launch_bounds__(256, 2) void rate_kernel(const char* wpk, float* si
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// Two independent 32-sample groups per wave, ONE wave per SIMD (512 registers): the A fragments of a (step, block)
+// unit are read once and feed 12 MFMAs (6 per group, interleaved => no two consecutive MFMAs depend on each other);
+// the operand split of one group issues under the MFMAs of the other.
+__global__ __launch_bounds__(256, 1) void rate2_kernel(const char* wpk, float* sink, int iters, long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < LAYER_BYTES / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(wpk)[i];
+  __syncthreads();
+  f32x16 h0[4], h1[4], a0[4], a1[4];
+  for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) { h0[m][r] = 0.01f * (lane + r + m); h1[m][r] = 0.02f * (lane + r + 2 * m); }
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(lds + lane * 16);
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    for (int m = 0; m < 4; ++m) { a0[m] = (f32x16)(0.f); a1[m] = (f32x16)(0.f); }
+    bf16x8 ch = a[0], cm = a[64], cl = a[128];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v0[j] = h0[t >> 1][(t & 1) * 8 + j]; v1[j] = h1[t >> 1][(t & 1) * 8 + j]; }
+      const Parts b0 = split8(v0), b1 = split8(v1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int nx = (t * 4 + m + 1) * 3 * 64;
+        const bf16x8 nh = a[nx], nm = a[nx + 64], nl = a[nx + 128];
+        __builtin_amdgcn_sched_barrier(0);
+        a0[m] = mm(ch, b0.lo, a0[m]);  a1[m] = mm(ch, b1.lo, a1[m]);
+        a0[m] = mm(cl, b0.hi, a0[m]);  a1[m] = mm(cl, b1.hi, a1[m]);
+        a0[m] = mm(cm, b0.mid, a0[m]); a1[m] = mm(cm, b1.mid, a1[m]);
+        a0[m] = mm(ch, b0.mid, a0[m]); a1[m] = mm(ch, b1.mid, a1[m]);
+        a0[m] = mm(cm, b0.hi, a0[m]);  a1[m] = mm(cm, b1.hi, a1[m]);
+        a0[m] = mm(ch, b0.hi, a0[m]);  a1[m] = mm(ch, b1.hi, a1[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        ch = nh; cm = nm; cl = nl;
+      }
+    }
+    for (int m = 0; m < 4; ++m)
+      for (int r = 0; r < 16; ++r) {
+        h0[m][r] = fmaxf(a0[m][r] * 1.001f, 0.0f) * 1e-3f + 0.01f;
+        h1[m][r] = fmaxf(a1[m][r] * 1.002f, 0.0f) * 1e-3f + 0.02f;
+      }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += h0[m][r] + h1[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 static unsigned short bf16_rn(float f) {
   unsigned u; memcpy(&u, &f, 4);
   unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
@@ -275,5 +325,20 @@ int main() {
       printf("mode %d grid %d: %.3f ms, %.1f memtime ticks per MFMA (wave 0), f32-equivalent %.1f TFLOP/s\n", mode, grid, ms,
              (double)c / mfma, useful / (ms * 1e-3) / 1e12);
     }
+  {
+    const int lds2 = 100 * 1024;  // > 80 KiB: one workgroup per CU
+    hipFuncSetAttribute((const void*)rate2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    const int iters = 2000, grid = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(rate2_kernel, dim3(grid), dim3(256), lds2, 0, d_w, d_sink, iters, d_c);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double useful = 2.0 * 128 * 128 * 64 * (double)iters * grid * 4;
+    printf("two groups per wave, 1 wave/SIMD, grid %d: %.3f ms, f32-equivalent %.1f TFLOP/s\n", grid, ms, useful / (ms * 1e-3) / 1e12);
+  }
   return 0;
 }
