@@ -251,6 +251,58 @@ __global__ __launch_bounds__(256, 1) void rate2_kernel(const char* wpk, float* s
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// Isolation variants of the layer loop (two workgroups per CU): WITH_LDS = A fragments re-read from LDS per unit
+// (else held in registers), WITH_SPLIT = operands split per step (else split once).
+template <int WITH_LDS, int WITH_SPLIT>
+__global__ __launch_bounds__(256, 2) void iso_kernel(const char* wpk, float* sink, int iters, long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < LAYER_BYTES / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(wpk)[i];
+  __syncthreads();
+  f32x16 h[4], acc[4];
+  for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) h[m][r] = 0.01f * (lane + r + m);
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(lds + lane * 16);
+  bf16x8 ch = a[0], cm = a[64], cl = a[128];
+  float v0[8];
+  for (int j = 0; j < 8; ++j) v0[j] = h[0][j];
+  Parts b = split8(v0);
+  for (int it = 0; it < iters; ++it) {
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (WITH_SPLIT) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = h[t >> 1][(t & 1) * 8 + j];
+        b = split8(v);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        bf16x8 nh = ch, nm = cm, nl = cl;
+        if (WITH_LDS) {
+          const int nx = (t * 4 + m + 1) * 3 * 64;
+          nh = a[nx]; nm = a[nx + 64]; nl = a[nx + 128];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[m] = mm(ch, b.lo, acc[m]);
+        acc[m] = mm(cl, b.hi, acc[m]);
+        acc[m] = mm(cm, b.mid, acc[m]);
+        acc[m] = mm(ch, b.mid, acc[m]);
+        acc[m] = mm(cm, b.hi, acc[m]);
+        acc[m] = mm(ch, b.hi, acc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        ch = nh; cm = nm; cl = nl;
+      }
+    }
+    for (int m = 0; m < 4; ++m)
+      for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * 1.001f, 0.0f) * 1e-3f + 0.01f;
+  }
+  float s = 0.f;
+  for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += h[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static unsigned short bf16_rn(float f) {
   unsigned u; memcpy(&u, &f, 4);
   unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
@@ -325,6 +377,27 @@ int main() {
       printf("mode %d grid %d: %.3f ms, %.1f memtime ticks per MFMA (wave 0), f32-equivalent %.1f TFLOP/s\n", mode, grid, ms,
              (double)c / mfma, useful / (ms * 1e-3) / 1e12);
     }
+  for (int v = 1; v < 4; v += 2) {  // (variants without the LDS reads are loop-invariant and get hoisted: not run)
+    const int iters = 2000, grid = 512;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    hipFuncSetAttribute((const void*)iso_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    hipFuncSetAttribute((const void*)iso_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    hipFuncSetAttribute((const void*)iso_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    hipFuncSetAttribute((const void*)iso_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      if (v == 0) hipLaunchKernelGGL((iso_kernel<0, 0>), dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      if (v == 1) hipLaunchKernelGGL((iso_kernel<1, 0>), dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      if (v == 2) hipLaunchKernelGGL((iso_kernel<0, 1>), dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      if (v == 3) hipLaunchKernelGGL((iso_kernel<1, 1>), dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double useful = 2.0 * 128 * 128 * 32 * (double)iters * grid * 4;
+    printf("isolation: LDS reads %d, per-step split %d: %.3f ms, f32-equivalent %.1f TFLOP/s (%.0f %% of 2.5 PF/6)\n", v & 1, v >> 1, ms,
+           useful / (ms * 1e-3) / 1e12, 100.0 * useful / (ms * 1e-3) / 1e12 / (2500.0 / 6));
+  }
   {
     const int lds2 = 100 * 1024;  // > 80 KiB: one workgroup per CU
     hipFuncSetAttribute((const void*)rate2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
