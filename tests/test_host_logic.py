@@ -62,6 +62,26 @@ def test_unsupported_architectures_fail_loudly():
         models_dict["matchnerf"](_opts(**{"decoder.posenc.L_view": 4}))
 
 
+def test_decoder_packing_follows_the_math_switch(monkeypatch):
+    """CondNeRF.packed: split-bf16 stream by default, exact-f32 stream on request and for S > 128 (the 8-wave
+    kernel is f32-only); the cache is keyed on the switch; bad values are rejected."""
+    from matchnerf_amd import cond_nerf as CN
+    from matchnerf_amd.models import models_dict
+    dec = models_dict["matchnerf"](_opts()).nerf_dec
+    monkeypatch.delenv("MNERF_DECODER_MATH", raising=False)
+    ws, small, cs, fmt = dec.packed(64, "cpu")
+    assert fmt == 1 and ws.numel() == CN.decoder_schedule16(dec.cond_dim, dec.L_3D)[1]
+    assert dec.packed(64, "cpu")[0] is ws                       # cached
+    ws256, _, _, fmt256 = dec.packed(256, "cpu")
+    assert fmt256 == 0 and ws256.numel() == CN.decoder_schedule(cs, dec.L_3D)[1]
+    monkeypatch.setenv("MNERF_DECODER_MATH", "f32")
+    ws32, _, _, fmt32 = dec.packed(64, "cpu")
+    assert fmt32 == 0 and ws32.numel() == ws256.numel()
+    monkeypatch.setenv("MNERF_DECODER_MATH", "fp8")
+    with pytest.raises(ValueError, match="MNERF_DECODER_MATH"):
+        dec.packed(64, "cpu")
+
+
 def test_render_refuses_cpu_tensors():
     from matchnerf_amd.models import models_dict
     model = models_dict["matchnerf"](_opts())
