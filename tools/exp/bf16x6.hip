@@ -303,6 +303,51 @@ __global__ __launch_bounds__(256, 2) void iso_kernel(const char* wpk, float* sin
   sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Same loop as iso_kernel<1,0> but with the accumulators pinned in AGPRs (inline-asm MFMA with "+a" operands):
+// does the accumulator register class matter for the issue rate?
+__device__ __forceinline__ void mm_agpr(f32x16& acc, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__global__ __launch_bounds__(256, 2) void agpr_kernel(const char* wpk, float* sink, int iters, long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < LAYER_BYTES / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(wpk)[i];
+  __syncthreads();
+  f32x16 h[4], acc[4];
+  for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) h[m][r] = 0.01f * (lane + r + m);
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(lds + lane * 16);
+  bf16x8 ch = a[0], cm = a[64], cl = a[128];
+  float v0[8];
+  for (int j = 0; j < 8; ++j) v0[j] = h[0][j];
+  const Parts b = split8(v0);
+  for (int it = 0; it < iters; ++it) {
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int nx = (t * 4 + m + 1) * 3 * 64;
+        const bf16x8 nh = a[nx], nm = a[nx + 64], nl = a[nx + 128];
+        __builtin_amdgcn_sched_barrier(0);
+        mm_agpr(acc[m], ch, b.lo);
+        mm_agpr(acc[m], cl, b.hi);
+        mm_agpr(acc[m], cm, b.mid);
+        mm_agpr(acc[m], ch, b.mid);
+        mm_agpr(acc[m], cm, b.hi);
+        mm_agpr(acc[m], ch, b.hi);
+        __builtin_amdgcn_sched_barrier(0);
+        ch = nh; cm = nm; cl = nl;
+      }
+    }
+    for (int m = 0; m < 4; ++m)
+      for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * 1.001f, 0.0f) * 1e-3f + 0.01f;
+  }
+  float s = 0.f;
+  for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += h[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static unsigned short bf16_rn(float f) {
   unsigned u; memcpy(&u, &f, 4);
   unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
@@ -396,6 +441,21 @@ int main() {
     }
     const double useful = 2.0 * 128 * 128 * 32 * (double)iters * grid * 4;
     printf("isolation: LDS reads %d, per-step split %d: %.3f ms, f32-equivalent %.1f TFLOP/s (%.0f %% of 2.5 PF/6)\n", v & 1, v >> 1, ms,
+           useful / (ms * 1e-3) / 1e12, 100.0 * useful / (ms * 1e-3) / 1e12 / (2500.0 / 6));
+  }
+  {
+    const int iters = 2000, grid = 512;
+    hipFuncSetAttribute((const void*)agpr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(agpr_kernel, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double useful = 2.0 * 128 * 128 * 32 * (double)iters * grid * 4;
+    printf("accumulators in AGPRs (LDS reads, no per-step split): %.3f ms, f32-equivalent %.1f TFLOP/s (%.0f %% of 2.5 PF/6)\n", ms,
            useful / (ms * 1e-3) / 1e12, 100.0 * useful / (ms * 1e-3) / 1e12 / (2500.0 / 6));
   }
   {
