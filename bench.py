@@ -47,6 +47,8 @@ CPU_THREADS_MAX = 16 # torch intra-op threads for the CPU baseline (more threads
                      # slower on the small tensors of this path: 256 threads measured 14x slower)
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (same table)
+BF16_32X32X16_SUSTAINED_TFLOPS = 1860.0  # measured on MI355X: register-only stream of independent
+                                         # v_mfma_f32_32x32x16_bf16 (tools/exp/bf16x6.hip, pure_kernel)
 MLP_FLOPS_PER_SAMPLE = 258336  # the MLP part of SURVEY.md §8(d): runs as 6 bf16 products per MAC in bf16x6 math
 
 
@@ -232,6 +234,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "math": math, "algorithmic_tflops": round(algorithmic, 2),
+                         "instruction_ceiling": ({"tflops": BF16_32X32X16_SUSTAINED_TFLOPS,
+                                                  "frac": round(achieved / BF16_32X32X16_SUSTAINED_TFLOPS, 4),
+                                                  "what": "sustained rate of a register-only v_mfma_f32_32x32x16_bf16 "
+                                                          "stream measured on this GPU model"} if math == "bf16x6" else None),
                          "issued_flops_per_launch": issued_launch,
                          "traffic": measured_traffic(int(dec["rays"] / dec["launches"])),
                          "avg_launch_ms": round(dec["avg_ms"], 4),

@@ -348,6 +348,81 @@ __global__ __launch_bounds__(256, 2) void agpr_kernel(const char* wpk, float* si
   sink[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// iso_kernel<1,0> with the MFMAs of two output blocks interleaved (no two consecutive MFMAs on one accumulator)
+__global__ __launch_bounds__(256, 2) void iso2_kernel(const char* wpk, float* sink, int iters, long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < LAYER_BYTES / 16; i += 256) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(wpk)[i];
+  __syncthreads();
+  f32x16 h[4], acc[4];
+  for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) h[m][r] = 0.01f * (lane + r + m);
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(lds + lane * 16);
+  bf16x8 ch0 = a[0], cm0 = a[64], cl0 = a[128], ch1 = a[192], cm1 = a[256], cl1 = a[320];
+  float v0[8];
+  for (int j = 0; j < 8; ++j) v0[j] = h[0][j];
+  const Parts b = split8(v0);
+  for (int it = 0; it < iters; ++it) {
+    for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int mp = 0; mp < 4; mp += 2) {
+        const int nx = (t * 4 + mp + 2) * 3 * 64;
+        const bf16x8 nh0 = a[nx], nm0 = a[nx + 64], nl0 = a[nx + 128], nh1 = a[nx + 192], nm1 = a[nx + 256], nl1 = a[nx + 320];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[mp] = mm(ch0, b.lo, acc[mp]);   acc[mp + 1] = mm(ch1, b.lo, acc[mp + 1]);
+        acc[mp] = mm(cl0, b.hi, acc[mp]);   acc[mp + 1] = mm(cl1, b.hi, acc[mp + 1]);
+        acc[mp] = mm(cm0, b.mid, acc[mp]);  acc[mp + 1] = mm(cm1, b.mid, acc[mp + 1]);
+        acc[mp] = mm(ch0, b.mid, acc[mp]);  acc[mp + 1] = mm(ch1, b.mid, acc[mp + 1]);
+        acc[mp] = mm(cm0, b.hi, acc[mp]);   acc[mp + 1] = mm(cm1, b.hi, acc[mp + 1]);
+        acc[mp] = mm(ch0, b.hi, acc[mp]);   acc[mp + 1] = mm(ch1, b.hi, acc[mp + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        ch0 = nh0; cm0 = nm0; cl0 = nl0; ch1 = nh1; cm1 = nm1; cl1 = nl1;
+      }
+    }
+    for (int m = 0; m < 4; ++m)
+      for (int r = 0; r < 16; ++r) h[m][r] = fmaxf(acc[m][r] * 1.001f, 0.0f) * 1e-3f + 0.01f;
+  }
+  float s = 0.f;
+  for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += h[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// Pure issue-rate ceiling: register-resident operands, loop-carried accumulators (nothing to hoist), no LDS, no VALU.
+__global__ __launch_bounds__(256, 2) void pure_kernel(const char* wpk, float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(wpk) + lane;
+  bf16x8 A[6];
+  for (int i = 0; i < 6; ++i) A[i] = a[i * 64];
+  f32x16 acc[4];
+  for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.f);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 48; ++u) acc[u & 3] = mm(A[u % 6], A[(u + 1) % 6], acc[u & 3]);
+  }
+  float s = 0.f;
+  for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) s += acc[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void pure16_kernel(const char* wpk, float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  const bf16x8* a = reinterpret_cast<const bf16x8*>(wpk) + lane;
+  bf16x8 A[6];
+  for (int i = 0; i < 6; ++i) A[i] = a[i * 64];
+  f32x4v acc[8];
+  for (int m = 0; m < 8; ++m) acc[m] = (f32x4v)(0.f);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 48; ++u) acc[u & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[u % 6], A[(u + 1) % 6], acc[u & 7], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int m = 0; m < 8; ++m) for (int r = 0; r < 4; ++r) s += acc[m][r];
+  sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static unsigned short bf16_rn(float f) {
   unsigned u; memcpy(&u, &f, 4);
   unsigned r = u + 0x7fffu + ((u >> 16) & 1u);
@@ -441,6 +516,49 @@ int main() {
     }
     const double useful = 2.0 * 128 * 128 * 32 * (double)iters * grid * 4;
     printf("isolation: LDS reads %d, per-step split %d: %.3f ms, f32-equivalent %.1f TFLOP/s (%.0f %% of 2.5 PF/6)\n", v & 1, v >> 1, ms,
+           useful / (ms * 1e-3) / 1e12, 100.0 * useful / (ms * 1e-3) / 1e12 / (2500.0 / 6));
+  }
+  for (int grid : {256, 512}) {
+    const int iters = 8000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(pure_kernel, dim3(grid), dim3(256), 0, 0, d_w, d_sink, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double flops = 2.0 * 32 * 32 * 16 * 48.0 * iters * grid * 4;
+    printf("pure MFMA stream (registers only), grid %d: %.3f ms, %.0f bf16 TFLOP/s = %.0f %% of 2.5 PF\n", grid, ms, flops / (ms * 1e-3) / 1e12,
+           100.0 * flops / (ms * 1e-3) / 1e12 / 2500.0);
+  }
+  for (int grid : {256, 512, 1024}) {
+    const int iters = 16000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(pure16_kernel, dim3(grid), dim3(256), 0, 0, d_w, d_sink, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double flops = 2.0 * 16 * 16 * 32 * 48.0 * iters * grid * 4;
+    printf("pure 16x16x32 bf16 MFMA stream, grid %d: %.3f ms, %.0f bf16 TFLOP/s = %.0f %% of 2.5 PF\n", grid, ms, flops / (ms * 1e-3) / 1e12,
+           100.0 * flops / (ms * 1e-3) / 1e12 / 2500.0);
+  }
+  for (int grid : {256, 512}) {
+    const int iters = 2000;
+    hipFuncSetAttribute((const void*)iso2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rate);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(iso2_kernel, dim3(grid), dim3(256), lds_rate, 0, d_w, d_sink, iters, d_c);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      hipEventElapsedTime(&ms, e0, e1);
+    }
+    const double useful = 2.0 * 128 * 128 * 32 * (double)iters * grid * 4;
+    printf("two blocks interleaved, no per-step split, grid %d: %.3f ms, f32-equivalent %.1f TFLOP/s (%.0f %% of 2.5 PF/6)\n", grid, ms,
            useful / (ms * 1e-3) / 1e12, 100.0 * useful / (ms * 1e-3) / 1e12 / (2500.0 / 6));
   }
   {
