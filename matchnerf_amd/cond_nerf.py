@@ -7,9 +7,10 @@ torch ops.  ``pack_wstream16`` / ``pack_wstream`` re-lay the weights out as the 
 the fused HIP kernel (csrc/decoder.hip) and the evaluation itself happens in
 ``libmnerf_hip.so`` (``mnerf_decoder_chunk`` / ``mnerf_render_chunk``).
 
-Weight-stream layout (also DESIGN.md §Decoder weight stream)
+Weight-stream layouts (also DESIGN.md §5).  Two formats: the exact-f32 one described here and
+the split-bf16 one (default; ``pack_wstream16`` below, same chain with 16-wide K-steps).
 ------------------------------------------------------------
-Every Linear ``y = W x + b`` is evaluated transposed with ``v_mfma_f32_32x32x2_f32``:
+f32 format: every Linear ``y = W x + b`` is evaluated transposed with ``v_mfma_f32_32x32x2_f32``:
 for K-step ``t`` and output block ``m`` the wave needs one float per lane,
 ``A[t][lane][m] = W[m*32 + (lane & 31)][col(t, lane >> 5)]`` where ``col(t, half)`` is the
 input feature the lower / upper half-wave feeds at that step:
