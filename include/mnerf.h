@@ -18,7 +18,13 @@
  *     so no host->device copy is hidden in a call;
  *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
  *     MNERF_E_* argument-check code.  Nothing throws across the ABI.  The message of the
- *     last failure on the calling thread is available from mnerf_last_error().
+ *     last failure on the calling thread is available from mnerf_last_error();
+ *   - launches go to the calling thread's CURRENT HIP device (hipSetDevice / torch.cuda.device):
+ *     every pointer and the stream must belong to it;
+ *   - process-wide state: none that a caller can observe.  Debug / tuning knobs (MNERF_DECODER_GRID,
+ *     MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID, MNERF_WA_MIN4) are read from the
+ *     environment ONCE, when the library is loaded; the library keeps one bit per (kernel, device) to
+ *     remember that the kernel's dynamic-LDS attribute has been raised on that device.
  */
 #ifndef MNERF_H_
 #define MNERF_H_
@@ -29,9 +35,14 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 2
+#define MNERF_ABI_VERSION 3
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
+/* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
+ * 16 views x ([8,8] groups) = 81 -> 88 fits the split weight-stream formats; the exact-f32 stream keeps its FiLM
+ * inputs in registers and is limited to 64 (13 views with the shipped [2,8] groups). */
+#define MNERF_COND_STRIDE_MAX 96
+#define MNERF_COND_STRIDE_MAX_F32 64
 
 enum {
   MNERF_OK = 0,
@@ -91,10 +102,15 @@ typedef struct mnerf_scene {
  *             MNERF_WSTREAM_BF16X3 each fp32 weight as three bf16 terms for
  *                                 v_mfma_f32_32x32x16_bf16, six product terms per MAC, fp32
  *                                 accumulate, fp32 bias fragments (pack_wstream16)
+ *             MNERF_WSTREAM_F16X2 each fp32 weight as two fp16 terms of 2^ew W (one power-of-two
+ *                                 scale per tensor) for v_mfma_f32_32x32x16_f16, three product terms
+ *                                 per MAC, per-sample power-of-two activation gains chosen in the
+ *                                 kernel, fp32 accumulate and biases (pack_wstream_h; default)
  *   small   : ray-transformer + density-head parameters (fp32, layout in DESIGN.md)
  * Architecture switches mirror opt.decoder.* / opt.nerf.* (configs/base.yaml:29-48). */
 #define MNERF_WSTREAM_F32 0
 #define MNERF_WSTREAM_BF16X3 1
+#define MNERF_WSTREAM_F16X2 2
 
 typedef struct mnerf_decoder {
   const float* wstream;
@@ -102,7 +118,7 @@ typedef struct mnerf_decoder {
   const float* small_;
   int32_t n_views;         /* V = opt.n_src_views                                               */
   int32_t cond_dim;        /* sum(cos_n_group) + 4*V (cond_nerf.py:18)                          */
-  int32_t cond_stride;     /* floats per sample in `cond` buffers: multiple of 8, > cond_dim, <=64 */
+  int32_t cond_stride;     /* floats per sample in `cond` buffers: multiple of 8, > cond_dim, <= MNERF_COND_STRIDE_MAX[_F32] */
   int32_t L_3D;            /* opt.decoder.posenc.L_3D (L_view must be 0)                        */
   int32_t raytrans_posenc; /* opt.decoder.raytrans_posenc                                       */
   int32_t raytrans_elu;    /* opt.decoder.raytrans_act == "ELU" (else ReLU)                     */
@@ -129,10 +145,12 @@ int mnerf_ray_samples(const mnerf_rays* rays, const mnerf_view* view, float* pts
 /* K5 — volume-rendering quadrature.  Replaces NeRF.composite
  * (models/rfdecoder/nerf.py:101-124).  rgb_s [R,S,3], sigma [R,S], depth_s [R,S],
  * ray_len [R] (|ray|, only read when wo_render_interval == 0; may be NULL otherwise)
- * -> rgb [R,3], depth [R], opacity [R]. */
+ * -> rgb [R,3], depth [R], opacity [R] and, when non-NULL, prob [R,S] (the per-sample weights
+ * T_j alpha_j that the reference returns as its fourth value, nerf.py:116,124). */
 int mnerf_composite(int32_t n_rays, int32_t n_samples, const float* rgb_s, const float* sigma,
                     const float* depth_s, const float* ray_len, int32_t wo_render_interval,
-                    int32_t setbg_opaque, float* rgb, float* depth, float* opacity, void* stream);
+                    int32_t setbg_opaque, float* rgb, float* depth, float* opacity, float* prob,
+                    void* stream);
 
 /* K1+K2 — epipolar feature sampling + group-cosine cost volume + colours + visibility mask.
  * Replaces MatchNeRF.query_cond_info (models/matchnerf.py:209-293), sample_features_by_grid
@@ -157,6 +175,17 @@ int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0, const
                         const float* cond, float* rgb, float* depth, float* opacity,
                         float* dbg_rgb_s, float* dbg_sigma, void* stream);
 
+/* K3+K4 with caller-supplied inputs — the literal CondNeRF.forward(opt, points_3D, ray_unit, cond_info)
+ * (models/rfdecoder/cond_nerf.py:52-100): x_ndc [R,S,3] sample coordinates w.r.t. source view 0
+ * (matchnerf.py:121-126), dir [R,S,3] unit view directions in that view's frame (matchnerf.py:129-132),
+ * cond [R*S, cond_stride] = cat(feat_info, color_info, mask_info) (+ the constant 1 and zero padding of
+ * mnerf_cost_volume's layout) -> rgb_s [R,S,3], sigma [R,S].  Same kernel as mnerf_decoder_chunk without
+ * the in-kernel ray geometry and without compositing; `legacy_coord` selects the positional-encoding
+ * frequencies (2^l vs 2^l pi) and must match the packing of dec->wstream. */
+int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, int32_t n_samples,
+                          int32_t legacy_coord, const float* x_ndc, const float* dir,
+                          const float* cond, float* rgb_s, float* sigma, void* stream);
+
 /* a7 — one full render chunk = cost volume + decoder + compositing
  * (MatchNeRF.render, models/matchnerf.py:88-143).  `workspace` must hold
  * mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride) bytes. */
@@ -168,10 +197,14 @@ int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const
  * Replaces single_head_split_window_attention / single_head_full_attention and the
  * shift-mask tensor (models/gmflow/transformer.py:8-16, 19-43, 46-105).
  * q,k,v,out [batch, h*w, 128]; num_splits >= 1 (1 = full attention); `shifted` applies the
- * swin roll by half a window with wrap-region masking (-100 added across regions). */
+ * swin roll by half a window with wrap-region masking (-100 added across regions).
+ * `math`: MNERF_WA_SPLIT_BF16 (fp32-grade products from three bf16 terms per operand on the bf16
+ * matrix cores) or MNERF_WA_EXACT_F32 (v_mfma_f32_32x32x2_f32). */
+#define MNERF_WA_SPLIT_BF16 0
+#define MNERF_WA_EXACT_F32 1
 int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                            int32_t batch, int32_t h, int32_t w, int32_t num_splits,
-                           int32_t shifted, void* stream);
+                           int32_t shifted, int32_t math, void* stream);
 
 #ifdef __cplusplus
 }

@@ -201,9 +201,9 @@ class _RenderRaysFn(torch.autograd.Function):
     into the feature maps and the decoder parameters."""
 
     @staticmethod
-    def forward(ctx, model, launch, n_feat, *tensors):
+    def forward(ctx, dec, launch, n_feat, *tensors):
         feats = tensors[:n_feat]
-        ctx.model, ctx.launch, ctx.n_feat = model, launch, n_feat
+        ctx.dec, ctx.launch, ctx.n_feat = dec, launch, n_feat
         ctx.save_for_backward(*tensors)
         with torch.no_grad():
             rgb, depth, opacity = launch["hip_render"](feats)
@@ -211,10 +211,10 @@ class _RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_op):
-        model, launch, n_feat = ctx.model, ctx.launch, ctx.n_feat
+        dec, launch, n_feat = ctx.dec, ctx.launch, ctx.n_feat
         saved = ctx.saved_tensors
         feats = [t.detach().requires_grad_(True) for t in saved[:n_feat]]
-        params = list(model.nerf_dec.parameters())
+        params = list(dec.parameters())
         with torch.enable_grad():
             outs = launch["torch_render"](feats)
         wanted = [t for t in feats if True] + [p for p in params if p.requires_grad]
@@ -225,8 +225,8 @@ class _RenderRaysFn(torch.autograd.Function):
         return (None, None, None, *g_feats, *g_params)
 
 
-def render_rays(model, launch, feats):
-    """Differentiable render of one chunk: ``launch`` carries two closures over the same
-    arguments, ``hip_render(feats)`` and ``torch_render(feats)``."""
-    params = list(model.nerf_dec.parameters())
-    return _RenderRaysFn.apply(model, launch, len(feats), *feats, *params)
+def render_rays(dec, launch, feats):
+    """Differentiable render of one chunk: ``dec`` is the CondNeRF parameter holder, ``launch`` carries two
+    closures over the same arguments, ``hip_render(feats)`` and ``torch_render(feats)``."""
+    params = list(dec.parameters())
+    return _RenderRaysFn.apply(dec, launch, len(feats), *feats, *params)

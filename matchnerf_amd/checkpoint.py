@@ -45,12 +45,18 @@ def load_gmflow_checkpoint(model_enc, ckpt_path, device, gmflow_n_blocks=6):
             child.load_state_dict(child_state_dict(keep, name), strict=True)
 
 
-def save_checkpoint(saved_dir, checkpoint, ep, it, backup_ckpt=True):
+def save_checkpoint(saved_dir, checkpoint, ep, it, backup_ckpt=True, children=None):
+    """misc/utils.py:208-222: ``epoch`` / ``iter`` are stamped into the file here (callers pass only
+    model / optim / sched), ``children`` keeps the model keys with that prefix (str or tuple)."""
     ckpt_dir = os.path.join(saved_dir, "models")
     os.makedirs(ckpt_dir, exist_ok=True)
+    model_sd = checkpoint["model"]
+    if children is not None:
+        model_sd = {k: v for k, v in model_sd.items() if k.startswith(children)}
+    full = dict(checkpoint, epoch=ep, iter=it, model=model_sd)
     latest = os.path.join(ckpt_dir, "latest.pth")
-    torch.save(checkpoint, latest)
+    torch.save(full, latest)
     if backup_ckpt:
-        slim = {k: v for k, v in checkpoint.items() if k not in ("optim", "sched")}
+        slim = {k: v for k, v in full.items() if k not in ("optim", "sched")}
         torch.save(slim, os.path.join(ckpt_dir, f"ep{ep}_it{it}.pth"))
     return latest

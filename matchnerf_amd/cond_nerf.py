@@ -3,12 +3,13 @@
 Host-side mirror of /root/reference/models/rfdecoder/cond_nerf.py:8-50 (+ nerf.py,
 ray_transformer.py): the module owns the same parameters under the same ``state_dict`` keys
 (binding for checkpoint drop-in), but it does not evaluate them with
-torch ops.  ``pack_wstream16`` / ``pack_wstream`` re-lay the weights out as the MFMA A-fragment stream consumed by
-the fused HIP kernel (csrc/decoder.hip) and the evaluation itself happens in
-``libmnerf_hip.so`` (``mnerf_decoder_chunk`` / ``mnerf_render_chunk``).
+torch ops.  ``pack_wstream_h`` / ``pack_wstream16`` / ``pack_wstream`` re-lay the weights out as the MFMA
+A-fragment stream consumed by the fused HIP kernel (csrc/decoder.hip) and the evaluation itself happens in
+``libmnerf_hip.so`` (``mnerf_decoder_chunk`` / ``mnerf_decoder_samples`` / ``mnerf_render_chunk``).
 
-Weight-stream layouts (also DESIGN.md §5).  Two formats: the exact-f32 one described here and
-the split-bf16 one (default; ``pack_wstream16`` below, same chain with 16-wide K-steps).
+Weight-stream layouts (also DESIGN.md §5).  Three formats: the exact-f32 one described here, the split-bf16
+one (``pack_wstream16``) and the split-fp16 one (default; ``pack_wstream_h``) — the last two run the same chain
+with 16-wide K-steps.
 ------------------------------------------------------------
 f32 format: every Linear ``y = W x + b`` is evaluated transposed with ``v_mfma_f32_32x32x2_f32``:
 for K-step ``t`` and output block ``m`` the wave needs one float per lane,
@@ -356,14 +357,161 @@ def pack_wstream16(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_
     return out, cond_dim, cond_stride
 
 
+# ----------------------------------------------------------------------------- split-fp16 stream
+# Format 2 ("f16x3", default): the same transposed chain on v_mfma_f32_32x32x16_f16 with TWO fp16 terms per
+# operand and THREE products per MAC (hi.hi + hi.lo + lo.hi; the dropped lo.lo is < 2^-22 of the product) -
+# half the matrix work and ~half the operand-split VALU work of bf16x6.  fp16 has 11 significand bits but only a
+# 5-bit exponent, so both operands are range-managed with exact power-of-two scales:
+#   * weights: one scale 2^ew per weight TENSOR chosen on the host so that max|W| lands in [2^13, 2^14);
+#     hi = f16(W 2^ew), lo = f16(W 2^ew - hi) (round-to-nearest; residual exact in fp32).  2^-ew travels in the
+#     stage header;
+#   * activations: one scale per SAMPLE and stage chosen in the kernel from the running maximum of the sample's
+#     128 features (in-lane max + one cross-half shuffle) so that the largest operand lands in [2^14, 2^15).
+# The accumulator then holds 2^ew * g * (W x) and the layer epilogue multiplies the exact inverse back in.
+# Error per product <= ~2^-22 relative (fp32 chain: 2^-24 per rounding); elements more than 2^17 below the
+# sample's largest feature lose their lo term to fp16 underflow, an absolute error below 2^-25 of that maximum.
+# Stream unit = (K16-step, block): [hi | lo] fragments of 1 KiB (64 lanes x 8 fp16), same (lane, j) -> k map as
+# format 1.  A stage's first segment starts with a 1 KiB fp32 header: floats [0,128) = bias in accumulator order
+# (UNscaled; the kernel multiplies it by the operand gain), float [128] = 2^-ew.
+
+F16_TARGET_EXP = 14  # weights: max |W 2^ew| in [2^13, 2^14); activations: max in [2^14, 2^15)
+H_SEG_STEPS = 4      # K16-steps per segment of a 4-block stage: 4 x 4 x 2 KiB + 1 KiB header = 33 KiB
+
+
+def decoder_stages_h(cond_dim, L_3D):
+    """(name, nmb, [K16-steps per segment], has_header) in consumption order for the split-fp16 stream."""
+    tf = (cond_dim + 15) // 16
+    te = (3 * L_3D + 2 + 7) // 8
+
+    def chunks(t, per):
+        return [per] * (t // per) + ([t % per] if t % per else [])
+
+    st = [("film", 4, chunks(tf, H_SEG_STEPS), True), ("l0", 4, chunks(te, H_SEG_STEPS), True)]
+    st += [(f"l{i}", 4, [4, 4], True) for i in range(1, 5)]
+    st += [("l5e", 4, chunks(te, H_SEG_STEPS), True), ("l5h", 4, [4, 4], False), ("alpha", 1, [8], True),
+           ("feature", 4, [4, 4], True), ("views", 2, [4, 5], True), ("rgb", 1, [4], True)]
+    return st
+
+
+def decoder_schedule_h(cond_dim, L_3D):
+    """-> (segments, total_floats); segment = (stage, first_step, n_steps, nmb, float_offset, floats, has_header)."""
+    segs, off = [], 0
+    for name, m, seg_steps, has_hdr in decoder_stages_h(cond_dim, L_3D):
+        first = 0
+        for k, steps in enumerate(seg_steps):
+            hdr = has_hdr and k == 0
+            fl = (steps * m * 2 + (1 if hdr else 0)) * FRAG_FLOATS
+            assert fl <= SEG_CAP_FLOATS, (name, fl)
+            segs.append((name, first, steps, m, off, fl, hdr))
+            off += fl
+            first += steps
+    fl = ((TAIL_FLOATS + 255) // 256) * 256
+    segs.append(("tail", 0, 0, 0, off, fl, False))
+    return segs, off + fl
+
+
+def f16_weight_exponent(w):
+    """ew such that max|w| * 2^ew is in [2^(F16_TARGET_EXP-1), 2^F16_TARGET_EXP)  (0 for an all-zero tensor)."""
+    m = float(np.max(np.abs(w))) if w.size else 0.0
+    if m == 0.0 or not np.isfinite(m):
+        return 0
+    return int(F16_TARGET_EXP - np.frexp(np.float32(m))[1])
+
+
+def split_f16x2(x):
+    """fp32 -> (hi, lo) fp16 with hi + lo ~= x to 22 bits (round to nearest; the residual is exact in fp32)."""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def _fragments_h(weight, cols, nmb, ew):
+    """float16 [T, nmb, 2, 64, 8]: (hi, lo) parts of 2^ew * W[32m + lane%32, cols[t, lane//32, j]]."""
+    n_out, n_in = weight.shape
+    ext = np.zeros((nmb * 32, n_in + 1), np.float32)
+    ext[:n_out, :n_in] = np.ldexp(weight.astype(np.float32), ew)
+    cols = np.where(cols < 0, n_in, cols)
+    t_n = cols.shape[0]
+    lane = np.arange(64)
+    col = cols[:, lane >> 5, :]
+    row = (lane & 31)[None, None, :, None] + 32 * np.arange(nmb)[None, :, None, None]
+    w = ext[np.broadcast_to(row, (t_n, nmb, 64, 8)), np.broadcast_to(col[:, None], (t_n, nmb, 64, 8))]
+    return np.stack(split_f16x2(w), 2)
+
+
+def pack_wstream_h(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_dec."):
+    """state_dict -> (wstream as float32 words [total], cond_dim, cond_stride) in the split-fp16 format."""
+
+    def g(name):
+        v = sd[prefix + name]
+        return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
+
+    cond_dim = int(sum(cos_n_group)) + 4 * n_views
+    cond_stride = ((cond_dim + 1 + 7) // 8) * 8
+    d_enc = 3 + 6 * L_3D
+    tf = (cond_dim + 15) // 16
+    film_cols = np.arange(16 * tf).reshape(tf, 2, 8)
+    film_cols = np.where(film_cols < cond_dim, film_cols, ZERO)
+    e_cols = _enc_cols16(L_3D, legacy)
+    h_cols = _reg_cols16(4)
+    w5 = g("pts_linears.5.weight")
+    assert w5.shape[1] == d_enc + 128, "decoder.skip must be [4] with net_width 128"
+    ew5 = f16_weight_exponent(w5)  # one tensor, one accumulator: both parts share the scale
+    dir_cols = np.full((1, 2, 8), ZERO, np.int64)
+    dir_cols[0, 0, :3] = [128, 129, 130]
+    stages = {
+        "film": (g("pts_bias.weight"), g("pts_bias.bias"), film_cols, None),
+        "l0": (g("pts_linears.0.weight"), g("pts_linears.0.bias"), e_cols, None),
+        "l5e": (w5[:, :d_enc], g("pts_linears.5.bias"), e_cols, ew5),
+        "l5h": (w5[:, d_enc:], None, h_cols, ew5),
+        "feature": (g("feature_linear.weight"), g("feature_linear.bias"), h_cols, None),
+        "views": (g("views_linears.0.weight"), g("views_linears.0.bias"), np.concatenate([h_cols, dir_cols], 0), None),
+        "rgb": (g("rgb_linear.weight"), g("rgb_linear.bias"), _reg_cols16(2), None),
+        "alpha": (g("alpha_linear.0.weight"), g("alpha_linear.0.bias"), h_cols, None),
+    }
+    for i in range(1, 5):
+        stages[f"l{i}"] = (g(f"pts_linears.{i}.weight"), g(f"pts_linears.{i}.bias"), h_cols, None)
+    segs, total = decoder_schedule_h(cond_dim, L_3D)
+    f32_tail = pack_wstream(sd, n_views, cos_n_group, L_3D, legacy, prefix)[0][-((TAIL_FLOATS + 255) // 256) * 256:]
+    out = np.zeros(total, np.float32)
+    out16 = out.view(np.float16)
+    frag_cache = {}
+    for name, first, steps, m, off, fl, hdr in segs:
+        if name == "tail":
+            out[off:off + fl] = f32_tail
+            continue
+        w, b, cols, ew = stages[name]
+        if ew is None:
+            ew = f16_weight_exponent(w)
+        if name not in frag_cache:
+            frag_cache[name] = _fragments_h(w, cols, m, ew)
+        if hdr:
+            out[off:off + 128] = _bias_fragment(b, m)[:128]
+            out[off + 128] = np.ldexp(np.float32(1.0), -ew)
+            off += FRAG_FLOATS
+        a = frag_cache[name][first:first + steps]
+        out16[2 * off:2 * off + a.size] = a.reshape(-1)
+    return out, cond_dim, cond_stride
+
+
+WSTREAM_FORMATS = {"f32": 0, "bf16x6": 1, "f16x3": 2}
+
+
 def decoder_math():
-    """Matrix arithmetic of the fused decoder: 'bf16x6' (default; fp32 via 3-way bf16 operand split on the
-    bf16 matrix cores) or 'f32' (exact-f32 MFMA), chosen with MNERF_DECODER_MATH."""
+    """Matrix arithmetic of the fused decoder, chosen with MNERF_DECODER_MATH:
+    'f16x3' (default) fp32 operands as two range-managed fp16 terms, three products per MAC on the fp16 MFMA;
+    'bf16x6' fp32 operands as three bf16 terms, six products per MAC (strict: error of an fp32 FMA chain);
+    'f32' the exact-f32 MFMA."""
     import os
-    m = os.environ.get("MNERF_DECODER_MATH", "bf16x6")
-    if m not in ("bf16x6", "f32"):
-        raise ValueError(f"MNERF_DECODER_MATH={m!r}: expected 'bf16x6' or 'f32'")
+    m = os.environ.get("MNERF_DECODER_MATH", "f16x3")
+    if m not in WSTREAM_FORMATS:
+        raise ValueError(f"MNERF_DECODER_MATH={m!r}: expected one of {sorted(WSTREAM_FORMATS)}")
     return m
+
+
+def pack_for_math(math):
+    return {"f32": pack_wstream, "bf16x6": pack_wstream16, "f16x3": pack_wstream_h}[math]
 
 
 def raytrans_table(n_samples, d_hid=16):
@@ -411,8 +559,9 @@ class _RayAttentionParams(nn.Module):
 
 class CondNeRF(nn.Module):
     """Same constructor contract and parameter names as the reference's CondNeRF
-    (cond_nerf.py:11-50).  ``forward`` is not an eager op chain here: use
-    ``MatchNeRF.render`` (fused HIP path).  ``composite`` keeps the reference signature
+    (cond_nerf.py:11-50).  ``forward`` keeps the reference signature and runs the fused HIP decoder on
+    caller-supplied sample coordinates (``mnerf_decoder_samples``); ``MatchNeRF.render`` uses the ray-chunk form
+    that also rebuilds the rays and composites in-kernel.  ``composite`` keeps the reference signature
     (nerf.py:101) and runs the K5 HIP kernel."""
 
     def __init__(self, opt):
@@ -459,34 +608,84 @@ class CondNeRF(nn.Module):
         return (ver, ptr, n_samples, bool(self.opt.decoder.raytrans_posenc), bool(self.opt.nerf.legacy_coord),
                 decoder_math())
 
+    def math_for(self, n_samples):
+        """the matrix path the kernel will run for S samples per ray: the 8-wave kernel for S > 128 is built for the
+        exact-f32 stream only"""
+        return decoder_math() if n_samples <= 128 else "f32"
+
     def packed(self, n_samples, device):
         """(wstream, small, cond_stride, wstream_format) for the HIP kernel; re-packed when any
         parameter changed (load_state_dict / optimizer step), S or MNERF_DECODER_MATH changed."""
         key = self._pack_key(n_samples)
         if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
             sd = {"nerf_dec." + k: v for k, v in self.state_dict().items()}
-            # the 8-wave kernel for S > 128 (128 VGPRs per wave) is built for the f32 stream only
-            fmt = 1 if (decoder_math() == "bf16x6" and n_samples <= 128) else 0
-            pack = pack_wstream16 if fmt == 1 else pack_wstream
-            ws, cond_dim, cond_stride = pack(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
-                                             self.L_3D, bool(self.opt.nerf.legacy_coord))
+            math = self.math_for(n_samples)
+            ws, cond_dim, cond_stride = pack_for_math(math)(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
+                                                            self.L_3D, bool(self.opt.nerf.legacy_coord))
             assert cond_dim == self.cond_dim
+            limit = 64 if math == "f32" else 96  # MNERF_COND_STRIDE_MAX_F32 / MNERF_COND_STRIDE_MAX
+            if cond_stride > limit:
+                raise NotImplementedError(
+                    f"cond_dim={cond_dim} (n_src_views={self.opt.n_src_views}) needs {cond_stride} floats per sample; "
+                    f"the {math} decoder stream supports {limit}")
             small = pack_small(sd, n_samples, bool(self.opt.decoder.raytrans_posenc))
-            self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride, fmt)
+            self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride,
+                            WSTREAM_FORMATS[math])
         return self._packed[1], self._packed[2], self._packed[3], self._packed[4]
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "CondNeRF is evaluated by the fused HIP ray-chunk kernel (mnerf_render_chunk); "
-            "call MatchNeRF.render / MatchNeRF.forward instead of CondNeRF.forward")
+    def decoder_struct(self, n_samples, device, setbg_opaque=False):
+        """C-ABI ``mnerf_decoder`` for S samples per ray (the packed tensors stay cached on the module)."""
+        from . import hip
+        ws, small, cond_stride, wfmt = self.packed(n_samples, device)
+        d = hip.Decoder()
+        d.wstream, d.wstream_floats, d.small_ = ws.data_ptr(), ws.numel(), small.data_ptr()
+        d.n_views, d.cond_dim, d.cond_stride = self.opt.n_src_views, self.cond_dim, cond_stride
+        d.wstream_format = wfmt
+        d.L_3D = self.L_3D
+        dec, nerf = self.opt.decoder, self.opt.nerf
+        d.raytrans_posenc, d.raytrans_elu = int(bool(dec.raytrans_posenc)), int(dec.raytrans_act == "ELU")
+        d.density_maskfill, d.wo_render_interval = int(bool(dec.density_maskfill)), int(bool(nerf.wo_render_interval))
+        d.setbg_opaque = int(bool(setbg_opaque))
+        return d
+
+    def forward(self, opt, points_3D, ray_unit=None, cond_info=None, mode=None):
+        """cond_nerf.py:52-100 with the reference's signature: points_3D [B,R,S,3] (coordinates w.r.t. source view
+        0), ray_unit [B,R,S,3] (or [B,R,3]), cond_info = dict(feat_info, color_info, mask_info) [B,R,S,*]
+        -> rgb [B,R,S,3], density [B,R,S].  One launch of the fused HIP decoder per batch element
+        (mnerf_decoder_samples): no eager op chain, no autograd (training goes through MatchNeRF.render)."""
+        from . import hip
+        if ray_unit is None or cond_info is None:
+            raise ValueError("CondNeRF.forward needs ray_unit and cond_info (nerf.view_dep is always true here)")
+        if not points_3D.is_cuda:
+            raise RuntimeError("CondNeRF.forward: the HIP decoder needs CUDA tensors (no CPU fallback)")
+        b, r, s, _ = points_3D.shape
+        dev = points_3D.device
+        dec = self.decoder_struct(s, dev)
+        if ray_unit.dim() == 3:
+            ray_unit = ray_unit[:, :, None, :].expand(b, r, s, 3)
+        cond = torch.zeros(b, r * s, dec.cond_stride, device=dev)
+        c = torch.cat([cond_info["feat_info"], cond_info["color_info"], cond_info["mask_info"]], -1)
+        if c.shape[-1] != self.cond_dim:
+            raise ValueError(f"cond_info has {c.shape[-1]} channels, the decoder was built for {self.cond_dim}")
+        cond[..., :self.cond_dim] = c.reshape(b, r * s, self.cond_dim).float()
+        cond[..., self.cond_dim] = 1.0
+        rgb, sigma = [], []
+        with torch.no_grad():
+            for i in range(b):
+                o = hip.decoder_samples(dec, points_3D[i].float().contiguous(), ray_unit[i].float().contiguous(), cond[i],
+                                        legacy_coord=bool(opt.nerf.legacy_coord))
+                rgb.append(o[0])
+                sigma.append(o[1])
+        return torch.stack(rgb, 0), torch.stack(sigma, 0)
 
     def composite(self, opt, ray, rgb_samples, density_samples, depth_samples, setbg_opaque):
-        """nerf.py:101-124 with the reference signature; tensors [B,R,S,*] on the GPU."""
+        """nerf.py:101-124 with the reference signature; tensors [B,R,S,*] on the GPU -> rgb [B,R,3], depth [B,R,1],
+        opacity [B,R,1], prob [B,R,S,1]."""
         from . import hip
         b, r, s = density_samples.shape
         ray_len = None if opt.nerf.wo_render_interval else ray.norm(dim=-1).reshape(b * r).contiguous()
-        rgb, depth, opacity = hip.composite(
+        rgb, depth, opacity, prob = hip.composite(
             rgb_samples.reshape(b * r, s, 3).contiguous(), density_samples.reshape(b * r, s).contiguous(),
             depth_samples.reshape(b * r, s).contiguous(), ray_len,
-            wo_render_interval=bool(opt.nerf.wo_render_interval), setbg_opaque=bool(setbg_opaque))
-        return rgb.reshape(b, r, 3), depth.reshape(b, r, 1), opacity.reshape(b, r, 1), None
+            wo_render_interval=bool(opt.nerf.wo_render_interval), setbg_opaque=bool(setbg_opaque), want_prob=True)
+        return rgb.reshape(b, r, 3), depth.reshape(b, r, 1), opacity.reshape(b, r, 1), prob.reshape(b, r, s, 1)

@@ -1,8 +1,9 @@
 // libmnerf_hip.so — error channel and ABI version (see include/mnerf.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
-#include "../../include/mnerf.h"
+#include "common.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -26,4 +27,33 @@ extern "C" int64_t mnerf_struct_size(int32_t which) {
     case 3: return (int64_t)sizeof(mnerf_decoder);
     default: return -1;
   }
+}
+
+// ---- debug / tuning knobs: the environment is read ONCE, when the library is loaded (a static initialiser), into a
+// table that is read-only from then on.  Nothing in a launch path calls getenv or keeps mutable state; the only
+// per-process bookkeeping left is "has this kernel's LDS attribute been set on this device" (mnerf_once_per_device).
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+static mnerf_tuning read_tuning() {
+  mnerf_tuning t;
+  t.decoder_grid = env_int("MNERF_DECODER_GRID", 512);          // persistent: 2 workgroups per CU x 256 CUs
+  t.decoder_stagger = env_int("MNERF_DECODER_STAGGER", 16);     // ~130k cycles ~ half a tile
+  t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
+  t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = plain
+  t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
+  t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
+  return t;
+}
+
+static const mnerf_tuning g_tuning = read_tuning();
+const mnerf_tuning& mnerf_tune() { return g_tuning; }
+
+bool mnerf_once_per_device(std::atomic<unsigned long long>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
 }

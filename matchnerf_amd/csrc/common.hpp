@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/mnerf.h"
 
 // ------------------------------------------------------------------ host: error channel
@@ -27,6 +29,18 @@ static inline int mnerf_check_launch(const char* what) {
 }
 
 static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ------------------------------------------------------------------ host: tuning table, per-device set-up
+// Debug / tuning knobs (MNERF_DECODER_GRID, MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID,
+// MNERF_WA_MIN4): read from the environment once at library load (api.cpp), constant afterwards.
+struct mnerf_tuning {
+  int decoder_grid, decoder_stagger, decoder_stagger_mode;
+  int cv_variant, cv_grid;
+  int wa_min4;
+};
+const mnerf_tuning& mnerf_tune();
+// true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device
+bool mnerf_once_per_device(std::atomic<unsigned long long>& mask);
 
 // ------------------------------------------------------------------ device: geometry
 // The positional encoding multiplies the projected coordinate by up to 2^9 (x pi), so a

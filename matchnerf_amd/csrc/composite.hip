@@ -30,7 +30,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void composite_kernel(
     int n_rays, int S, const float* __restrict__ rgb_s, const float* __restrict__ sigma,
     const float* __restrict__ depth_s, const float* __restrict__ ray_len, int wo_interval,
-    int setbg, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ opacity) {
+    int setbg, float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ opacity,
+    float* __restrict__ prob) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
       if (lane == 0) prev = 0.f;
       const float excl = carry + wave_incl_scan(prev, lane);
       const float w = ok ? expf(-excl) * (1.0f - expf(-sd)) : 0.f;
+      if (prob && ok) prob[base + j] = w;
       acc_r += w * cr;
       acc_g += w * cg;
       acc_b += w * cb;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void composite_kernel(
 extern "C" int mnerf_composite(int32_t n_rays, int32_t n_samples, const float* rgb_s,
                                const float* sigma, const float* depth_s, const float* ray_len,
                                int32_t wo_render_interval, int32_t setbg_opaque, float* rgb,
-                               float* depth, float* opacity, void* stream) {
+                               float* depth, float* opacity, float* prob, void* stream) {
   MNERF_REQUIRE(n_rays >= 0 && n_samples >= 1, MNERF_E_RANGE,
                 "mnerf_composite: n_rays=%d n_samples=%d", n_rays, n_samples);
   if (n_rays == 0) return MNERF_OK;  // empty chunk: nothing to read or write
@@ -97,6 +99,6 @@ extern "C" int mnerf_composite(int32_t n_rays, int32_t n_samples, const float* r
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(composite_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays,
                      n_samples, rgb_s, sigma, depth_s, ray_len, wo_render_interval, setbg_opaque,
-                     rgb, depth, opacity);
+                     rgb, depth, opacity, prob);
   return mnerf_check_launch("mnerf_composite");
 }

@@ -587,24 +587,28 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
   if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
-  int variant = 3;  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = one sample per slot iteration
-  if (const char* e = getenv("MNERF_CV_VARIANT")) variant = atoi(e);
+  int variant = mnerf_tune().cv_variant;  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = one sample per slot iteration
+  if (variant != 3 && variant != 4) variant = 0;
   if (sumG > CVW_CS_MAX) variant = 0;
   if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
     const int nslot = variant == 4 ? 32 : 16;
     const size_t lds = (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + ((sumG + 3) & ~3)) * sizeof(float);
     MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
-    static size_t lean_lds_set[2] = {0, 0};
-    if (lds > lean_lds_set[variant - 3]) {
+    // the LDS attribute is per device and only ever raised: largest request seen per (variant, device)
+    static std::atomic<int> lean_lds_set[2][64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int>& seen = lean_lds_set[variant - 3][dev & 63];
+    if ((int)lds > seen.load(std::memory_order_relaxed)) {
       if (variant == 4)
         (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       else
         (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      lean_lds_set[variant - 3] = lds;
+      seen.store((int)lds, std::memory_order_relaxed);
     }
     long long wgs = ((long long)rays->n_rays + nslot - 1) / nslot;
     int cap = variant == 4 ? 2048 : 4096;
-    if (const char* e = getenv("MNERF_CV_GRID")) cap = atoi(e);
+    if (mnerf_tune().cv_grid > 0) cap = mnerf_tune().cv_grid;
     if (wgs > cap) wgs = cap;
     if (variant == 4)
       hipLaunchKernelGGL(cost_volume_lean_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,

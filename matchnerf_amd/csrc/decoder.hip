@@ -343,6 +343,127 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
 }
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
 
+
+// ---------------------------------------------------------------- split-fp16 matrix path ("f16x3", FMT = 2)
+// Same chain on v_mfma_f32_32x32x16_f16 with TWO fp16 terms per operand and THREE products per MAC
+// (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is < 2^-22 of the product): half the matrix instructions of
+// bf16x6 and about half its operand-split VALU work (gfx950 has v_cvt_pk_f16_f32; the residual is one
+// v_pk_fma_f32 per pair).  fp16 has 11 significand bits but a 5-bit exponent, so both operands are range-managed
+// with exact power-of-two scales (cond_nerf.py: pack_wstream_h): weights carry one scale 2^ew per tensor (host),
+// activations one gain per SAMPLE and stage, taken from the running maximum of the sample's features (in-lane
+// max + one cross-half shuffle) so that the largest operand lands in [2^14, 2^15).  The accumulator then holds
+// 2^(ew+eg) (W x); scales are tracked as integer exponents per lane and multiplied back in exactly.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define H16_UNIT_BYTES 2048  // one (step, block): hi | lo fragments
+#define H16_TARGET_EXP 15    // largest operand of a sample is scaled into [2^14, 2^15)
+
+struct PartsH {
+  f16x8 hi, lo;
+};
+
+// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual
+__device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
+  u32x4 H, L;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i] * mult, b = v[2 * i + 1] * mult;
+    const f32x2 ab = {a, b};
+    const f16x2 h = __builtin_convertvector(ab, f16x2);  // v_cvt_pk_f16_f32
+    const f32x2 r = {a - (float)h[0], b - (float)h[1]};
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    H[i] = __builtin_bit_cast(unsigned, h);
+    L[i] = __builtin_bit_cast(unsigned, l);
+  }
+  PartsH p;
+  p.hi = __builtin_bit_cast(f16x8, H);
+  p.lo = __builtin_bit_cast(f16x8, L);
+  return p;
+}
+
+__device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// exponent em with 2^em * m in [2^14, 2^15) (m > 0; clamped so that every scale stays a normal fp32 number)
+__device__ __forceinline__ int gain_exp(float m) {
+  int e = __builtin_amdgcn_frexp_expf(m);  // m = f 2^e, f in [0.5, 1); 0 for m = 0 / inf / nan
+  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  return H16_TARGET_EXP - e;
+}
+__device__ __forceinline__ float pow2i(int e) { return ldexpf(1.0f, e); }
+
+typedef const float __attribute__((address_space(3)))* lds_f32_cptr;
+// stage header (1 KiB): floats [0,128) bias in accumulator order, [128] 2^-ew, [129] (float)ew
+__device__ __forceinline__ int header_ew(unsigned frag_lds) {
+  return __builtin_amdgcn_readfirstlane((int)((lds_f32_cptr)(size_t)frag_lds)[129]);
+}
+
+// accumulators <- bias * bmult (bmult = 2^(ew + operand-gain exponent): the accumulator's scale)
+template <int NMB>
+__device__ __forceinline__ void bias_init_h(f32x16 (&acc)[NMB], unsigned frag_lds, int hl, float bmult) {
+  lds_v4f32_cptr p = (lds_v4f32_cptr)(size_t)frag_lds + hl * 16;
+#pragma unroll
+  for (int m = 0; m < NMB; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const v4f32 t = p[m * 4 + q];
+      acc[m][4 * q] = t.x * bmult;
+      acc[m][4 * q + 1] = t.y * bmult;
+      acc[m][4 * q + 2] = t.z * bmult;
+      acc[m][4 * q + 3] = t.w * bmult;
+    }
+}
+
+// NS K16-steps against NMB output blocks; v: the lane's 8*NS operand values, mult: their power-of-two gain.
+// A fragments of unit (step, block) i+1 are read before the three MFMAs of unit i.
+template <int NMB, int NS>
+__device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const float (&v)[8 * NS],
+                                         float mult) {
+  lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
+  u32x4 ch = a[0], cl = a[64];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    float vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] = v[8 * u + j];
+    const PartsH b = split8h(vv, mult);
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) {
+      const int i = u * NMB + m;
+      const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;  // the last unit re-reads itself
+      const u32x4 nh = a[nx], nl = a[nx + 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
+      acc[m] = mfma16h(ah, b.lo, acc[m]);
+      acc[m] = mfma16h(al, b.hi, acc[m]);
+      acc[m] = mfma16h(ah, b.hi, acc[m]);
+      __builtin_amdgcn_sched_barrier(0);
+      ch = nh;
+      cl = nl;
+    }
+  }
+}
+
+template <int NMB>
+__device__ __forceinline__ void kblock_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const f32x16& h, float mult) {
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = h[r];
+  ksteps_h<NMB, 2>(acc, base_lds, lane, v, mult);
+}
+
+// largest |value| of a sample's features held in NB accumulator blocks of its two lanes
+template <int NB>
+__device__ __forceinline__ float sample_absmax(const f32x16 (&a)[NB]) {
+  float mx = 0.0f;
+#pragma unroll
+  for (int m = 0; m < NB; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(a[m][r]));
+  return fmaxf(mx, __shfl_xor(mx, 32, 64));
+}
+
 template <int NW, int SP>
 struct Smem {
   static constexpr int TILE = NW * 32;
@@ -362,7 +483,8 @@ template <int NW, int SP, int FMT>
 __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     mnerf_decoder D, DecSched sch, mnerf_view view0, mnerf_rays R,
     const float* __restrict__ cond, float* __restrict__ out_rgb, float* __restrict__ out_depth,
-    float* __restrict__ out_opacity, float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma) {
+    float* __restrict__ out_opacity, float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma,
+    const float* __restrict__ ext_ndc, const float* __restrict__ ext_dir) {
   constexpr int Sp = SP;
   using SM = Smem<NW, SP>;
   constexpr int TILE = SM::TILE;
@@ -420,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     int r = t * rays_per_tile + r_t;
     if (r >= R.n_rays) r = R.n_rays - 1;
     const size_t g_s = (size_t)r * S + (j_p < S ? j_p : (S - 1));
-    if constexpr (FMT == 1) {  // K16 steps 0,1: cond[16 t + 8 hl + 4 q .. +4), q = i & 1, t = i >> 1
+    if constexpr (FMT >= 1) {  // K16 steps 0,1: cond[16 t + 8 hl + 4 q .. +4), q = i & 1, t = i >> 1
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
@@ -466,20 +588,29 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     const int j = jp < S ? jp : (S - 1);            // padded slots recompute the last sample
     const size_t gs = (size_t)ray * S + j;          // global sample index
 
-    const RayGeom g = make_ray(R, ray);
-    const float dpt = sample_depth(R, ray, j);
-    float x, y, z;
-    {
+    float x, y, z, dx, dy, dz;
+    if (ext_ndc) {
+      // mnerf_decoder_samples: the caller supplies the decoder inputs of CondNeRF.forward (cond_nerf.py:52) —
+      // sample coordinates w.r.t. source view 0 and the (already rotated) unit view direction per sample
+      x = ext_ndc[gs * 3 + 0];
+      y = ext_ndc[gs * 3 + 1];
+      z = ext_ndc[gs * 3 + 2];
+      dx = ext_dir[gs * 3 + 0];
+      dy = ext_dir[gs * 3 + 1];
+      dz = ext_dir[gs * 3 + 2];
+    } else {
+      const RayGeom g = make_ray(R, ray);
+      const float dpt = sample_depth(R, ray, j);
       float wx_, wy_, wz_;
       ray_point(g, dpt, wx_, wy_, wz_);
       project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
+      // view direction in the frame of source view 0 (matchnerf.py:129-131)
+      const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
+      const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
+      dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
+      dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
+      dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
     }
-    // view direction in the frame of source view 0 (matchnerf.py:129-131)
-    const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
-    const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
-    const float dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
-    const float dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
-    const float dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
 
     load_tile_inputs(tile);  // issued before the geometry below is consumed: latency overlaps it
     const bool q_valid = n_valid > 1.0f;
@@ -515,7 +646,236 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 
     TL_STAMP(1);
     float av[8];  // alpha-head activations: rows 0..15 <-> registers 0..7, feature (r&3) + 8*(r>>2) + 4*hl
-    if constexpr (FMT == 1) {
+    if constexpr (FMT == 2) {
+      // ============================================================ trunk, split-fp16 matrix path
+      // Scale bookkeeping: register values carry an integer exponent per lane (the same in the two lanes of a
+      // sample): true value = register * 2^ec.  A stage picks the operand gain 2^em from the sample's largest
+      // operand, the accumulator then holds 2^(ew + em - ec) (W h_true + b), i.e. its exponent is ec - em - ew.
+      unsigned wb;
+#define CUR_LDS ((seg & 1) ? wbuf1_lds : wbuf0_lds)
+      // ------------------------------------------------------------ FiLM = pts_bias(cond); inputs in [-1, 1]
+      f32x16 film[4];
+      int ecf = 0;  // film_true = film * 2^ecf (never multiplied out: it rides in the exponent of each layer)
+      {
+        int done = 0;
+        while (done < sch.film_steps) {
+          const int ns = sch.seg_steps[seg];
+          SEG_BEGIN();
+          wb = CUR_LDS;
+          if (done == 0) {
+            const int ew = header_ew(CUR_LDS);
+            ecf = -(ew + (H16_TARGET_EXP - 1));
+            bias_init_h<4>(film, CUR_LDS, hl, pow2i(ew + (H16_TARGET_EXP - 1)));
+            wb += 1024;
+          }
+          for (int u = 0; u < ns; ++u) {
+            const int t = done + u;
+            float v[8];
+            float4 c0, c1;
+            if (t == 0) {
+              c0 = cpre[0];
+              c1 = cpre[1];
+            } else if (t == 1) {
+              c0 = cpre[2];
+              c1 = cpre[3];
+            } else {  // more than 32 conditioning inputs (n_src_views > 5): straight from global
+              const int o = 16 * t + 8 * hl;
+              const float* crow = cond + gs * CS;
+              c0 = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+              c1 = (o + 8 <= CS) ? *reinterpret_cast<const float4*>(crow + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w;
+            v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+            ksteps_h<4, 1>(film, wb + u * 4 * H16_UNIT_BYTES, lane, v, (float)(1 << (H16_TARGET_EXP - 1)));
+          }
+          done += ns;
+          SEG_END();
+        }
+      }
+      TL_STAMP(2);
+      // ------------------------------------------------------------ positional-encoding stages (L0, L5)
+      f32x16 acc[4], h[4];
+      const float enc_max = fmaxf(fmaxf(1.0f, fabsf(x)), fmaxf(fabsf(y), fabsf(z)));  // sin / cos <= 1; raw x, y, z
+      int ew_cur = 0;
+      // acc (+)= W_enc . enc(x) with operand gain 2^em; the first call of a stage loads bias * 2^(ew + em)
+      auto enc_stage = [&](int em) {
+        const float mult = pow2i(em);
+        if (sch.enc_steps == 4) {  // L_3D = 10: one segment of four K16-steps, register-fed in two halves
+          SEG_BEGIN();
+          ew_cur = header_ew(CUR_LDS);
+          bias_init_h<4>(acc, CUR_LDS, hl, pow2i(ew_cur + em));
+          {
+            const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
+            kblock_h<4>(acc, CUR_LDS + 1024, lane, e0, mult);
+          }
+          {
+            const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+            kblock_h<4>(acc, CUR_LDS + 1024 + 8 * H16_UNIT_BYTES, lane, e1, mult);
+          }
+          SEG_END();
+        } else {
+          int done = 0;
+          while (done < sch.enc_steps) {
+            const int ns = sch.seg_steps[seg];
+            SEG_BEGIN();
+            wb = CUR_LDS;
+            if (done == 0) {
+              ew_cur = header_ew(CUR_LDS);
+              bias_init_h<4>(acc, CUR_LDS, hl, pow2i(ew_cur + em));
+              wb += 1024;
+            }
+            for (int u = 0; u < ns; ++u) {
+              float v[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = enc_operand(8 * (done + u) + j, L3, hl, x, y, z, freq_mul);
+              ksteps_h<4, 1>(acc, wb + u * 4 * H16_UNIT_BYTES, lane, v, mult);
+            }
+            done += ns;
+            SEG_END();
+          }
+        }
+      };
+      // acc (+)= W . h with register gain `mult`; with a header: acc <- bias * 2^bexp first (bexp - ew given)
+      auto hidden_stage = [&](bool with_hdr, float mult, int bexp_minus_ew) {
+#pragma unroll
+        for (int sgi = 0; sgi < 2; ++sgi) {
+          SEG_BEGIN();
+          wb = CUR_LDS;
+          if (sgi == 0 && with_hdr) {
+            ew_cur = header_ew(CUR_LDS);
+            bias_init_h<4>(acc, CUR_LDS, hl, pow2i(ew_cur + bexp_minus_ew));
+            wb += 1024;
+          }
+          kblock_h<4>(acc, wb, lane, h[2 * sgi], mult);
+          kblock_h<4>(acc, wb + 8 * H16_UNIT_BYTES, lane, h[2 * sgi + 1], mult);
+          SEG_END();
+        }
+      };
+      // h <- max(acc * film, 0); returns the sample's largest new activation (register units)
+      auto film_relu = [&]() -> float {
+        float mx = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float t = fmaxf(acc[m][r] * film[m][r], 0.0f);
+            h[m][r] = t;
+            mx = fmaxf(mx, t);
+          }
+        return fmaxf(mx, __shfl_xor(mx, 32, 64));
+      };
+      int ec;  // exponent of the values in h
+      {
+        const int em = gain_exp(enc_max);
+        enc_stage(em);
+        ec = -em - ew_cur + ecf;
+      }
+      float hmax = film_relu();
+      TL_STAMP(3);
+      // ------------------------------------------------------------ layers 1..4: 128 -> 128
+      for (int layer = 1; layer <= 4; ++layer) {
+        const int em = gain_exp(hmax);
+        hidden_stage(true, pow2i(em), em - ec);
+        ec = ec - em - ew_cur + ecf;
+        hmax = film_relu();
+      }
+      TL_STAMP(4);
+      // ------------------------------------------------------------ layer 5: [enc, h] -> 128, one accumulator:
+      // both operand sets share one TRUE gain 2^eg, from the larger of the two maxima
+      {
+        const int eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
+        enc_stage(eg);
+        hidden_stage(false, pow2i(eg + ec), 0);
+        ec = -eg - ew_cur + ecf;
+        hmax = film_relu();
+      }
+      // ------------------------------------------------------------ alpha head: 128 -> 16 (its activations wait in 8 registers for the ray transformer)
+      const int em5 = gain_exp(hmax);
+      const float mult5 = pow2i(em5);
+      {
+        f32x16 al[1];
+        SEG_BEGIN();
+        wb = CUR_LDS + 1024;
+        const int ew = header_ew(CUR_LDS);
+        bias_init_h<1>(al, CUR_LDS, hl, pow2i(ew + em5 - ec));
+        const float ca = pow2i(ec - em5 - ew);
+#pragma unroll
+        for (int sgi = 0; sgi < 4; ++sgi) kblock_h<1>(al, wb + sgi * 2 * H16_UNIT_BYTES, lane, h[sgi], mult5);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = al[0][r] * ca;
+          t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+          av[r] = t;
+        }
+        if (D.raytrans_posenc) {
+          const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
+        }
+        SEG_END();
+      }
+      TL_STAMP(5);
+      // ------------------------------------------------------------ feature_linear: 128 -> 128 (no activation)
+      hidden_stage(true, mult5, em5 - ec);
+      const int ecfeat = ec - em5 - ew_cur;
+      TL_STAMP(6);
+      // ------------------------------------------------------------ views_linear: [feat, dir] -> 64
+      f32x16 hv[2];
+      int ecv;
+      {
+        const int eg = gain_exp(fmaxf(1.0f, sample_absmax<4>(acc) * pow2i(ecfeat)));  // |dir| <= 1
+        const float multf = pow2i(eg + ecfeat), multd = pow2i(eg);
+        SEG_BEGIN();
+        wb = CUR_LDS + 1024;
+        const int ew = header_ew(CUR_LDS);
+        bias_init_h<2>(hv, CUR_LDS, hl, pow2i(ew + eg));
+        kblock_h<2>(hv, wb, lane, acc[0], multf);
+        kblock_h<2>(hv, wb + 4 * H16_UNIT_BYTES, lane, acc[1], multf);
+        SEG_END();
+        SEG_BEGIN();
+        wb = CUR_LDS;
+        kblock_h<2>(hv, wb, lane, acc[2], multf);
+        kblock_h<2>(hv, wb + 4 * H16_UNIT_BYTES, lane, acc[3], multf);
+        const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        ksteps_h<2, 1>(hv, wb + 8 * H16_UNIT_BYTES, lane, v, multd);
+        SEG_END();
+        ecv = -eg - ew;
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[m][r] = fmaxf(hv[m][r], 0.0f);
+      TL_STAMP(7);
+      // ------------------------------------------------------------ rgb_linear: 64 -> 3, sigmoid
+      {
+        const int em = gain_exp(sample_absmax<2>(hv));
+        const float mult = pow2i(em);
+        f32x16 c3[1];
+        SEG_BEGIN();
+        wb = CUR_LDS + 1024;
+        const int ew = header_ew(CUR_LDS);
+        bias_init_h<1>(c3, CUR_LDS, hl, pow2i(ew + em - ecv));
+        const float cc = pow2i(ecv - em - ew);
+        kblock_h<1>(c3, wb, lane, hv[0], mult);
+        kblock_h<1>(c3, wb + 2 * H16_UNIT_BYTES, lane, hv[1], mult);
+        if (hl == 0) {
+          const float cr = 1.0f / (1.0f + expf(-c3[0][0] * cc));
+          const float cg = 1.0f / (1.0f + expf(-c3[0][1] * cc));
+          const float cb = 1.0f / (1.0f + expf(-c3[0][2] * cc));
+          rs_lds[s_local * 4 + 0] = cr;
+          rs_lds[s_local * 4 + 1] = cg;
+          rs_lds[s_local * 4 + 2] = cb;
+          if (dbg_rgb_s && ray_ok && jp < S) {
+            dbg_rgb_s[gs * 3 + 0] = cr;
+            dbg_rgb_s[gs * 3 + 1] = cg;
+            dbg_rgb_s[gs * 3 + 2] = cb;
+          }
+        }
+        SEG_END();
+      }
+      TL_STAMP(8);
+#undef CUR_LDS
+    } else if constexpr (FMT == 1) {
       // ============================================================ trunk, split-bf16 matrix path
       unsigned wb;  // LDS byte cursor inside the current weight segment
 #define CUR_LDS ((seg & 1) ? wbuf1_lds : wbuf0_lds)
@@ -1135,7 +1495,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // ============================================================ compositing (K5)
     for (int rt = wave; rt < rays_per_tile; rt += NW) {
       const int rr = tile * rays_per_tile + rt;
-      if (rr >= R.n_rays) continue;  // wave-uniform
+      if (rr >= R.n_rays || !out_rgb) continue;  // wave-uniform (no compositing in the per-sample entry point)
       float rlen = 1.0f;
       if (!D.wo_render_interval) {
         const RayGeom gg = make_ray(R, rr);
@@ -1204,61 +1564,64 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 }
 
 // ------------------------------------------------------------------ host side
-// Segment schedule shared with the Python packer (matchnerf_amd/cond_nerf.py):
-// stages (steps, M-blocks) in consumption order; a stage is cut into ceil(T/cap) segments,
-// the first ones get floor(T/nseg) steps, the last one the rest; every segment is padded to
-// a multiple of 256 floats.
-static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
-  if (D->wstream_format == MNERF_WSTREAM_BF16X3) {
-    // mirror of cond_nerf.py:decoder_schedule16 — stages (blocks, K16-steps per segment, bias header)
-    const int tf = (D->cond_dim + 15) / 16, te = (3 * D->L_3D + 2 + 7) / 8;
-    int n = 0;
-    long long off = 0;
-    auto add = [&](int nmb, int steps, bool hdr) -> bool {
-      if (n >= MAX_SEGS) return false;
-      const int fl = (steps * nmb * 3 + (hdr ? 1 : 0)) * 256;
-      if (fl > SEG_CAP_FLOATS) return false;
-      sch->seg_off[n] = (int)off;
-      sch->seg_floats[n] = fl;
-      sch->seg_steps[n] = steps;
-      off += fl;
-      ++n;
-      return true;
-    };
-    auto add_pairs = [&](int t) -> bool {  // stage of 4 blocks cut into segments of two K16-steps
-      for (int k = 0; k < t; k += 2)
-        if (!add(4, (t - k) >= 2 ? 2 : 1, k == 0)) return false;
-      return true;
-    };
-    bool ok = add_pairs(tf) && add_pairs(te);
-    for (int l = 1; l <= 4 && ok; ++l)
-      for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);
-    ok = ok && add_pairs(te);
-    for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, false);  // l5h
-    ok = ok && add(1, 8, true);                                 // alpha
-    for (int k = 0; k < 4 && ok; ++k) ok = add(4, 2, k == 0);  // feature
-    ok = ok && add(2, 4, true) && add(2, 5, false);             // views
-    ok = ok && add(1, 4, true);                                 // rgb
-    if (!ok || n >= MAX_SEGS) return -1;
-    const int fl = ((TAIL_FLOATS + 255) / 256) * 256;
+// Segment schedules shared with the Python packers (matchnerf_amd/cond_nerf.py).
+static void finish_schedule(DecSched* sch, int n, int film_steps, int enc_steps) {
+  sch->n_seg = n;
+#ifdef MNERF_TIMELINE
+  sch->tl = nullptr;
+  if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+  sch->stagger_sleeps = mnerf_tune().decoder_stagger;  // ~130k cycles ~ half a tile
+  sch->stagger_mode = mnerf_tune().decoder_stagger_mode;
+  sch->film_steps = film_steps;
+  sch->enc_steps = enc_steps;
+}
+
+// split formats (bf16x3: PARTS = 3, fp16x2: PARTS = 2): stages (blocks, K16-steps per segment, header)
+static int build_schedule_split(const mnerf_decoder* D, DecSched* sch, int parts) {
+  const int tf = (D->cond_dim + 15) / 16, te = (3 * D->L_3D + 2 + 7) / 8;
+  const int per = parts == 3 ? 2 : 4;  // K16-steps per segment of a 4-block stage (<= 33 KiB with the header)
+  int n = 0;
+  long long off = 0;
+  auto add = [&](int nmb, int steps, bool hdr) -> bool {
+    if (n >= MAX_SEGS - 1) return false;
+    const int fl = (steps * nmb * parts + (hdr ? 1 : 0)) * 256;
+    if (fl > SEG_CAP_FLOATS) return false;
     sch->seg_off[n] = (int)off;
     sch->seg_floats[n] = fl;
-    sch->seg_steps[n] = 0;
+    sch->seg_steps[n] = steps;
     off += fl;
     ++n;
-    sch->n_seg = n;
-#ifdef MNERF_TIMELINE
-    sch->tl = nullptr;
-    if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
-#endif
-    sch->stagger_sleeps = 16;
-    if (const char* e = getenv("MNERF_DECODER_STAGGER")) sch->stagger_sleeps = atoi(e);
-    sch->stagger_mode = 0;
-    if (const char* e = getenv("MNERF_DECODER_STAGGER_MODE")) sch->stagger_mode = atoi(e);
-    sch->film_steps = tf;
-    sch->enc_steps = te;
-    return (int)off;
-  }
+    return true;
+  };
+  auto add_chunks = [&](int t, bool hdr) -> bool {  // stage of 4 blocks cut into segments of `per` K16-steps
+    for (int k = 0; k < t; k += per)
+      if (!add(4, (t - k) >= per ? per : (t - k), hdr && k == 0)) return false;
+    return true;
+  };
+  bool ok = add_chunks(tf, true) && add_chunks(te, true);
+  for (int l = 1; l <= 4 && ok; ++l) ok = add_chunks(8, true);
+  ok = ok && add_chunks(te, true) && add_chunks(8, false);  // l5e, l5h
+  ok = ok && add(1, 8, true);                               // alpha
+  ok = ok && add_chunks(8, true);                           // feature
+  ok = ok && add(2, 4, true) && add(2, 5, false);           // views
+  ok = ok && add(1, 4, true);                               // rgb
+  if (!ok) return -1;
+  const int fl = ((TAIL_FLOATS + 255) / 256) * 256;  // f32 tail: [w_qs;w_ks;w_vs | fc | out_alpha.0 | out_alpha.2]
+  sch->seg_off[n] = (int)off;
+  sch->seg_floats[n] = fl;
+  sch->seg_steps[n] = 0;
+  off += fl;
+  ++n;
+  finish_schedule(sch, n, tf, te);
+  return (int)off;
+}
+
+// f32 format: a stage is cut into ceil(T/cap) segments, the first ones get floor(T/nseg) steps, the last one the
+// rest; every segment is padded to a multiple of 256 floats.
+static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
+  if (D->wstream_format == MNERF_WSTREAM_BF16X3) return build_schedule_split(D, sch, 3);
+  if (D->wstream_format == MNERF_WSTREAM_F16X2) return build_schedule_split(D, sch, 2);
   const int fs = D->cond_stride / 2, es = 3 * D->L_3D + 2;
   // film, l0, l1..l4, l5-enc, l5-h, feature, views, rgb, alpha (+ the resident tail segment)
   const int T[12] = {fs, es, 65, 65, 65, 65, es, 64, 65, 66, 33, 65};
@@ -1290,23 +1653,17 @@ static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
     off += fl;
     ++n;
   }
-  sch->n_seg = n;
-#ifdef MNERF_TIMELINE
-  sch->tl = nullptr;
-  if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
-#endif
-  sch->stagger_sleeps = 16;  // ~130k cycles ~ half a tile (MNERF_DECODER_STAGGER overrides)
-  if (const char* e = getenv("MNERF_DECODER_STAGGER")) sch->stagger_sleeps = atoi(e);
-  sch->stagger_mode = 0;
-  if (const char* e = getenv("MNERF_DECODER_STAGGER_MODE")) sch->stagger_mode = atoi(e);
-  sch->film_steps = fs;
-  sch->enc_steps = es;
+  finish_schedule(sch, n, fs, es);
   return (int)off;
+}
+
+static bool known_format(int f) {
+  return f == MNERF_WSTREAM_F32 || f == MNERF_WSTREAM_BF16X3 || f == MNERF_WSTREAM_F16X2;
 }
 
 extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_stride, int32_t L_3D,
                                                 int32_t wstream_format) {
-  if (wstream_format != MNERF_WSTREAM_F32 && wstream_format != MNERF_WSTREAM_BF16X3) return -1;
+  if (!known_format(wstream_format)) return -1;
   if (L_3D < 0 || L_3D > 16 || cond_dim < 1 || cond_stride < cond_dim) return -1;
   mnerf_decoder d = {};
   d.cond_dim = cond_dim;
@@ -1325,63 +1682,55 @@ static int pick_padded_samples(int S) {
   return -1;
 }
 
-extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,
-                                   const mnerf_rays* rays, const float* cond, float* rgb,
-                                   float* depth, float* opacity, float* dbg_rgb_s,
-                                   float* dbg_sigma, void* stream) {
-  MNERF_REQUIRE(dec && view0 && rays, MNERF_E_NULL, "mnerf_decoder_chunk: NULL argument struct");
-  MNERF_REQUIRE(dec->wstream && dec->small_ && cond && rgb && depth && opacity, MNERF_E_NULL,
-                "mnerf_decoder_chunk: NULL buffer");
+// Shared by mnerf_decoder_chunk (rays rebuilt in-kernel, composited outputs) and mnerf_decoder_samples
+// (caller-supplied sample coordinates / directions, per-sample outputs only).
+static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf_view* view0, const mnerf_rays* rays,
+                          const float* cond, float* rgb, float* depth, float* opacity, float* rgb_s, float* sigma,
+                          const float* ext_ndc, const float* ext_dir, void* stream) {
+  MNERF_REQUIRE(dec->wstream && dec->small_ && cond, MNERF_E_NULL, "%s: NULL buffer", who);
   MNERF_REQUIRE(mnerf_aligned16(dec->wstream) && mnerf_aligned16(cond), MNERF_E_ALIGN,
-                "mnerf_decoder_chunk: wstream / cond must be 16-byte aligned");
-  MNERF_REQUIRE(dec->L_3D >= 0 && dec->L_3D <= 16, MNERF_E_RANGE, "mnerf_decoder_chunk: L_3D=%d",
-                dec->L_3D);
-  MNERF_REQUIRE(dec->cond_stride % 8 == 0 && dec->cond_stride >= dec->cond_dim + 1 &&
-                    dec->cond_stride <= 64,
-                MNERF_E_RANGE,
-                "mnerf_decoder_chunk: cond_stride=%d (cond_dim=%d) must be a multiple of 8 in (cond_dim, 64]",
-                dec->cond_stride, dec->cond_dim);
+                "%s: wstream / cond must be 16-byte aligned", who);
+  MNERF_REQUIRE(dec->L_3D >= 0 && dec->L_3D <= 16, MNERF_E_RANGE, "%s: L_3D=%d", who, dec->L_3D);
+  MNERF_REQUIRE(known_format(dec->wstream_format), MNERF_E_UNSUPPORTED, "%s: wstream_format=%d", who,
+                dec->wstream_format);
+  const int cs_max = dec->wstream_format == MNERF_WSTREAM_F32 ? MNERF_COND_STRIDE_MAX_F32 : MNERF_COND_STRIDE_MAX;
+  MNERF_REQUIRE(dec->cond_stride % 8 == 0 && dec->cond_stride >= dec->cond_dim + 1 && dec->cond_stride <= cs_max,
+                MNERF_E_RANGE, "%s: cond_stride=%d (cond_dim=%d) must be a multiple of 8 in (cond_dim, %d]", who,
+                dec->cond_stride, dec->cond_dim, cs_max);
   MNERF_REQUIRE(dec->n_views >= 1 && dec->n_views * 4 < dec->cond_dim, MNERF_E_RANGE,
-                "mnerf_decoder_chunk: n_views=%d inconsistent with cond_dim=%d", dec->n_views,
-                dec->cond_dim);
-  MNERF_REQUIRE(rays->n_rays >= 0 && rays->n_samples >= 1, MNERF_E_RANGE,
-                "mnerf_decoder_chunk: n_rays=%d S=%d", rays->n_rays, rays->n_samples);
-  MNERF_REQUIRE(rays->legacy_coord == 0 || rays->n_samples >= 2, MNERF_E_RANGE,
-                "mnerf_decoder_chunk: legacy depth sampling needs S >= 2");
-  MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32 || dec->wstream_format == MNERF_WSTREAM_BF16X3,
-                MNERF_E_UNSUPPORTED, "mnerf_decoder_chunk: wstream_format=%d", dec->wstream_format);
+                "%s: n_views=%d inconsistent with cond_dim=%d", who, dec->n_views, dec->cond_dim);
+  MNERF_REQUIRE(rays->n_rays >= 0 && rays->n_samples >= 1, MNERF_E_RANGE, "%s: n_rays=%d S=%d", who,
+                rays->n_rays, rays->n_samples);
   const int Sp = pick_padded_samples(rays->n_samples);
-  MNERF_REQUIRE(Sp > 0, MNERF_E_UNSUPPORTED,
-                "mnerf_decoder_chunk: sample_intvs=%d > 256 is not supported by the fused kernel",
+  MNERF_REQUIRE(Sp > 0, MNERF_E_UNSUPPORTED, "%s: sample_intvs=%d > 256 is not supported by the fused kernel", who,
                 rays->n_samples);
   DecSched sch;
   const int total = build_schedule(dec, &sch);
-  MNERF_REQUIRE(total > 0, MNERF_E_RANGE, "mnerf_decoder_chunk: cannot schedule weight stream");
-  MNERF_REQUIRE(dec->wstream_floats == total, MNERF_E_RANGE,
-                "mnerf_decoder_chunk: wstream has %lld floats, schedule expects %d",
+  MNERF_REQUIRE(total > 0, MNERF_E_RANGE, "%s: cannot schedule weight stream", who);
+  MNERF_REQUIRE(dec->wstream_floats == total, MNERF_E_RANGE, "%s: wstream has %lld floats, schedule expects %d", who,
                 (long long)dec->wstream_floats, total);
   if (rays->n_rays == 0) return MNERF_OK;
   hipStream_t st = (hipStream_t)stream;
-  int resident = 512;  // persistent: 2 workgroups per CU x 256 CUs
-  if (const char* e = getenv("MNERF_DECODER_GRID")) resident = atoi(e);
+  const int resident = mnerf_tune().decoder_grid;  // persistent: 2 workgroups per CU x 256 CUs
 #define MNERF_LAUNCH_DECODER(NW_, SP_, FMT_)                                                         \
   do {                                                                                               \
     const int rpt = (NW_ * 32) / SP_;                                                                \
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
     const int grid = tiles < resident ? tiles : resident;                                            \
     const size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                 \
-    static bool attr_set = false;                                                                    \
-    if (!attr_set) {                                                                                 \
+    static std::atomic<unsigned long long> attr_set{0};                                              \
+    if (mnerf_once_per_device(attr_set))                                                             \
       (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-      attr_set = true;                                                                               \
-    }                                                                                                \
     hipLaunchKernelGGL((decoder_kernel<NW_, SP_, FMT_>), dim3(grid), dim3(NW_ * 64), lds, st, *dec,  \
-                       sch, *view0, *rays, cond, rgb, depth, opacity, dbg_rgb_s, dbg_sigma);         \
+                       sch, *view0, *rays, cond, rgb, depth, opacity, rgb_s, sigma, ext_ndc,         \
+                       ext_dir);                                                                     \
   } while (0)
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_)                                   \
   do {                                                                       \
-    if (dec->wstream_format == MNERF_WSTREAM_BF16X3)                         \
+    if (dec->wstream_format == MNERF_WSTREAM_F16X2)                          \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 2);                                     \
+    else if (dec->wstream_format == MNERF_WSTREAM_BF16X3)                    \
       MNERF_LAUNCH_DECODER(NW_, SP_, 1);                                     \
     else                                                                     \
       MNERF_LAUNCH_DECODER(NW_, SP_, 0);                                     \
@@ -1392,11 +1741,38 @@ extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* v
     case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
     default:
       MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32, MNERF_E_UNSUPPORTED,
-                    "mnerf_decoder_chunk: sample_intvs=%d > 128 needs the MNERF_WSTREAM_F32 weight stream", rays->n_samples);
+                    "%s: sample_intvs=%d > 128 needs the MNERF_WSTREAM_F32 weight stream", who, rays->n_samples);
       MNERF_LAUNCH_DECODER(8, 256, 0);
       break;
   }
 #undef MNERF_LAUNCH_DECODER_FMT
 #undef MNERF_LAUNCH_DECODER
-  return mnerf_check_launch("mnerf_decoder_chunk");
+  return mnerf_check_launch(who);
+}
+
+extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,
+                                   const mnerf_rays* rays, const float* cond, float* rgb,
+                                   float* depth, float* opacity, float* dbg_rgb_s,
+                                   float* dbg_sigma, void* stream) {
+  MNERF_REQUIRE(dec && view0 && rays, MNERF_E_NULL, "mnerf_decoder_chunk: NULL argument struct");
+  MNERF_REQUIRE(rgb && depth && opacity, MNERF_E_NULL, "mnerf_decoder_chunk: NULL output buffer");
+  MNERF_REQUIRE(rays->legacy_coord == 0 || rays->n_samples >= 2, MNERF_E_RANGE,
+                "mnerf_decoder_chunk: legacy depth sampling needs S >= 2");
+  return launch_decoder("mnerf_decoder_chunk", dec, view0, rays, cond, rgb, depth, opacity, dbg_rgb_s, dbg_sigma,
+                        nullptr, nullptr, stream);
+}
+
+extern "C" int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, int32_t n_samples,
+                                     int32_t legacy_coord, const float* x_ndc, const float* dir,
+                                     const float* cond, float* rgb_s, float* sigma, void* stream) {
+  MNERF_REQUIRE(dec, MNERF_E_NULL, "mnerf_decoder_samples: dec is NULL");
+  MNERF_REQUIRE(x_ndc && dir && rgb_s && sigma, MNERF_E_NULL, "mnerf_decoder_samples: NULL buffer");
+  mnerf_rays rays = {};
+  rays.n_rays = n_rays;
+  rays.n_samples = n_samples;
+  rays.height = rays.width = 2;
+  rays.legacy_coord = legacy_coord ? 1 : 0;  // here it only selects the positional-encoding frequency factor (1 | pi)
+  const mnerf_view none = {};
+  return launch_decoder("mnerf_decoder_samples", dec, &none, &rays, cond, nullptr, nullptr, nullptr, rgb_s, sigma,
+                        x_ndc, dir, stream);
 }

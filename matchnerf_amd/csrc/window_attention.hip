@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_bf16_kernel(
 
 extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                                       int32_t batch, int32_t h, int32_t w, int32_t num_splits,
-                                      int32_t shifted, void* stream) {
+                                      int32_t shifted, int32_t math, void* stream) {
   MNERF_REQUIRE(q && k && v && out, MNERF_E_NULL, "mnerf_window_attention: NULL buffer");
   MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(k) && mnerf_aligned16(v) && mnerf_aligned16(out),
                 MNERF_E_ALIGN, "mnerf_window_attention: buffers must be 16-byte aligned");
@@ -413,6 +413,8 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
                 "mnerf_window_attention: %dx%d not divisible into %d splits", h, w, num_splits);
   MNERF_REQUIRE(batch <= 65535 && num_splits * num_splits <= 65535, MNERF_E_RANGE,
                 "mnerf_window_attention: grid too large");
+  MNERF_REQUIRE(math == MNERF_WA_SPLIT_BF16 || math == MNERF_WA_EXACT_F32, MNERF_E_UNSUPPORTED,
+                "mnerf_window_attention: math=%d", math);
   if (batch == 0) return MNERF_OK;
   WinGeom G;
   G.h = h;
@@ -428,22 +430,17 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   hipStream_t st = (hipStream_t)stream;
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * num_splits * num_splits * batch;
   const size_t lds = 4 * WA_KT * WA_C * sizeof(float);  // 64 KiB: K and V tiles, double buffered
-  static bool attr_set = false;
-  if (!attr_set) {
+  const bool split = math == MNERF_WA_SPLIT_BF16;  // split-bf16 products (default) or the exact-f32 MFMA
+  static std::atomic<unsigned long long> attr_f32{0}, attr_split{0};
+  if (!split && mnerf_once_per_device(attr_f32)) {
     (void)hipFuncSetAttribute((const void*)window_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)window_attention_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
-  int min4 = 200;  // use 128-query workgroups once they (nearly) fill the 256 CUs
-  if (const char* e = getenv("MNERF_WA_MIN4")) min4 = atoi(e);
-  bool split = true;  // split-bf16 products (default) or the exact-f32 MFMA (MNERF_WA_MATH=f32)
-  if (const char* e = getenv("MNERF_WA_MATH")) split = !(e[0] == 'f' && e[1] == '3' && e[2] == '2');
-  static bool attr16_set = false;
-  if (split && !attr16_set) {
+  if (split && mnerf_once_per_device(attr_split)) {
     (void)hipFuncSetAttribute((const void*)window_attention_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)window_attention_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr16_set = true;
   }
+  const int min4 = mnerf_tune().wa_min4;
   if (wgs4 >= min4) {
     dim3 grid((G.Lw + 127) / 128, num_splits * num_splits, batch);
     if (split)

@@ -2,24 +2,28 @@
 
 There is deliberately NO fallback: if the shared library is missing or a call fails, a
 ``MnerfError`` is raised.  The product path never routes through the CPU oracle.
-Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus explicit sizes; the
-stream is ``torch.cuda.current_stream().cuda_stream``.  The binding itself needs no GPU
+Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus explicit sizes.  Every
+launch runs under ``torch.cuda.device(<device of the tensors>)`` on that device's current torch
+stream (the library launches on the calling thread's current HIP device), so the module works on
+any ``--gpu_ids`` / LOCAL_RANK, like the pure-torch reference.  The binding itself needs no GPU
 (``load()`` works on a CPU-only box; that is what the ``-m "not gpu"`` ABI tests exercise).
 """
+import contextlib
 import ctypes as C
 import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 2
+MNERF_ABI_VERSION = 3
 MNERF_MAX_VIEWS = 16
+MNERF_COND_STRIDE_MAX, MNERF_COND_STRIDE_MAX_F32 = 96, 64
 SMALL_FIXED = 32  # floats of the `small` parameter block (LayerNorm weight|bias) before the ray-posenc table
 
 _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
-           "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_render_workspace_bytes",
+           "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_window_attention")
 
 
@@ -52,7 +56,8 @@ class Decoder(C.Structure):
                 ("setbg_opaque", C.c_int32), ("wstream_format", C.c_int32)]
 
 
-WSTREAM_F32, WSTREAM_BF16X3 = 0, 1
+WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
+WA_SPLIT_BF16, WA_EXACT_F32 = 0, 1
 
 
 def lib_path():
@@ -86,19 +91,21 @@ def load():
     lib.mnerf_ray_samples.restype = C.c_int
     lib.mnerf_ray_samples.argtypes = [C.POINTER(Rays), C.POINTER(View), fp, fp, fp, vp]
     lib.mnerf_composite.restype = C.c_int
-    lib.mnerf_composite.argtypes = [i32, i32, fp, fp, fp, fp, i32, i32, fp, fp, fp, vp]
+    lib.mnerf_composite.argtypes = [i32, i32, fp, fp, fp, fp, i32, i32, fp, fp, fp, fp, vp]
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
     lib.mnerf_decoder_wstream_floats.restype = i64
     lib.mnerf_decoder_wstream_floats.argtypes = [i32, i32, i32, i32]
     lib.mnerf_decoder_chunk.restype = C.c_int
     lib.mnerf_decoder_chunk.argtypes = [C.POINTER(Decoder), C.POINTER(View), C.POINTER(Rays), fp, fp, fp, fp, fp, fp, vp]
+    lib.mnerf_decoder_samples.restype = C.c_int
+    lib.mnerf_decoder_samples.argtypes = [C.POINTER(Decoder), i32, i32, i32, fp, fp, fp, fp, fp, vp]
     lib.mnerf_render_workspace_bytes.restype = i64
     lib.mnerf_render_workspace_bytes.argtypes = [i32, i32, i32]
     lib.mnerf_render_chunk.restype = C.c_int
     lib.mnerf_render_chunk.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), vp, fp, fp, fp, vp]
     lib.mnerf_window_attention.restype = C.c_int
-    lib.mnerf_window_attention.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_window_attention.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
@@ -148,11 +155,17 @@ def make_rays(n_rays, n_samples, height, width, kinv, c2w, near, far, ray_begin=
     return r
 
 
-def _stream_ptr(stream=None):
+@contextlib.contextmanager
+def _on(device, stream=None):
+    """Make ``device`` the current HIP device for the launch and yield the stream handle to launch on
+    (``stream`` or that device's current torch stream)."""
     import torch
-    if stream is None:
-        stream = torch.cuda.current_stream()
-    return C.c_void_p(stream.cuda_stream)
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise MnerfError(f"the HIP kernels need CUDA tensors, got device {device} (there is no CPU fallback)")
+    with torch.cuda.device(device):
+        st = stream if stream is not None else torch.cuda.current_stream(device)
+        yield C.c_void_p(st.cuda_stream)
 
 
 def _ptr(t):
@@ -167,46 +180,64 @@ def _f32c(t, name):
     return t
 
 
+def _current_device():
+    import torch
+    if not torch.cuda.is_available():
+        raise MnerfError("the HIP kernels need a GPU (there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 # ----------------------------------------------------------------------- op wrappers
 
 
-def ray_samples(rays, view, stream=None):
+def ray_samples(rays, view, device=None, stream=None):
     """a8-a10 (camera.py:255-286, 351-379) -> pts [R,S,3], ndc [R,S,3], depth [R,S]."""
     import torch
     lib = load()
+    device = torch.device(device) if device is not None else _current_device()
     r, s = rays.n_rays, rays.n_samples
-    pts = torch.empty(r, s, 3, device="cuda")
-    ndc = torch.empty(r, s, 3, device="cuda")
-    depth = torch.empty(r, s, device="cuda")
-    check(lib.mnerf_ray_samples(C.byref(rays), C.byref(view), _ptr(pts), _ptr(ndc), _ptr(depth),
-                                _stream_ptr(stream)), "mnerf_ray_samples")
+    pts = torch.empty(r, s, 3, device=device)
+    ndc = torch.empty(r, s, 3, device=device)
+    depth = torch.empty(r, s, device=device)
+    with _on(device, stream) as st:
+        check(lib.mnerf_ray_samples(C.byref(rays), C.byref(view), _ptr(pts), _ptr(ndc), _ptr(depth), st),
+              "mnerf_ray_samples")
     return pts, ndc, depth
 
 
-def composite(rgb_s, sigma, depth_s, ray_len=None, wo_render_interval=True, setbg_opaque=False, stream=None):
-    """K5 (nerf.py:101-124). rgb_s [R,S,3], sigma [R,S], depth_s [R,S] -> rgb [R,3], depth [R], opacity [R]."""
+def composite(rgb_s, sigma, depth_s, ray_len=None, wo_render_interval=True, setbg_opaque=False, want_prob=False,
+              stream=None):
+    """K5 (nerf.py:101-124). rgb_s [R,S,3], sigma [R,S], depth_s [R,S] -> rgb [R,3], depth [R], opacity [R]
+    (+ prob [R,S] with ``want_prob``)."""
     import torch
     lib = load()
     r, s = sigma.shape
     _f32c(rgb_s, "rgb_s"), _f32c(sigma, "sigma"), _f32c(depth_s, "depth_s")
-    rgb = torch.empty(r, 3, device=sigma.device)
-    depth = torch.empty(r, device=sigma.device)
-    opacity = torch.empty(r, device=sigma.device)
-    check(lib.mnerf_composite(r, s, _ptr(rgb_s), _ptr(sigma), _ptr(depth_s), _ptr(ray_len),
-                              int(wo_render_interval), int(setbg_opaque), _ptr(rgb), _ptr(depth),
-                              _ptr(opacity), _stream_ptr(stream)), "mnerf_composite")
+    dev = sigma.device
+    rgb = torch.empty(r, 3, device=dev)
+    depth = torch.empty(r, device=dev)
+    opacity = torch.empty(r, device=dev)
+    prob = torch.empty(r, s, device=dev) if want_prob else None
+    with _on(dev, stream) as st:
+        check(lib.mnerf_composite(r, s, _ptr(rgb_s), _ptr(sigma), _ptr(depth_s), _ptr(ray_len),
+                                  int(wo_render_interval), int(setbg_opaque), _ptr(rgb), _ptr(depth),
+                                  _ptr(opacity), _ptr(prob), st), "mnerf_composite")
+    if want_prob:
+        return rgb, depth, opacity, prob
     return rgb, depth, opacity
 
 
-def cost_volume(scene, rays, cond_stride, out=None, stream=None):
-    """K1+K2 (matchnerf.py:209-293) -> cond [n_rays*S, cond_stride]."""
+def cost_volume(scene, rays, cond_stride, out=None, device=None, stream=None):
+    """K1+K2 (matchnerf.py:209-293) -> cond [n_rays*S, cond_stride].  The launch device is ``out``'s, else
+    ``device``, else the current one (it must be where the scene's maps live)."""
     import torch
     lib = load()
     n = rays.n_rays * rays.n_samples
     if out is None:
-        out = torch.empty(n, cond_stride, device="cuda")
-    check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), int(cond_stride), _ptr(out),
-                                _stream_ptr(stream)), "mnerf_cost_volume")
+        out = torch.empty(n, cond_stride, device=torch.device(device) if device is not None else _current_device())
+    with _on(out.device, stream) as st:
+        check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), int(cond_stride), _ptr(out), st),
+              "mnerf_cost_volume")
     return out
 
 
@@ -221,12 +252,32 @@ def decoder_chunk(dec, view0, rays, cond, want_samples=False, stream=None):
     opacity = torch.empty(r, device=dev)
     rgb_s = torch.empty(r, s, 3, device=dev) if want_samples else None
     sigma = torch.empty(r, s, device=dev) if want_samples else None
-    check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(view0), C.byref(rays), _ptr(cond), _ptr(rgb),
-                                  _ptr(depth), _ptr(opacity), _ptr(rgb_s), _ptr(sigma),
-                                  _stream_ptr(stream)), "mnerf_decoder_chunk")
+    with _on(dev, stream) as st:
+        check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(view0), C.byref(rays), _ptr(cond), _ptr(rgb),
+                                      _ptr(depth), _ptr(opacity), _ptr(rgb_s), _ptr(sigma), st),
+              "mnerf_decoder_chunk")
     if want_samples:
         return rgb, depth, opacity, rgb_s, sigma
     return rgb, depth, opacity
+
+
+def decoder_samples(dec, x_ndc, dirs, cond, legacy_coord=True, stream=None):
+    """K3+K4 with caller-supplied inputs (the literal CondNeRF.forward, cond_nerf.py:52-100):
+    x_ndc [R,S,3], dirs [R,S,3], cond [R*S, cond_stride] -> rgb_s [R,S,3], sigma [R,S]."""
+    import torch
+    lib = load()
+    _f32c(x_ndc, "x_ndc"), _f32c(dirs, "dirs"), _f32c(cond, "cond")
+    r, s, _ = x_ndc.shape
+    if tuple(dirs.shape) != (r, s, 3) or cond.numel() != r * s * dec.cond_stride:
+        raise MnerfError(f"decoder_samples: x_ndc {tuple(x_ndc.shape)}, dirs {tuple(dirs.shape)}, cond "
+                         f"{tuple(cond.shape)} (stride {dec.cond_stride}) do not agree")
+    dev = x_ndc.device
+    rgb_s = torch.empty(r, s, 3, device=dev)
+    sigma = torch.empty(r, s, device=dev)
+    with _on(dev, stream) as st:
+        check(lib.mnerf_decoder_samples(C.byref(dec), r, s, int(bool(legacy_coord)), _ptr(x_ndc), _ptr(dirs),
+                                        _ptr(cond), _ptr(rgb_s), _ptr(sigma), st), "mnerf_decoder_samples")
+    return rgb_s, sigma
 
 
 class KernelTimer:
@@ -246,9 +297,10 @@ class KernelTimer:
         self.spans = {}
 
     def summary(self):
-        import torch
-        torch.cuda.synchronize()
         out = {}
+        for spans in self.spans.values():
+            for _, end, _ in spans:
+                end.synchronize()
         for name, spans in self.spans.items():
             ms = [a.elapsed_time(b) for a, b, _ in spans]
             out[name] = dict(launches=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / max(len(ms), 1),
@@ -260,30 +312,39 @@ def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None, 
     """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place.
     With ``timer`` the two kernels are enqueued through their own entry points (same work,
     same stream) with events around each, so that per-kernel durations can be reported."""
-    lib = load()
-    if timer is None:
-        check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
-                                     _ptr(depth), _ptr(opacity), _stream_ptr(stream)), "mnerf_render_chunk")
-        return
     import torch
-    st = stream or torch.cuda.current_stream()
-    a0, a1 = timer.span("cost_volume", rays.n_rays)
-    a0.record(st)
-    check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), dec.cond_stride, _ptr(workspace), _stream_ptr(st)),
-          "mnerf_cost_volume")
-    a1.record(st)
-    b0, b1 = timer.span("decoder", rays.n_rays)
-    b0.record(st)
-    check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(scene.views[0]), C.byref(rays), _ptr(workspace), _ptr(rgb),
-                                  _ptr(depth), _ptr(opacity), None, None, _stream_ptr(st)), "mnerf_decoder_chunk")
-    b1.record(st)
+    lib = load()
+    with _on(rgb.device, stream) as st:
+        if timer is None:
+            check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
+                                         _ptr(depth), _ptr(opacity), st), "mnerf_render_chunk")
+            return
+        tst = stream if stream is not None else torch.cuda.current_stream(rgb.device)
+        a0, a1 = timer.span("cost_volume", rays.n_rays)
+        a0.record(tst)
+        check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), dec.cond_stride, _ptr(workspace), st),
+              "mnerf_cost_volume")
+        a1.record(tst)
+        b0, b1 = timer.span("decoder", rays.n_rays)
+        b0.record(tst)
+        check(lib.mnerf_decoder_chunk(C.byref(dec), C.byref(scene.views[0]), C.byref(rays), _ptr(workspace),
+                                      _ptr(rgb), _ptr(depth), _ptr(opacity), None, None, st), "mnerf_decoder_chunk")
+        b1.record(tst)
 
 
 def render_workspace_bytes(n_rays, n_samples, cond_stride):
     return int(load().mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride))
 
 
-def window_attention(q, k, v, h, w, num_splits, shifted, out=None, stream=None):
+def wa_math():
+    """Matrix arithmetic of the window-attention kernel: MNERF_WA_MATH = 'bf16x6' (default) or 'f32'."""
+    m = os.environ.get("MNERF_WA_MATH", "bf16x6")
+    if m not in ("bf16x6", "f32"):
+        raise ValueError(f"MNERF_WA_MATH={m!r}: expected 'bf16x6' or 'f32'")
+    return WA_EXACT_F32 if m == "f32" else WA_SPLIT_BF16
+
+
+def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, stream=None):
     """K6 (gmflow/transformer.py:8-105). q,k,v [B,h*w,128] -> [B,h*w,128]."""
     import torch
     lib = load()
@@ -293,6 +354,8 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, stream=None):
         raise MnerfError(f"window_attention: expected [B,{h * w},128], got {tuple(q.shape)}")
     if out is None:
         out = torch.empty_like(q)
-    check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
-                                     int(bool(shifted)), _stream_ptr(stream)), "mnerf_window_attention")
+    with _on(q.device, stream) as st:
+        check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
+                                         int(bool(shifted)), wa_math() if math is None else int(math), st),
+              "mnerf_window_attention")
     return out

@@ -28,6 +28,8 @@ from .gmflow import GMFlow, pair_major_to_view_chunks
 # ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
 # chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
 MAX_RAYS_PER_LAUNCH = 65536
+# rays per autograd node when gradients are required (bounds the temporaries of the re-evaluated backward)
+GRAD_RAYS_PER_CALL = 8192
 
 
 class MatchNeRF(torch.nn.Module):
@@ -48,7 +50,12 @@ class MatchNeRF(torch.nn.Module):
             raise NotImplementedError("encoder.feature_sample_local_radius > 0 (gmflow/utils.py:136-162) is not "
                                       "built; every shipped config uses 0 (base.yaml:27)")
         self._ws = None
+        self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
+
+    def _dec(self):
+        """the CondNeRF module, also when the reference's coach wrapped it in nn.DataParallel (coach.py:83-85)"""
+        return getattr(self.nerf_dec, "module", self.nerf_dec)
 
     # ------------------------------------------------------------------ forward (matchnerf.py:32-73)
     def forward(self, batch, mode=None, render_video=False, render_path_mode="interpolate"):
@@ -94,7 +101,7 @@ class MatchNeRF(torch.nn.Module):
                 for k, v in ret.items():
                     collected.setdefault(k, []).append(v)
         if render_video:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(ref_images.device).synchronize()
             for k, v in collected.items():
                 batch[k] = v
         else:
@@ -142,17 +149,7 @@ class MatchNeRF(torch.nn.Module):
         return sc
 
     def _decoder(self, n_samples, device):
-        ws, small, cond_stride, wfmt = self.nerf_dec.packed(n_samples, device)
-        d = hip.Decoder()
-        d.wstream, d.wstream_floats, d.small_ = ws.data_ptr(), ws.numel(), small.data_ptr()
-        d.n_views, d.cond_dim, d.cond_stride = self.n_src_views, self.nerf_dec.cond_dim, cond_stride
-        d.wstream_format = wfmt
-        d.L_3D = self.nerf_dec.L_3D
-        dec, nerf = self.opts.decoder, self.opts.nerf
-        d.raytrans_posenc, d.raytrans_elu = int(bool(dec.raytrans_posenc)), int(dec.raytrans_act == "ELU")
-        d.density_maskfill, d.wo_render_interval = int(bool(dec.density_maskfill)), int(bool(nerf.wo_render_interval))
-        d.setbg_opaque = int(bool(self.nerf_setbg_opaque))
-        return d
+        return self._dec().decoder_struct(n_samples, device, self.nerf_setbg_opaque)
 
     def _workspace(self, n_floats, device):
         if self._ws is None or self._ws.numel() < n_floats or self._ws.device != device:
@@ -162,6 +159,29 @@ class MatchNeRF(torch.nn.Module):
     @staticmethod
     def _host(t):
         return t.detach().float().cpu().numpy()
+
+    def _frame_ctx(self, ref_poses, ref_images):
+        """Launch context of one source set, built once and shared by every target pose rendered from it (all
+        frames of a video, all chunks of a frame): host copies of the source cameras (they travel by value in the
+        kernel arguments) and the channel-last RGBA copy of the source images.  Keyed on the identity and version
+        of the tensors, so in-place edits or a new batch rebuild it."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in
+                    (ref_images, ref_poses["extrinsics"], ref_poses["intrinsics"], ref_poses["near_fars"]))
+        if self._frame is None or self._frame[0] != key:
+            b, v, _, h, w = ref_images.shape
+            ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
+                        self._host(ref_poses["near_fars"]))
+            images_cl = torch.zeros(b, v, h, w, 4, device=ref_images.device)
+            images_cl[..., :3] = ref_images.detach().permute(0, 1, 3, 4, 2)
+            self._frame = (key, ref_host, images_cl)
+        return self._frame[1], self._frame[2]
+
+    def _tgt_host(self, tgt_pose):
+        """(extrinsics, intrinsics, near_fars) of the target pose on the host; poses generated on the host
+        (video paths) carry their numpy originals under "_host" and cost no device sync."""
+        if "_host" in tgt_pose:
+            return tgt_pose["_host"]
+        return tuple(self._host(tgt_pose[k]) for k in ("extrinsics", "intrinsics", "near_fars"))
 
     # ------------------------------------------------------------------ render (matchnerf.py:88-143)
     def render(self, opt, tgt_pose=None, ray_idx=None, mode=None, ref_poses=None, ref_images=None,
@@ -180,24 +200,20 @@ class MatchNeRF(torch.nn.Module):
         idx32 = None if ray_idx is None else ray_idx.to(device=device, dtype=torch.int32).contiguous()
         stratified = mode == "train" and bool(opt.nerf.sample_stratified)
 
-        # one small device->host copy per call for the camera matrices (kernel arguments)
-        ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
-                    self._host(ref_poses["near_fars"]))
-        tgt_ex, tgt_in, tgt_nf = (self._host(tgt_pose[k]) for k in ("extrinsics", "intrinsics", "near_fars"))
-        images_cl = torch.zeros(batch_size, self.n_src_views, img_h, img_w, 4, device=device)
-        images_cl[..., :3] = ref_images.permute(0, 1, 3, 4, 2)
-        dec = self._decoder(n_samples, device)
-        chunk = min(n_rays, MAX_RAYS_PER_LAUNCH)
-        ws = self._workspace(hip.render_workspace_bytes(chunk, n_samples, dec.cond_stride) // 4, device)
-
-        rgb = torch.empty(batch_size, n_rays, 3, device=device)
-        depth = torch.empty(batch_size, n_rays, 1, device=device)
-        opacity = torch.empty(batch_size, n_rays, 1, device=device)
+        dec_mod = self._dec()
         needs_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in ref_feats_list) or
-                                                  any(p.requires_grad for p in self.nerf_dec.parameters()))
+                                                  any(p.requires_grad for p in dec_mod.parameters()))
+        ref_host, images_cl = self._frame_ctx(ref_poses, ref_images)
+        tgt_ex, tgt_in, tgt_nf = self._tgt_host(tgt_pose)
         if needs_grad:
             return self._render_with_grad(opt, ref_host, (tgt_ex, tgt_in, tgt_nf), ray_idx, stratified, ref_images,
                                           ref_feats_list, images_cl, n_rays, n_samples, img_h, img_w)
+        dec = self._decoder(n_samples, device)
+        chunk = min(n_rays, MAX_RAYS_PER_LAUNCH)
+        ws = self._workspace(hip.render_workspace_bytes(chunk, n_samples, dec.cond_stride) // 4, device)
+        rgb = torch.empty(batch_size, n_rays, 3, device=device)
+        depth = torch.empty(batch_size, n_rays, 1, device=device)
+        opacity = torch.empty(batch_size, n_rays, 1, device=device)
         for b in range(batch_size):
             sc = self._scene(b, ref_host, ref_feats_list, images_cl)
             kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
@@ -215,41 +231,50 @@ class MatchNeRF(torch.nn.Module):
 
     def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,
                           n_rays, n_samples, img_h, img_w):
-        """Training path: forward through the HIP kernels, backward through a torch re-evaluation
-        of the same ray chunk (matchnerf_amd/autograd.py)."""
+        """Training path: forward through the HIP kernels, backward through a torch re-evaluation of the same
+        ray chunk (matchnerf_amd/autograd.py).  Rays go through in chunks of GRAD_RAYS_PER_CALL so that a
+        full-image call under autograd keeps the re-evaluation's temporaries bounded."""
         from . import autograd as ag
         device = ref_images.device
         legacy = bool(opt.nerf.legacy_coord)
         tgt_ex, tgt_in, tgt_nf = tgt_host
         batch_size = ref_images.shape[0]
-        idx = torch.arange(n_rays, device=device) if ray_idx is None else ray_idx.to(device)
-        idx32 = idx.to(torch.int32).contiguous()
+        idx_all = torch.arange(n_rays, device=device) if ray_idx is None else ray_idx.to(device)
+        dec_mod = self._dec()
         outs = []
         for b in range(batch_size):
-            strat = torch.rand(n_rays, n_samples, device=device) if stratified else None
+            strat_all = torch.rand(n_rays, n_samples, device=device) if stratified else None
             kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
+            parts = []
+            for c in range(0, n_rays, GRAD_RAYS_PER_CALL):
+                idx = idx_all[c:c + GRAD_RAYS_PER_CALL]
+                idx32 = idx.to(torch.int32).contiguous()
+                strat = None if strat_all is None else strat_all[c:c + GRAD_RAYS_PER_CALL].contiguous()
+                m = int(idx.numel())
 
-            def hip_render(feats, b=b, strat=strat, kinv=kinv, c2w=c2w):
-                dec = self._decoder(n_samples, device)
-                sc = self._scene(b, ref_host, None, images_cl, feats_b=[f.contiguous() for f in feats])
-                ws = self._workspace(hip.render_workspace_bytes(n_rays, n_samples, dec.cond_stride) // 4, device)
-                rays = hip.make_rays(n_rays, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1],
-                                     legacy=legacy, depth_inverse=(opt.nerf.depth.param == "inverse"),
-                                     ray_idx_ptr=idx32.data_ptr(),
-                                     strat_u_ptr=None if strat is None else strat.data_ptr())
-                o_rgb = torch.empty(n_rays, 3, device=device)
-                o_d = torch.empty(n_rays, 1, device=device)
-                o_o = torch.empty(n_rays, 1, device=device)
-                hip.render_chunk(sc, dec, rays, ws, o_rgb, o_d, o_o)
-                return o_rgb, o_d, o_o
+                def hip_render(feats, b=b, strat=strat, kinv=kinv, c2w=c2w, idx32=idx32, m=m):
+                    dec = self._decoder(n_samples, device)
+                    sc = self._scene(b, ref_host, None, images_cl, feats_b=[f.contiguous() for f in feats])
+                    ws = self._workspace(hip.render_workspace_bytes(m, n_samples, dec.cond_stride) // 4, device)
+                    rays = hip.make_rays(m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1],
+                                         legacy=legacy, depth_inverse=(opt.nerf.depth.param == "inverse"),
+                                         ray_idx_ptr=idx32.data_ptr(),
+                                         strat_u_ptr=None if strat is None else strat.data_ptr())
+                    o_rgb = torch.empty(m, 3, device=device)
+                    o_d = torch.empty(m, 1, device=device)
+                    o_o = torch.empty(m, 1, device=device)
+                    hip.render_chunk(sc, dec, rays, ws, o_rgb, o_d, o_o)
+                    return o_rgb, o_d, o_o
 
-            def torch_render(feats, b=b, strat=strat):
-                ex, it, nf = ref_host
-                return ag.render_rays_torch(opt, self.nerf_dec, feats, ref_images[b], ex[b], it[b], nf[b], tgt_ex[b],
-                                            tgt_in[b], tgt_nf[b], idx, strat, img_h, img_w, bool(self.nerf_setbg_opaque))
+                def torch_render(feats, b=b, strat=strat, idx=idx):
+                    ex, it, nf = ref_host
+                    return ag.render_rays_torch(opt, dec_mod, feats, ref_images[b], ex[b], it[b], nf[b], tgt_ex[b],
+                                                tgt_in[b], tgt_nf[b], idx, strat, img_h, img_w,
+                                                bool(self.nerf_setbg_opaque))
 
-            outs.append(ag.render_rays(self, dict(hip_render=hip_render, torch_render=torch_render),
-                                       [f[b] for f in ref_feats_list]))
+                parts.append(ag.render_rays(dec_mod, dict(hip_render=hip_render, torch_render=torch_render),
+                                            [f[b] for f in ref_feats_list]))
+            outs.append([torch.cat([p[k] for p in parts], 0) for k in range(3)])
         return edict(rgb=torch.stack([o[0] for o in outs], 0), depth=torch.stack([o[1] for o in outs], 0),
                      opacity=torch.stack([o[2] for o in outs], 0))
 
@@ -285,20 +310,17 @@ class MatchNeRF(torch.nn.Module):
         b_n, n_rays, n_samples = point_samples.shape[:3]
         _, v, _, img_h, img_w = ref_images.shape
         device = ref_images.device
-        ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
-                    self._host(ref_poses["near_fars"]))
-        images_cl = torch.zeros(b_n, v, img_h, img_w, 4, device=device)
-        images_cl[..., :3] = ref_images.permute(0, 1, 3, 4, 2)
-        dc = self.nerf_dec.cond_dim
+        ref_host, images_cl = self._frame_ctx(ref_poses, ref_images)
+        dc = self._dec().cond_dim
         stride = ((dc + 1 + 7) // 8) * 8
         sum_g = dc - 4 * v
         out = torch.empty(b_n, n_rays * n_samples, stride, device=device)
         idx32 = None if ray_idx is None else ray_idx.to(device=device, dtype=torch.int32).contiguous()
         for b in range(b_n):
             sc = self._scene(b, ref_host, ref_feats_list, images_cl)
-            kinv, c2w = camera.target_ray_consts(self._host(tgt_pose["extrinsics"])[b], self._host(tgt_pose["intrinsics"])[b],
-                                                 bool(self.opts.nerf.legacy_coord))
-            nf = self._host(tgt_pose["near_fars"])[b]
+            t_ex, t_in, t_nf = self._tgt_host(tgt_pose)
+            kinv, c2w = camera.target_ray_consts(t_ex[b], t_in[b], bool(self.opts.nerf.legacy_coord))
+            nf = t_nf[b]
             rays = hip.make_rays(n_rays, n_samples, img_h, img_w, kinv, c2w, nf[0], nf[1],
                                  legacy=bool(self.opts.nerf.legacy_coord),
                                  depth_inverse=(self.opts.nerf.depth.param == "inverse"),
@@ -331,8 +353,13 @@ class MatchNeRF(torch.nn.Module):
                                                 n_views=n_frames)
             else:
                 raise Exception(f"Unknown video rendering path mode {mode}")
-            per_batch.append(torch.tensor(np.asarray(path)).inverse()[:, :3].to(torch.float32).to(device))
-        paths = torch.stack(per_batch, 0)
-        # the reference indexes frames 0..n_frames-1 of the path (matchnerf.py:319-323)
+            per_batch.append(torch.tensor(np.asarray(path)).inverse()[:, :3].to(torch.float32))
+        paths_host = torch.stack(per_batch, 0)                       # [B, n_frames, 3, 4] on the host
+        paths = paths_host.to(device)
+        _, t_in, t_nf = self._tgt_host(tgt_pose)                     # one device->host copy for the whole path
+        paths_np = paths_host.numpy()
+        # the reference indexes frames 0..n_frames-1 of the path (matchnerf.py:319-323); "_host" carries the numpy
+        # originals so that render() needs no device->host copy per frame
         return [dict(extrinsics=paths[:, i], intrinsics=tgt_pose["intrinsics"].clone().detach(),
-                     near_fars=tgt_pose["near_fars"].clone().detach()) for i in range(n_frames)]
+                     near_fars=tgt_pose["near_fars"].clone().detach(), _host=(paths_np[:, i], t_in, t_nf))
+                for i in range(n_frames)]

@@ -54,12 +54,11 @@ def make_rays_struct(cfg, batch, n_rays, ray_begin=0, ray_idx_gpu=None, b=0):
 
 
 def make_decoder_struct(cfg, sd, setbg_opaque=False, device="cuda", math=None):
-    """math: 'bf16x6' / 'f32' (default: MNERF_DECODER_MATH, i.e. what the product uses)."""
+    """math: 'f16x3' / 'bf16x6' / 'f32' (default: MNERF_DECODER_MATH, i.e. what the product uses)."""
     math = math or CN.decoder_math()
     if cfg.sample_intvs > 128:
         math = "f32"
-    pack = CN.pack_wstream16 if math == "bf16x6" else CN.pack_wstream
-    ws, cond_dim, cs = pack(sd, cfg.n_src_views, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    ws, cond_dim, cs = CN.pack_for_math(math)(sd, cfg.n_src_views, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
     small = CN.pack_small(sd, cfg.sample_intvs, cfg.raytrans_posenc)
     ws_t, small_t = torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device)
     d = hip.Decoder()
@@ -68,7 +67,7 @@ def make_decoder_struct(cfg, sd, setbg_opaque=False, device="cuda", math=None):
     d.raytrans_posenc, d.raytrans_elu = int(cfg.raytrans_posenc), int(cfg.raytrans_act == "ELU")
     d.density_maskfill, d.wo_render_interval = int(cfg.density_maskfill), int(cfg.wo_render_interval)
     d.setbg_opaque = int(setbg_opaque)
-    d.wstream_format = hip.WSTREAM_BF16X3 if math == "bf16x6" else hip.WSTREAM_F32
+    d.wstream_format = CN.WSTREAM_FORMATS[math]
     return d, (ws_t, small_t)  # keep the tensors alive
 
 

@@ -41,17 +41,32 @@ def test_state_dict_keys_and_shapes_match_reference_layout():
 
 
 def test_checkpoint_roundtrip_per_child(tmp_path):
-    """misc/utils.py:183-205 semantics: {model: state_dict} restored per top-level child, strict."""
+    """misc/utils.py:183-222 semantics: the caller hands over {model, optim} only (coach.py:290-300), epoch / iter
+    are stamped by save_checkpoint; restore is per top-level child, strict; resume returns (epoch, iter)."""
     from matchnerf_amd import checkpoint
     from matchnerf_amd.models import models_dict
     m1 = models_dict["matchnerf"](_opts())
     m1.load_state_dict(syn.to_torch(syn.seeded_state_dict(syn.state_dict_spec(), 5)))
-    path = checkpoint.save_checkpoint(str(tmp_path), dict(model=m1.state_dict(), epoch=3, iter=7), ep=3, it=7)
+    opt1 = torch.optim.SGD(m1.parameters(), lr=0.25)
+    path = checkpoint.save_checkpoint(str(tmp_path), dict(model=m1.state_dict(), optim=opt1.state_dict()), ep=3, it=7)
+    slim = torch.load(tmp_path / "models" / "ep3_it7.pth")
+    assert slim["epoch"] == 3 and slim["iter"] == 7 and "optim" not in slim
     m2 = models_dict["matchnerf"](_opts())
     ep, it = checkpoint.restore_checkpoint(m2, path, "cpu")
     assert (ep, it) == (None, None)
     for (k1, a), (k2, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(a, b)
+    opt2 = torch.optim.SGD(m2.parameters(), lr=1.0)
+    assert checkpoint.restore_checkpoint(m2, path, "cpu", resume=True, optims_scheds=dict(optim=opt2)) == (3, 7)
+    assert opt2.param_groups[0]["lr"] == 0.25
+    # children filter (misc/utils.py:211-212): decoder-only checkpoint leaves the encoder untouched
+    path = checkpoint.save_checkpoint(str(tmp_path / "dec"), dict(model=m1.state_dict()), 1, 2, children="nerf_dec")
+    assert all(k.startswith("nerf_dec.") for k in torch.load(path)["model"])
+    m3 = models_dict["matchnerf"](_opts())
+    enc_before = {k: v.clone() for k, v in m3.feat_enc.state_dict().items()}
+    checkpoint.restore_checkpoint(m3, path, "cpu")
+    assert all(torch.equal(v, enc_before[k]) for k, v in m3.feat_enc.state_dict().items())
+    assert torch.equal(m3.nerf_dec.pts_bias.weight, m1.nerf_dec.pts_bias.weight)
 
 
 def test_unsupported_architectures_fail_loudly():
@@ -63,23 +78,53 @@ def test_unsupported_architectures_fail_loudly():
 
 
 def test_decoder_packing_follows_the_math_switch(monkeypatch):
-    """CondNeRF.packed: split-bf16 stream by default, exact-f32 stream on request and for S > 128 (the 8-wave
-    kernel is f32-only); the cache is keyed on the switch; bad values are rejected."""
+    """CondNeRF.packed: split-fp16 stream by default, split-bf16 / exact-f32 streams on request, exact-f32 for
+    S > 128 (the 8-wave kernel is f32-only); the cache is keyed on the switch; bad values are rejected."""
     from matchnerf_amd import cond_nerf as CN
     from matchnerf_amd.models import models_dict
     dec = models_dict["matchnerf"](_opts()).nerf_dec
     monkeypatch.delenv("MNERF_DECODER_MATH", raising=False)
     ws, small, cs, fmt = dec.packed(64, "cpu")
-    assert fmt == 1 and ws.numel() == CN.decoder_schedule16(dec.cond_dim, dec.L_3D)[1]
+    assert fmt == 2 and ws.numel() == CN.decoder_schedule_h(dec.cond_dim, dec.L_3D)[1]
     assert dec.packed(64, "cpu")[0] is ws                       # cached
     ws256, _, _, fmt256 = dec.packed(256, "cpu")
     assert fmt256 == 0 and ws256.numel() == CN.decoder_schedule(cs, dec.L_3D)[1]
+    monkeypatch.setenv("MNERF_DECODER_MATH", "bf16x6")
+    ws16, _, _, fmt16 = dec.packed(64, "cpu")
+    assert fmt16 == 1 and ws16.numel() == CN.decoder_schedule16(dec.cond_dim, dec.L_3D)[1]
     monkeypatch.setenv("MNERF_DECODER_MATH", "f32")
     ws32, _, _, fmt32 = dec.packed(64, "cpu")
     assert fmt32 == 0 and ws32.numel() == ws256.numel()
     monkeypatch.setenv("MNERF_DECODER_MATH", "fp8")
     with pytest.raises(ValueError, match="MNERF_DECODER_MATH"):
         dec.packed(64, "cpu")
+
+
+def test_view_limit_is_the_kernels(monkeypatch):
+    """MNERF_MAX_VIEWS = 16 is reachable with the split streams (cond_stride 88 <= 96); the exact-f32 stream keeps
+    its 64-float limit and says so when it is asked for more."""
+    from matchnerf_amd.models import models_dict
+    monkeypatch.delenv("MNERF_DECODER_MATH", raising=False)
+    m16 = models_dict["matchnerf"](_opts(n_src_views=16))
+    assert m16.nerf_dec.packed(64, "cpu")[2] == 80
+    monkeypatch.setenv("MNERF_DECODER_MATH", "f32")
+    with pytest.raises(NotImplementedError, match="supports 64"):
+        m16.nerf_dec.packed(64, "cpu")
+    with pytest.raises(NotImplementedError):
+        models_dict["matchnerf"](_opts(n_src_views=17))
+
+
+def test_data_parallel_wrapping_is_transparent():
+    """coach.py:83-85 wraps feat_enc / nerf_dec in nn.DataParallel when len(gpu_ids) > 1: the module keeps
+    finding its decoder (packing, cond_dim) through the wrapper."""
+    from matchnerf_amd.models import models_dict
+    model = models_dict["matchnerf"](_opts())
+    plain = model._dec()
+    model.nerf_dec = torch.nn.DataParallel(model.nerf_dec, [0, 1])
+    assert model._dec() is plain and model._dec().cond_dim == 22
+    d = model._decoder(64, torch.device("cpu"))
+    assert d.cond_dim == 22 and d.wstream_format == 2 and d.wstream_floats == plain.packed(64, "cpu")[0].numel()
+    assert list(model.state_dict())[-1].startswith("nerf_dec.module.")
 
 
 def test_render_refuses_cpu_tensors():
@@ -111,9 +156,11 @@ def test_library_exports_every_declared_symbol():
     # host-only entry points are callable without a GPU
     assert lib.mnerf_render_workspace_bytes(4096, 64, 24) == 4096 * 64 * 24 * 4
     from matchnerf_amd import cond_nerf as CN
-    for cd, cs, L in ((22, 24, 10), (50, 56, 10), (22, 24, 6)):
+    for cd, cs, L in ((22, 24, 10), (50, 56, 10), (22, 24, 6), (74, 80, 10)):
         assert lib.mnerf_decoder_wstream_floats(cd, cs, L, hip.WSTREAM_F32) == CN.decoder_schedule(cs, L)[1]
         assert lib.mnerf_decoder_wstream_floats(cd, cs, L, hip.WSTREAM_BF16X3) == CN.decoder_schedule16(cd, L)[1]
+        assert lib.mnerf_decoder_wstream_floats(cd, cs, L, hip.WSTREAM_F16X2) == CN.decoder_schedule_h(cd, L)[1]
+    assert lib.mnerf_decoder_wstream_floats(22, 24, 10, 7) == -1
 
 
 def test_struct_layouts_match_the_header():

@@ -278,3 +278,136 @@ def test_small_block_layout():
     assert np.array_equal(s[0:16], sd["nerf_dec.ray_attention.layer_norm.weight"].numpy())
     assert np.array_equal(s[16:32], sd["nerf_dec.ray_attention.layer_norm.bias"].numpy())
     assert linf(s[CN.SMALL_FIXED:].reshape(64, 16), O.raytrans_table(64)) == 0.0
+
+
+# ----------------------------------------------------------------------------- split-fp16 stream
+
+
+def gain_for(m):
+    """the kernel's operand gain: a power of two that puts the sample's largest |operand| m in [2^14, 2^15)"""
+    e = np.frexp(np.asarray(m, np.float32))[1]                      # m = f * 2^e, f in [0.5, 1)
+    return np.ldexp(np.float32(1.0), (CN.F16_TARGET_EXP + 1) - np.clip(e, -100, 100)).astype(np.float32)
+
+
+def emulate_stage_h(ws, segs, names, v, gain):
+    """v [T,2,8,N] TRUE operand values, gain [N] per-sample power-of-two gain -> Y [nmb*32, N] true outputs.
+    Emulates the kernel: operands scaled in fp32 and split into two fp16 terms, weights as (hi, lo) fp16 of
+    2^ew W, products hi.hi + hi.lo + lo.hi, bias header times (2^ew gain) as the initial accumulator, and the
+    exact inverse scale on the way out.  ``names``: stages that share one accumulator (e.g. l5e + l5h)."""
+    names = [names] if isinstance(names, str) else list(names)
+    parts = [s for s in segs if s[0] in names]
+    nmb = parts[0][3]
+    n = v.shape[-1]
+    y = np.zeros((nmb * 32, n), np.float64)
+    w16 = ws.view(np.float16)
+    winv = None
+    step0 = 0
+    for name in names:
+        mine = [s for s in parts if s[0] == name]
+        for _, first, steps, m, off, fl, hdr in mine:
+            if hdr:
+                winv = float(ws[off + 128])
+                bias = ws[off:off + 128].astype(np.float64)
+                for h in range(2):
+                    for mb in range(m):
+                        for r in range(16):
+                            row = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h
+                            y[row] += bias[(h * 4 + mb) * 16 + r] * (gain.astype(np.float64) / winv)
+                off += CN.FRAG_FLOATS
+            a = w16[2 * off:2 * off + steps * m * 2 * 512].reshape(steps, m, 2, 64, 8).astype(np.float64)
+            ah, al = a[:, :, 0], a[:, :, 1]
+            xs = (v[step0 + first:step0 + first + steps].astype(np.float32) * gain.astype(np.float32)).astype(np.float32)
+            assert np.abs(xs).max() < 65504
+            bh = xs.astype(np.float16)
+            bl = (xs - bh.astype(np.float32)).astype(np.float16)
+            bh, bl = bh.astype(np.float64), bl.astype(np.float64)
+            for wa, vb in ((ah, bl), (al, bh), (ah, bh)):
+                for mb in range(m):
+                    for h in range(2):
+                        y[mb * 32:(mb + 1) * 32] += np.einsum("tlj,tjn->ln", wa[:, mb, 32 * h:32 * h + 32, :], vb[:, h])
+        step0 += sum(s[2] for s in mine)
+    return y * (winv / gain.astype(np.float64))
+
+
+def _rowmax(*arrs):
+    return np.max(np.stack([np.abs(a).reshape(-1, a.shape[-1]).max(0) for a in arrs]), 0)
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4", "nonlegacy", "rect_wide"])
+def test_emulated_split_fp16_chain_matches_oracle(name):
+    g, cfg, sd, batch = golden_case(name)
+    n_rays = 8
+    x_ref = torch.from_numpy(g["x_ref"][:n_rays])
+    dir_ref = torch.from_numpy(g["dir_ref"][:n_rays])
+    cond = torch.from_numpy(g["cond"][:n_rays])
+    v = cfg.n_src_views
+    mask = cond[..., -v:]
+    with torch.no_grad():
+        rgb_o, sigma_o = O.decoder(cfg, sd, x_ref, dir_ref, cond, mask)
+    ws, cond_dim, cs = CN.pack_wstream_h(sd, v, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    segs, total = CN.decoder_schedule_h(cond_dim, cfg.L_3D)
+    assert ws.size == total
+    n = n_rays * cfg.sample_intvs
+    x = x_ref.reshape(n, 3).numpy().T.astype(np.float64)
+    tf = (cond_dim + 15) // 16
+    cpad = np.zeros((16 * tf, n))
+    cpad[:cond_dim] = cond.reshape(n, cond_dim).numpy().T
+    if cond_dim < 16 * tf:
+        cpad[cond_dim] = 1.0
+    fixed = np.full(n, 2.0 ** CN.F16_TARGET_EXP, np.float32)            # cosines, colours, masks: |.| <= 1
+    film = emulate_stage_h(ws, segs, "film", cpad.reshape(tf, 2, 8, n), fixed)
+    e = enc_operands16(x, cfg.L_3D, cfg.legacy_coord)
+    enc_max = np.maximum(1.0, np.abs(x).max(0))
+    h = np.maximum(emulate_stage_h(ws, segs, "l0", e, gain_for(enc_max)) * film, 0)
+    for i in range(1, 5):
+        h = np.maximum(emulate_stage_h(ws, segs, f"l{i}", reg_operands16(h, 4), gain_for(_rowmax(h))) * film, 0)
+    g5 = gain_for(np.maximum(_rowmax(h), enc_max))
+    h = np.maximum(emulate_stage_h(ws, segs, ["l5e", "l5h"], np.concatenate([e, reg_operands16(h, 4)], 0), g5) * film, 0)
+    gh = gain_for(_rowmax(h))
+    a = emulate_stage_h(ws, segs, "alpha", reg_operands16(h, 4), gh)
+    assert np.abs(a[16:]).max() == 0.0
+    feat = emulate_stage_h(ws, segs, "feature", reg_operands16(h, 4), gh)
+    d = np.repeat(dir_ref.numpy().astype(np.float64), cfg.sample_intvs, 0).T
+    dv = np.zeros((1, 2, 8, n))
+    dv[0, 0, :3] = d
+    gv = gain_for(np.maximum(_rowmax(feat), 1.0))
+    hv = np.maximum(emulate_stage_h(ws, segs, "views", np.concatenate([reg_operands16(feat, 4), dv], 0), gv), 0)
+    rgb = 1 / (1 + np.exp(-emulate_stage_h(ws, segs, "rgb", reg_operands16(hv, 2), gain_for(_rowmax(hv)))[:3]))
+    err = linf(rgb.T.reshape(n_rays, -1, 3), rgb_o)
+    print(f"f16x3 emulation {name}: per-sample rgb err {err:.2e}")
+    assert err < 5e-6
+    ws32, _, cs32 = CN.pack_wstream(sd, v, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
+    segs32, _ = CN.decoder_schedule(cs32, cfg.L_3D)
+    tail_floats = segs[-1][5]
+    assert np.array_equal(ws[-tail_floats:], ws32[-tail_floats:])
+    lo, hi = reg_order_operands(h, 4)
+    one, zero = np.ones((1, n)), np.zeros((1, n))
+    a32 = emulate_stage(ws32, segs32, "alpha", np.vstack([lo, one]), np.vstack([hi, zero]))
+    assert np.abs(a - a32).max() < 4e-6 * max(1.0, np.abs(a32).max())
+
+
+def test_schedule_h_invariants():
+    for cd, L in ((22, 10), (26, 10), (50, 10), (74, 10), (22, 6), (22, 0)):
+        segs, total = CN.decoder_schedule_h(cd, L)
+        assert total % 256 == 0 and len(segs) <= 64
+        off = 0
+        for name, first, steps, m, o, fl, hdr in segs:
+            assert o == off and fl % 256 == 0 and fl <= CN.SEG_CAP_FLOATS
+            off += fl
+        assert off == total
+        names = [s[0] for s in segs]
+        assert names[-4:] == ["views", "views", "rgb", "tail"]
+        assert names.index("alpha") == max(i for i, n in enumerate(names) if n == "l5h") + 1
+        for name in ("l1", "l2", "l3", "l4", "l5h", "feature"):
+            assert [s[2] for s in segs if s[0] == name] == [4, 4]
+
+
+def test_split_f16x2_is_22_bit():
+    rng = np.random.default_rng(0)
+    x = (rng.uniform(0.25, 32768.0, 20000) * rng.choice([-1, 1], 20000)).astype(np.float32)
+    hi, lo = CN.split_f16x2(x)
+    rec = hi.astype(np.float64) + lo.astype(np.float64)
+    assert np.max(np.abs(rec - x) / np.abs(x)) < 2.0 ** -21.9
+    w = rng.standard_normal((128, 128)).astype(np.float32) * 0.09
+    ew = CN.f16_weight_exponent(w)
+    assert 2.0 ** 13 <= np.abs(w).max() * 2.0 ** ew < 2.0 ** 14
