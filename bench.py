@@ -2,7 +2,6 @@
 """bench.py — rendered rays/sec of the MatchNeRF hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full pass of the hot path over one synthetic batch of BASELINE config[1]:
 ``MatchNeRF.forward(batch, mode='test')`` for a 3-view 512x640 DTU-shaped scene with 64
@@ -10,27 +9,38 @@ samples/ray — the GMFlow encoder on the 3 source views plus all 327,680 target
 (encoder INCLUDED in the timed region; render-only rate reported separately under
 ``config``).  Inputs are resident in HBM when the timed region starts.  Arithmetic is fp32
 ("f32": the 1e-4 RGB parity gate cannot be met in bf16): fp32 data, fp32
-accumulation everywhere; the decoder's matrix products run either on the exact-f32 MFMA
-(MNERF_DECODER_MATH=f32) or, by default, as fp32-grade products assembled from three bf16 terms
-per operand on the bf16 MFMA ("bf16x6", DESIGN.md §5: error not above an fp32 FMA chain's).
+accumulation everywhere; the decoder's matrix products run, by MNERF_DECODER_MATH, as
+  f16x3  (default) fp32 operands as two range-managed fp16 terms, 3 products per MAC on the fp16 MFMA,
+  bf16x6 fp32 operands as three bf16 terms, 6 products per MAC on the bf16 MFMA,
+  f32    the exact-f32 MFMA;
+all three are checked against the reference to the same tolerances.
 
-N > 1: one process per GPU (RCCL); every rank encodes the shared source views and renders a
-DIFFERENT target view (weak scaling: BASELINE config[3], "target views sharded across GPUs"),
-then one all_gather returns every rank's [327680,5] tile to all ranks.  value = all rays of
-all ranks / max-over-ranks time.
+N > 1: one process per GPU over RCCL.  Started WITHOUT a launcher (``python bench.py --gpus N``)
+the script re-executes itself under ``torch.distributed.run`` with N ranks on 127.0.0.1; started
+under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.  Every rank encodes
+the shared source views and renders a DIFFERENT target view (weak scaling: BASELINE config[3],
+"target views sharded across GPUs"), then one all_gather returns every rank's [327680,5] tile to
+all ranks.  value = all rays of all ranks / max-over-ranks time.
 
-Also printed in the same JSON line:
-  roofline     dominant kernel (fused decoder): FLOPs per launch / average launch duration measured
-               with events on the launch stream inside the timed region.  f32 math: algorithmic
-               FLOPs (258,336 + 64*S per sample) vs the 157.3 TFLOP/s f32-MFMA peak.
-               bf16x6 math: the matrix FLOPs actually issued (6 bf16 products per algorithmic MLP
-               MAC) vs the 2.5 PFLOP/s dense bf16 peak; the algorithmic rate is reported next to it.
-  cpu_baseline the CPU oracle (a port of the reference path, pinned to it by goldens) timed
-               on this host's cores on a bounded sample (rank 0, N=1 only).
+Also in the JSON line (N = 1):
+  roofline      the dominant kernel (fused decoder), SURVEY.md §8(d): ALGORITHMIC FLOPs per launch
+                (258,336 + 64 S per sample) / average launch duration measured with events on the launch
+                stream inside the timed region, against the f32-MFMA peak that §8(d) declares binding in
+                parity mode (157.3 TFLOP/s) — the split paths run on the 16-bit matrix pipe, so this
+                fraction can exceed 1; next to it the same rate against the 2.5 PFLOP/s dense 16-bit peak,
+                the pipe utilisation (issued products / 2.5 PFLOP/s), the measured MFMA-busy fraction and
+                HBM-side bytes per launch from the committed PMC passes (profiles/decoder_counters.json,
+                ignored when the kernel sources changed since), and the §8(d) rays/s form.
+  config        secondary workloads timed outside the timed region: BASELINE config[2] (Blender-like
+                800x800, 128 samples/ray) and config[4] (10 source views, 512x640).
+  cpu_baseline  the CPU oracle (a port of the reference path, pinned to it by goldens) timed on this
+                host's cores: one encoder pass + one full 4096-ray chunk, best of 3.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,54 +48,58 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 H, W, V, S, CHUNK = 512, 640, 3, 64, 4096
-CPU_RAYS = 1024      # rays of the bounded CPU-baseline sample
-CPU_THREADS_MAX = 16 # torch intra-op threads for the CPU baseline (more threads than this is
-                     # slower on the small tensors of this path: 256 threads measured 14x slower)
-F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (same table)
-BF16_32X32X16_SUSTAINED_TFLOPS = 1860.0  # measured on MI355X: register-only stream of independent
-                                         # v_mfma_f32_32x32x16_bf16 (tools/exp/bf16x6.hip, pure_kernel)
-MLP_FLOPS_PER_SAMPLE = 258336  # the MLP part of SURVEY.md §8(d): runs as 6 bf16 products per MAC in bf16x6 math
-
-
-def measured_traffic(launch_rays):
-    """HBM-side bytes per decoder launch from the committed rocprofv3 PMC passes (bench.py cannot
-    run the profiler itself); None when the launch size differs from the profiled one."""
-    try:
-        with open(os.path.join(REPO, "profiles", "decoder_traffic.json")) as f:
-            t = json.load(f)
-        return t["hbm_bytes_per_launch"] if t["launch_rays"] == launch_rays else None
-    except Exception:  # noqa: BLE001
-        return None
+CPU_RAYS = 4096      # one full chunk of the reference's slicing loop (matchnerf.py:145-161, rand_rays_test)
+CPU_THREADS_MAX = 16  # torch intra-op threads for the CPU baseline (more threads than this is
+                      # slower on the small tensors of this path: 256 threads measured 14x slower)
+F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+DENSE16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (same table)
+HBM_PEAK_BYTES = 8.0e12
+MLP_FLOPS_PER_SAMPLE = 258336   # the Linear layers of SURVEY.md §8(d); they run as 3 (f16x3) / 6 (bf16x6) products per MAC
+PRODUCTS_PER_MAC = {"f16x3": 3, "bf16x6": 6, "f32": 1}
+GATHER_BYTES_PER_SAMPLE = 24720  # §8(d): fp32 taps, no-reuse model, V = 3
 
 
 def flops_per_sample(s):
     return 258336 + 64 * s  # SURVEY.md §8(d)
 
 
-def build_model(device):
+def measured_counters(kernel_prefix):
+    """PMC-derived figures of the decoder kernel from the committed rocprofv3 passes (bench.py cannot run the
+    profiler itself): HBM-side bytes per launch and MFMA-busy fraction — None when the file is missing or was
+    collected on other kernel sources than the ones in the tree (build hash)."""
+    from matchnerf_amd.csrc.build import source_hash
+    try:
+        with open(os.path.join(REPO, "profiles", "decoder_counters.json")) as f:
+            c = json.load(f)
+    except Exception:  # noqa: BLE001
+        return None
+    if c.get("build_hash") != source_hash() or not str(c.get("kernel", "")).startswith(kernel_prefix):
+        return dict(stale=True, build_hash_profiled=c.get("build_hash"), build_hash_now=source_hash())
+    return c
+
+
+def build_model(device, n_views=V, n_samples=S):
+    import torch  # noqa: F401
     from matchnerf_amd import options, synthetic as syn
     from matchnerf_amd.models import models_dict
     opt = options.load_options("configs/test.yaml", verbose=False)
     opt.device = str(device)
-    opt.n_src_views = V
-    opt.nerf.sample_intvs = S
+    opt.n_src_views = n_views
+    opt.nerf.sample_intvs = n_samples
     opt.nerf.rand_rays_test = CHUNK
     model = models_dict[opt.model](opt).to(device).eval()
-    weights = syn.seeded_state_dict(syn.state_dict_spec(n_src_views=V), 1)
+    weights = syn.seeded_state_dict(syn.state_dict_spec(n_src_views=n_views), 1)
     model.load_state_dict(syn.to_torch(weights, device))
     return opt, model, weights
 
 
-def make_batch(device, target_shift):
+def make_batch(device, target_shift, height=H, width=W, n_views=V, **scene_kw):
     """Synthetic DTU-shaped scene; ``target_shift`` moves the target camera (one view per rank)."""
+    import torch
     from matchnerf_amd import synthetic as syn
     from matchnerf_amd.edict import EasyDict
-    sc = syn.make_scene(H, W, V, seed=0)
+    sc = syn.make_scene(height, width, n_views, seed=scene_kw.pop("seed", 0), **scene_kw)
     if target_shift:
         ext = sc["extrinsics"].copy()
         ext[0, -1, 0, 3] += 0.04 * target_shift  # slide the target along x (camera frame)
@@ -94,9 +108,9 @@ def make_batch(device, target_shift):
 
 
 def cpu_baseline(weights, scene, n_threads):
-    """Oracle timed on the host: 1 encoder pass + 1 slice of CPU_RAYS rays, extrapolated to a
-    full frame (the reference's own loop structure, matchnerf.py:145-161).  Bounded sample:
-    ~10-30 s of CPU work."""
+    """Oracle timed on the host: 1 encoder pass + one full chunk of CPU_RAYS rays (best of 3), extrapolated to
+    a full frame (the reference's own loop structure, matchnerf.py:145-161)."""
+    import torch
     from matchnerf_amd import synthetic as syn
     from oracle import matchnerf_oracle as O
     torch.set_num_threads(n_threads)
@@ -109,16 +123,67 @@ def cpu_baseline(weights, scene, n_threads):
         feats = O.encode_pairs(cfg, sd, imgs)
         t_enc = time.perf_counter() - t0
         idx = torch.arange(100 * W, 100 * W + CPU_RAYS)
-        t0 = time.perf_counter()
-        O.render_rays(cfg, sd, idx, b["extrinsics"][0, -1, :3], b["intrinsics"][0, -1], b["near_fars"][0, -1],
-                      b["extrinsics"][0, :-1, :3], b["intrinsics"][0, :-1], b["near_fars"][0, :-1], imgs, feats)
-        t_chunk = time.perf_counter() - t0
+        t_chunks = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.render_rays(cfg, sd, idx, b["extrinsics"][0, -1, :3], b["intrinsics"][0, -1], b["near_fars"][0, -1],
+                          b["extrinsics"][0, :-1, :3], b["intrinsics"][0, :-1], b["near_fars"][0, :-1], imgs, feats)
+            t_chunks.append(time.perf_counter() - t0)
+    t_chunk = min(t_chunks)
     n_chunks = H * W / CPU_RAYS
     frame_s = t_enc + n_chunks * t_chunk
     return dict(value=round(H * W / frame_s, 2), unit="rays/s", cores=n_threads, kind="port",
-                sample=f"oracle (torch-CPU port of the reference path): 1 encoder pass ({t_enc:.2f} s) + 1 slice of "
-                       f"{CPU_RAYS} rays ({t_chunk:.2f} s), extrapolated to a {H * W}-ray frame",
+                sample=f"oracle (torch-CPU port of the reference path): 1 encoder pass ({t_enc:.2f} s) + one full chunk of "
+                       f"{CPU_RAYS} rays, best of 3 ({', '.join(f'{t:.2f}' for t in t_chunks)} s), extrapolated to a "
+                       f"{H * W}-ray frame",
                 render_only_rays_per_s=round(CPU_RAYS / t_chunk, 2))
+
+
+def secondary_workload(device, name, n_views, n_samples, height, width, bg, **scene_kw):
+    """One of the other BASELINE configs at full size, outside the timed region: frame time incl. encoder."""
+    import torch
+    from matchnerf_amd import hip
+    opt, model, _ = build_model(device, n_views, n_samples)
+    model.nerf_setbg_opaque = bg
+    _, batch = make_batch(device, 0, height, width, n_views, **scene_kw)
+    with torch.no_grad():
+        out = model(batch, mode="test")  # warm-up (MIOpen find, weight packing)
+        timer = hip.KernelTimer()
+        model.kernel_timer = timer
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            out = model(batch, mode="test")
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 2 * 1e3
+        model.kernel_timer = None
+        t0 = time.perf_counter()
+        model.get_img_feat(batch.images[:, :n_views], cur_n_src_views=n_views)
+        torch.cuda.synchronize()
+        enc_ms = (time.perf_counter() - t0) * 1e3
+    k = timer.summary()
+    ok = bool(torch.isfinite(out.rgb).all())
+    del model, batch, out
+    torch.cuda.empty_cache()
+    n = height * width
+    return {"workload": name, "rays_per_s": round(n / (ms * 1e-3), 1), "ms_per_frame": round(ms, 3),
+            "encoder_ms": round(enc_ms, 3), "cost_volume_ms": round(k["cost_volume"]["total_ms"] / 2, 3),
+            "decoder_ms": round(k["decoder"]["total_ms"] / 2, 3), "finite": ok}
+
+
+def respawn_under_launcher(args):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script with torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -127,15 +192,22 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config[2] / config[4] timings")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_launcher(args))
+
+    import torch
     from matchnerf_amd import dist as mdist
     from matchnerf_amd import hip
-    rank, world, device = mdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
+    if "MNERF_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")):
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    rank, world, device = mdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     hip.load()
     torch.backends.cudnn.benchmark = True  # MIOpen find mode for the backbone convolutions
 
@@ -166,52 +238,75 @@ def main():
 
     ksum = timer.summary()
     model.kernel_timer = None
-    # encoder-only and render-only rates (outside the timed region, rank-local)
+    # encoder-only rate (outside the timed region, rank-local)
     with torch.no_grad():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(3):
-            feats = model.get_img_feat(batch.images[:, :V], cur_n_src_views=V)
+            model.get_img_feat(batch.images[:, :V], cur_n_src_views=V)
         torch.cuda.synchronize()
         enc_ms = (time.perf_counter() - t1) / 3 * 1e3
 
-    # secondary figure (N=1, outside the timed region): the same frame with the decoder's matrix products on
-    # the exact-f32 MFMA instead of the default split-bf16 path, and the largest RGB difference between the two
-    exact_f32 = None
+    # secondary figures (N=1, outside the timed region): the same frame with the other decoder matrix paths, and the
+    # largest RGB difference to the default path
     from matchnerf_amd.cond_nerf import decoder_math
-    if world == 1 and decoder_math() == "bf16x6" and S <= 128:
-        rgb_split = full[:, :3].clone()
-        os.environ["MNERF_DECODER_MATH"] = "f32"
+    math = model.nerf_dec.math_for(S)
+    other_math = {}
+    if world == 1:
+        rgb_default = full[:, :3].clone()
+        keep = os.environ.get("MNERF_DECODER_MATH")
         try:
-            step()  # re-packs the weight stream
-            t32 = hip.KernelTimer()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                full32 = step(t32)
-            torch.cuda.synchronize()
-            ms32 = (time.perf_counter() - t1) / 2 * 1e3
-            exact_f32 = {"rays_per_s": round(n_rays / (ms32 * 1e-3), 1), "ms_per_step": round(ms32, 3),
-                         "decoder_ms_per_frame": round(t32.summary()["decoder"]["total_ms"] / 2, 3),
-                         "rgb_linf_vs_default_math": float((full32[:, :3] - rgb_split).abs().max())}
+            for m in ("f16x3", "bf16x6", "f32"):
+                if m == math:
+                    continue
+                os.environ["MNERF_DECODER_MATH"] = m
+                step()  # re-packs the weight stream
+                tm = hip.KernelTimer()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    fullm = step(tm)
+                torch.cuda.synchronize()
+                msm = (time.perf_counter() - t1) / 2 * 1e3
+                other_math[m] = {"rays_per_s": round(n_rays / (msm * 1e-3), 1), "ms_per_step": round(msm, 3),
+                                 "decoder_ms_per_frame": round(tm.summary()["decoder"]["total_ms"] / 2, 3),
+                                 "rgb_linf_vs_default_math": float((fullm[:, :3] - rgb_default).abs().max())}
         finally:
-            os.environ["MNERF_DECODER_MATH"] = "bf16x6"
+            if keep is None:
+                os.environ.pop("MNERF_DECODER_MATH", None)
+            else:
+                os.environ["MNERF_DECODER_MATH"] = keep
             model.kernel_timer = None
+        assert decoder_math() == math or S > 128
+
+    secondary = []
+    if world == 1 and not args.no_secondary:
+        del full
+        torch.cuda.empty_cache()
+        secondary.append(secondary_workload(device, "BASELINE config[2]: Blender-like 3-view 800x800, 128 samples/ray, "
+                                            "white background, full frame incl. encoder", 3, 128, 800, 800, True,
+                                            seed=31, wide=True, focal_scale=1.389, near_far=(2.0, 6.0)))
+        secondary.append(secondary_workload(device, "BASELINE config[4]: 10 source views 512x640, 64 samples/ray "
+                                            "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
+                                            10, 64, 512, 640, False, seed=32))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n_rays * args.steps / elapsed
         dec = ksum["decoder"]
-        math = decoder_math() if S <= 128 else "f32"
-        samples_launch = dec["rays"] / dec["launches"] * S
+        launch_rays = dec["rays"] / dec["launches"]
+        samples_launch = launch_rays * S
         flops_launch = samples_launch * flops_per_sample(S)
-        algorithmic = flops_launch / (dec["avg_ms"] * 1e-3) / 1e12
-        if math == "bf16x6":
-            issued_launch = samples_launch * (6 * MLP_FLOPS_PER_SAMPLE + (flops_per_sample(S) - MLP_FLOPS_PER_SAMPLE))
-            achieved, peak = issued_launch / (dec["avg_ms"] * 1e-3) / 1e12, BF16_MFMA_PEAK_TFLOPS
-        else:
-            issued_launch, achieved, peak = flops_launch, algorithmic, F32_MFMA_PEAK_TFLOPS
+        secs = dec["avg_ms"] * 1e-3
+        algorithmic = flops_launch / secs / 1e12
+        ppm = PRODUCTS_PER_MAC[math]
+        issued_launch = samples_launch * (ppm * MLP_FLOPS_PER_SAMPLE + (flops_per_sample(S) - MLP_FLOPS_PER_SAMPLE))
         render_ms = (dec["total_ms"] + ksum["cost_volume"]["total_ms"]) / args.steps
+        render_rate = n_rays / (render_ms * 1e-3)
+        counters = measured_counters("decoder_kernel") if math == decoder_math() else None
+        fresh = bool(counters) and not counters.get("stale")
+        mfma_bound = F32_MFMA_PEAK_TFLOPS * 1e12 / (S * flops_per_sample(S))
+        gather_bound = HBM_PEAK_BYTES / (S * GATHER_BYTES_PER_SAMPLE)
         line = {
             "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -219,29 +314,50 @@ def main():
             "config": {
                 "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
                             "(327680 rays) per step incl. GMFlow encoder; fp32 parity mode",
-                "decoder_math": math if math == "f32" else
-                "bf16x6: fp32 operands as 3 bf16 terms, 6 products per MAC on the bf16 MFMA, fp32 accumulate "
-                "(error <= an fp32 FMA chain's; DESIGN.md section 4)",
-                "exact_f32_mfma_path": exact_f32,
-                "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(dec["rays"] / dec["launches"]),
+                "decoder_math": {"f16x3": "f16x3: fp32 operands as 2 range-managed fp16 terms, 3 products per MAC on the "
+                                          "fp16 MFMA, fp32 accumulate (DESIGN.md section 4)",
+                                 "bf16x6": "bf16x6: fp32 operands as 3 bf16 terms, 6 products per MAC on the bf16 MFMA, "
+                                           "fp32 accumulate",
+                                 "f32": "f32: exact-f32 MFMA"}[math],
+                "other_decoder_math": other_math or None,
+                "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(launch_rays),
                 "parallelism": f"target views x{world}" if world > 1 else "single GPU",
                 "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
-                "render_only_rays_per_s_per_gpu": round(n_rays / (render_ms * 1e-3), 1),
+                "render_only_rays_per_s_per_gpu": round(render_rate, 1),
                 "cost_volume_ms_per_frame": round(ksum["cost_volume"]["total_ms"] / args.steps, 3),
                 "decoder_ms_per_frame": round(dec["total_ms"] / args.steps, 3),
+                "secondary_workloads": secondary or None,
             },
-            "roofline": {"bound": "mfma", "kernel": "decoder_kernel<4> (fused MLP + ray transformer + compositing)",
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         "math": math, "algorithmic_tflops": round(algorithmic, 2),
-                         "instruction_ceiling": ({"tflops": BF16_32X32X16_SUSTAINED_TFLOPS,
-                                                  "frac": round(achieved / BF16_32X32X16_SUSTAINED_TFLOPS, 4),
-                                                  "what": "sustained rate of a register-only v_mfma_f32_32x32x16_bf16 "
-                                                          "stream measured on this GPU model"} if math == "bf16x6" else None),
-                         "issued_flops_per_launch": issued_launch,
-                         "traffic": measured_traffic(int(dec["rays"] / dec["launches"])),
-                         "avg_launch_ms": round(dec["avg_ms"], 4),
-                         "flops_per_launch": flops_launch},
+            "roofline": {
+                "bound": "mfma", "kernel": "decoder_kernel<4,64> (fused MLP + ray transformer + compositing)",
+                "achieved": round(algorithmic, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
+                "what": "ALGORITHMIC FLOPs (SURVEY.md 8d: 258336 + 64 S per sample) / measured launch time vs the f32-MFMA "
+                        "peak that 8d declares binding in fp32 parity mode; > 1 is possible because the split paths "
+                        "compute fp32-grade products on the 16-bit matrix pipe",
+                "math": math, "algorithmic_tflops": round(algorithmic, 2),
+                "frac_of_dense_16bit_peak": round(algorithmic / DENSE16_MFMA_PEAK_TFLOPS, 4),
+                "mfma_pipe_frac": round(issued_launch / secs / 1e12 / DENSE16_MFMA_PEAK_TFLOPS, 4) if math != "f32"
+                else round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
+                "mfma_pipe_what": f"matrix FLOPs actually issued ({ppm} products per MLP MAC) / launch time vs the "
+                                  f"{'2.5 PFLOP/s dense 16-bit' if math != 'f32' else '157.3 TFLOP/s f32'} MFMA peak",
+                "mfma_busy_measured": counters.get("mfma_busy_frac") if fresh else None,
+                "traffic": counters.get("hbm_bytes_per_launch") if fresh else None,
+                "traffic_algorithmic_bytes": int(samples_launch * 96 + launch_rays * 20),
+                "counters_source": (counters.get("source") if fresh else
+                                    ("profiles/decoder_counters.json is stale or absent: re-run tools/profile_round.sh" if
+                                     counters is None or counters.get("stale") else None)),
+                "avg_launch_ms": round(dec["avg_ms"], 4), "flops_per_launch": flops_launch,
+                "issued_flops_per_launch": issued_launch,
+                "rays_form": {
+                    "what": "SURVEY.md 8d: render-only rays/s / min(MFMA_peak / F_ray, HBM_BW / B_ray), fp32 parity mode",
+                    "render_only_rays_per_s": round(render_rate, 1),
+                    "mfma_f32_bound_rays_per_s": round(mfma_bound, 1),
+                    "gather_hbm_no_reuse_bound_rays_per_s": round(gather_bound, 1),
+                    "frac_of_mfma_bound": round(render_rate / mfma_bound, 4),
+                    "frac_of_min_bound": round(render_rate / min(mfma_bound, gather_bound), 4),
+                },
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights, scene, min(os.cpu_count() or 1, CPU_THREADS_MAX))

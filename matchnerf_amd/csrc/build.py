@@ -15,6 +15,19 @@ SOURCES = ["api.cpp", "composite.hip", "cost_volume.hip", "decoder.hip", "geomet
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 over the kernel sources and the ABI header: identifies the build that profile-derived numbers
+    (profiles/decoder_counters.json) belong to, so that bench.py can tell when they have gone stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + ["common.hpp"]):
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(PKG, "..", "include", "mnerf.h"), "rb") as f:
+        h.update(b"mnerf.h\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 

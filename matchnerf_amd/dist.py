@@ -50,19 +50,26 @@ def shard_rows(height, width, rank, world):
 
 def gather_tiles(local, counts=None):
     """All ranks receive the concatenation of every rank's ``local`` [n_r, C] tile, in rank
-    order.  ``counts`` = per-rank row counts (needed when they differ: tiles are padded to the
-    largest and trimmed after the collective, so a single all_gather_into_tensor suffices)."""
+    order.  ``counts`` = per-rank row counts; when omitted they are exchanged first (one int per rank), so
+    ragged tiles (height % world != 0) never reach the collective with mismatched sizes.  Tiles are padded to
+    the largest and trimmed after the collective, so a single all_gather_into_tensor suffices."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_host = dist.get_backend() == "gloo"
     if counts is None:
-        counts = [local.shape[0]] * world
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device="cpu" if on_host else local.device)
+        allc = torch.empty(world, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(allc, mine)
+        counts = [int(c) for c in allc.tolist()]
+    if len(counts) != world or counts[rank] != local.shape[0]:
+        raise ValueError(f"gather_tiles: rank {rank} holds {local.shape[0]} rows, counts={list(counts)} (world {world})")
     width = max(counts)
     send = local
     if local.shape[0] != width:
         send = local.new_zeros((width,) + tuple(local.shape[1:]))
         send[:local.shape[0]] = local
-    if send.is_cuda and dist.get_backend() == "gloo":  # dry-run path: stage through the host
+    if send.is_cuda and on_host:  # dry-run path (gloo with GPU tensors): stage through the host
         host = send.contiguous().cpu()
         out_h = host.new_empty((world * width,) + tuple(host.shape[1:]))
         dist.all_gather_into_tensor(out_h, host)
@@ -73,6 +80,29 @@ def gather_tiles(local, counts=None):
     if all(c == width for c in counts):
         return out
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], 0)
+
+
+def render_frame_sharded(model, batch, mode="test"):
+    """BASELINE config[3], row-tile form: every rank encodes the (replicated) source views, renders its
+    contiguous band of rows of the target view through the HIP path, and ONE all_gather returns the
+    [rays_local, 5] tiles (rgb, depth, opacity) to all ranks.  -> edict(rgb [B,HW,3], depth [B,HW,1],
+    opacity [B,HW,1]), identical on every rank and bit-identical to the unsharded ``model(batch, mode)``
+    (rays are independent; tests/test_dist_gpu.py)."""
+    from .edict import EasyDict as edict
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    ref_images = batch.images[:, :model.n_src_views]
+    feats = model.get_img_feat(ref_images, cur_n_src_views=model.n_src_views)
+    tgt_pose, ref_poses = model.extract_poses(batch)
+    b, _, _, h, w = ref_images.shape
+    first, n = shard_rows(h, w, rank, world)
+    idx = torch.arange(first, first + n, device=ref_images.device)
+    out = model.render(model.opts, tgt_pose, ray_idx=idx, mode=mode, ref_poses=ref_poses, ref_images=ref_images,
+                       ref_feats_list=feats)
+    tile = torch.cat([out.rgb, out.depth, out.opacity], -1).permute(1, 0, 2).reshape(n, b * 5)   # rows = rays
+    full = gather_tiles(tile, [shard_rows(h, w, r, world)[1] for r in range(world)])
+    full = full.reshape(h * w, b, 5).permute(1, 0, 2)
+    return edict(rgb=full[..., :3].contiguous(), depth=full[..., 3:4].contiguous(), opacity=full[..., 4:5].contiguous())
 
 
 def barrier():

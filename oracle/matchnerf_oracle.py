@@ -288,7 +288,8 @@ def decoder(cfg, sd, x_ref, dir_ref, cond, mask):
 
 
 def composite(cfg, ray, rgb, sigma, depth, setbg_opaque=False):
-    """models/rfdecoder/nerf.py:101-124.  ray [R,3], rgb [R,S,3], sigma [R,S], depth [R,S]."""
+    """models/rfdecoder/nerf.py:101-124.  ray [R,3], rgb [R,S,3], sigma [R,S], depth [R,S]
+    -> rgb [R,3], depth [R,1], opacity [R,1], prob [R,S,1] (the reference's four return values)."""
     if cfg.wo_render_interval:
         sd_ = sigma
     else:
@@ -302,7 +303,7 @@ def composite(cfg, ray, rgb, sigma, depth, setbg_opaque=False):
     opacity = w.sum(1, keepdim=True)
     if setbg_opaque:
         out_rgb = out_rgb + (1 - opacity)
-    return out_rgb, out_depth, opacity
+    return out_rgb, out_depth, opacity, w[..., None]
 
 
 # =============================================================================== a7 render
@@ -320,7 +321,7 @@ def render_rays(cfg, sd, ray_idx, tgt_extr, tgt_intr, tgt_nf, src_extr, src_intr
     x_ref = project_to_view(pts, src_extr[0], src_intr[0], width, height, src_nf[0, 0], src_nf[0, 1])
     dir_ref = F.normalize(ray, dim=-1) @ src_extr[0][:, :3].t()
     rgb_s, sigma = decoder(cfg, sd, x_ref, dir_ref, cond, mask)
-    rgb, depth, opacity = composite(cfg, ray, rgb_s, sigma, d, setbg_opaque)
+    rgb, depth, opacity, _ = composite(cfg, ray, rgb_s, sigma, d, setbg_opaque)
     if return_stages:
         return dict(rgb=rgb, depth=depth, opacity=opacity, cond=cond, x_ref=x_ref, dir_ref=dir_ref,
                     rgb_samples=rgb_s, sigma=sigma, depth_samples=d, ray=ray, center=center)

@@ -16,6 +16,7 @@ def cfg_from_meta(meta):
         raytrans_act=ov.get("decoder.raytrans_act", "ReLU"),
         legacy_coord=ov.get("nerf.legacy_coord", True),
         wo_render_interval=ov.get("nerf.wo_render_interval", True),
+        depth_param=ov.get("nerf.depth.param", "metric"),
         attn_splits=ov.get("encoder.attn_splits_list", [2])[0])
 
 

@@ -32,6 +32,13 @@ def _worker(rank, world, port, height, width, q):
     counts = [mdist.shard_rows(height, width, i, w)[1] for i in range(w)]
     full = mdist.gather_tiles(_fake_render(first, n), counts)
     ok = torch.equal(full, _fake_render(0, height * width))
+    # without counts the (possibly ragged) row counts are exchanged first
+    ok = ok and torch.equal(mdist.gather_tiles(_fake_render(first, n)), full)
+    try:
+        mdist.gather_tiles(_fake_render(first, n), [n + 1] * w)
+        ok = False
+    except ValueError:
+        pass
     # view sharding (weak scaling): each rank owns whole frames
     v0, vn = mdist.shard_range(5, r, w)
     frames = torch.cat([_fake_render(v * 7, 7) for v in range(v0, v0 + vn)], 0)
@@ -67,3 +74,20 @@ def test_shard_range_partitions_exactly():
             for (b0, c0), (b1, _) in zip(spans, spans[1:]):
                 assert b0 + c0 == b1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_bench_respawns_itself_under_the_launcher(monkeypatch):
+    """`python bench.py --gpus N` without RANK/WORLD_SIZE (how the driver starts it) must start N ranks itself."""
+    import argparse
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    rc = bench.respawn_under_launcher(argparse.Namespace(gpus=4, steps=7, warmup=2, no_cpu_baseline=False))
+    cmd = seen["cmd"]
+    assert rc == 0 and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ

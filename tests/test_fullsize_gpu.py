@@ -3,7 +3,11 @@
 * a Blender-like 128-sample case with white background (config[2] class) vs the oracle;
 * at the FULL benchmark size (512x640, 3 views, 64 samples) size-independent properties:
   ray-subset consistency (bit-exact), chunk-boundary invariance, closed-form opacity,
-  compositing bounds, cost-volume range — the oracle cannot cover 21 M samples in seconds."""
+  compositing bounds, cost-volume range — the oracle cannot cover 21 M samples in seconds;
+* BASELINE config[2] (Blender-like 800x800, 128 samples/ray, white background: 2500-token attention windows of a
+  100x100 map) and config[4] (10 source views at 512x640: 45 view pairs, 1.18 GB of feature maps that do not fit
+  the 256 MiB Infinity Cache) AT FULL SIZE: the same properties plus a 256-ray slab rendered by the CPU oracle
+  from the very feature maps the GPU encoder produced."""
 import numpy as np
 import pytest
 import torch
@@ -142,3 +146,100 @@ def test_fullsize_opacity_closed_form_and_cost_volume_range(full_frame):
     m = c[..., 19:22]
     assert bool(((m == 0) | (m == 1)).all())
     assert float((c[..., 22] - 1).abs().max()) == 0
+
+
+# ----------------------------------------------------------------------------- config[2] / config[4] at full size
+
+FULL_CASES = {
+    "c3_blender_800": dict(n_views=3, S=128, hw=(800, 800), scene=dict(seed=31, wide=True, focal_scale=1.389, near_far=(2.0, 6.0)),
+                           bg=True),
+    "c5_ten_views": dict(n_views=10, S=64, hw=(512, 640), scene=dict(seed=32), bg=False),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(FULL_CASES))
+def big_frame(request):
+    c = FULL_CASES[request.param]
+    opt, model, sd = build(n_views=c["n_views"], S=c["S"])
+    model.nerf_setbg_opaque = c["bg"]
+    h, w = c["hw"]
+    scene = syn.make_scene(h, w, c["n_views"], **c["scene"])
+    batch = gpu_batch(scene)
+    with torch.no_grad():
+        feats = model.get_img_feat(batch.images[:, :c["n_views"]], cur_n_src_views=c["n_views"])
+        model.get_img_feat = lambda *a, **k: feats
+        out = model(batch, mode="test")
+        rgb, depth, opacity = out.rgb.clone(), out.depth.clone(), out.opacity.clone()
+    yield request.param, c, opt, model, sd, batch, scene, feats, rgb, depth, opacity
+    del model, feats
+    torch.cuda.empty_cache()
+
+
+def test_big_frame_outputs_are_finite_and_bounded(big_frame):
+    name, c, _, _, _, _, scene, feats, rgb, depth, opacity = big_frame
+    h, w = c["hw"]
+    p = c["n_views"] * (c["n_views"] - 1) // 2
+    assert rgb.shape == (1, h * w, 3) and feats[0].shape == (1, p, 2, h // 8, w // 8, 128)
+    for t in (rgb, depth, opacity):
+        assert bool(torch.isfinite(t).all())
+    assert float(opacity.min()) >= 0 and float(opacity.max()) <= 1 + 1e-5
+    assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 + 1e-5
+    near, far = scene["near_fars"][0, -1]
+    assert float(depth.max()) <= far * (1 + 1e-5) and float((depth - opacity * near).min()) >= -1e-4
+    assert float(rgb.std()) > 1e-3   # not a constant image
+
+
+def test_big_frame_ray_subset_is_bit_identical(big_frame):
+    name, c, opt, model, _, batch, _, feats, rgb, depth, opacity = big_frame
+    h, w = c["hw"]
+    idx = torch.randperm(h * w, generator=torch.Generator().manual_seed(9))[:3000].cuda()
+    tgt, ref = model.extract_poses(batch)
+    with torch.no_grad():
+        sub = model.render(opt, tgt, ray_idx=idx, mode="test", ref_poses=ref, ref_images=batch.images[:, :c["n_views"]],
+                           ref_feats_list=feats)
+    assert torch.equal(sub.rgb[0], rgb[0, idx]) and torch.equal(sub.opacity[0], opacity[0, idx])
+    assert torch.equal(sub.depth[0], depth[0, idx])
+
+
+def test_big_frame_slab_matches_oracle(big_frame):
+    """256 rays from the middle of the frame rendered by the CPU oracle from the GPU encoder's own feature maps
+    (so the comparison isolates the render path at full size: real map sizes, real pair counts)."""
+    name, c, _, _, sd, batch, scene, feats, rgb, depth, opacity = big_frame
+    h, w = c["hw"]
+    v = c["n_views"]
+    first = (h // 2) * w + w // 3
+    idx = torch.arange(first, first + 256)
+    pair_feats = [(f[0, :, 0].permute(0, 3, 1, 2).cpu(), f[0, :, 1].permute(0, 3, 1, 2).cpu()) for f in feats]
+    b = {k: torch.from_numpy(val) for k, val in scene.items()}
+    cfg = O.OracleConfig(n_src_views=v, sample_intvs=c["S"])
+    te, ti, tn = b["extrinsics"][0, -1, :3], b["intrinsics"][0, -1], b["near_fars"][0, -1]
+    se, si, sn = b["extrinsics"][0, :-1, :3], b["intrinsics"][0, :-1], b["near_fars"][0, :-1]
+    with torch.no_grad():
+        ref = O.render_rays(cfg, sd, idx, te, ti, tn, se, si, sn, b["images"][0, :v], pair_feats, c["bg"])
+    assert linf(rgb[0, idx], ref[0]) < 1e-4
+    assert linf(opacity[0, idx], ref[2]) < 1e-4
+    assert linf(depth[0, idx], ref[1]) < 3e-4 * (6.0 / 4.5 if c["bg"] else 1.0)
+
+
+def test_big_frame_opacity_closed_form(big_frame):
+    """opacity = 1 - exp(-sum sigma) on a slab through the staged C-ABI entry points; masks exactly 0/1."""
+    from matchnerf_amd import camera, hip
+    name, c, opt, model, _, batch, _, feats, rgb, depth, opacity = big_frame
+    h, w = c["hw"]
+    v, S = c["n_views"], c["S"]
+    n0, n = (h // 3) * w, 2048
+    tgt, ref = model.extract_poses(batch)
+    ref_host, images_cl = model._frame_ctx(ref, batch.images[:, :v])
+    sc = model._scene(0, ref_host, feats, images_cl)
+    dec = model._decoder(S, torch.device("cuda"))
+    t_ex, t_in, t_nf = model._tgt_host(tgt)
+    kinv, c2w = camera.target_ray_consts(t_ex[0], t_in[0], True)
+    rays = hip.make_rays(n, S, h, w, kinv, c2w, t_nf[0, 0], t_nf[0, 1], ray_begin=n0)
+    cond = hip.cost_volume(sc, rays, dec.cond_stride)
+    r, d, o, rgb_s, sigma = hip.decoder_chunk(dec, sc.views[0], rays, cond, want_samples=True)
+    assert torch.equal(o, opacity[0, n0:n0 + n, 0])
+    assert linf(o, 1 - torch.exp(-sigma.sum(1))) < 2e-5
+    cc = cond.reshape(n, S, -1)
+    dc = dec.cond_dim
+    m = cc[..., dc - v:dc]
+    assert bool(((m == 0) | (m == 1)).all()) and float(cc[..., :dc - 4 * v].abs().max()) <= 1 + 1e-5

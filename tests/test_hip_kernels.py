@@ -41,6 +41,10 @@ def test_composite_matches_oracle(hip, S, interval, bg):
     assert linf(out[0], ref[0]) < 2e-6
     assert linf(out[1], ref[1][:, 0]) < 1e-5
     assert linf(out[2], ref[2][:, 0]) < 2e-6
+    # the fourth return value of NeRF.composite (nerf.py:116,124): per-sample weights
+    prob = hip.composite(rgb_s.cuda(), sigma.cuda(), depth.cuda(), ray.norm(dim=-1).cuda().contiguous(),
+                         wo_render_interval=interval, setbg_opaque=bg, want_prob=True)[3]
+    assert linf(prob, ref[3][..., 0]) < 2e-6 and linf(prob.sum(1), out[2]) < 2e-6
 
 
 def test_composite_empty_and_errors(hip):
@@ -76,7 +80,7 @@ def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
             assert linf(out, ref) < 2e-5, (h, w, shifted)
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
 def test_ray_geometry_is_bit_exact(hip, name):
     """world points and ref-view-0 NDC coordinates: identical bits to the reference CPU path."""
     g, cfg, sd, batch = golden_case(name)
@@ -102,7 +106,7 @@ def _case_on_gpu(name):
     return g, cfg, sd, batch, feats_gpu, img_gpu
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
 def test_cost_volume_matches_reference(hip, name):
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
     sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
@@ -120,11 +124,11 @@ def test_cost_volume_matches_reference(hip, name):
     assert bool(((m == 0) | (m == 1)).all())
 
 
-@pytest.mark.parametrize("math", ["bf16x6", "f32"])
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4"])
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
 def test_decoder_chunk_matches_reference(hip, name, math):
-    """Both matrix paths of the fused decoder (split-bf16 on the bf16 MFMA = the default, and the
-    exact-f32 MFMA) against the reference's own per-sample and per-ray outputs, same tolerances."""
+    """All three matrix paths of the fused decoder (split-fp16 on the fp16 MFMA = the default, split-bf16 on the
+    bf16 MFMA, exact-f32 MFMA) against the reference's own per-sample and per-ray outputs, same tolerances."""
     g, cfg, sd, batch, _, _ = _case_on_gpu(name)
     dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
     idx = torch.from_numpy(g["stage_rays"]).int().cuda()
@@ -144,9 +148,9 @@ def test_decoder_chunk_matches_reference(hip, name, math):
 
 @pytest.mark.parametrize("name", ["c1_default", "v4"])
 def test_decoder_math_variants_agree(hip, name):
-    """bf16x6 (three bf16 terms per fp32 operand, six products, fp32 accumulate) is fp32-grade: it
-    agrees with the exact-f32 MFMA path far inside the parity tolerance, and is not further from
-    the reference than that path is."""
+    """The split paths are fp32-grade: bf16x6 (three bf16 terms per operand, six products) and f16x3 (two
+    range-managed fp16 terms, three products), both with fp32 accumulation, agree with the exact-f32 MFMA path
+    far inside the parity tolerance and are not materially further from the reference than that path is."""
     g, cfg, sd, batch, _, _ = _case_on_gpu(name)
     idx = torch.from_numpy(g["stage_rays"]).int().cuda()
     rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
@@ -154,27 +158,29 @@ def test_decoder_math_variants_agree(hip, name):
     view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
                           float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
     out = {}
-    for math in ("bf16x6", "f32"):
+    for math in ("f16x3", "bf16x6", "f32"):
         dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
         cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
         out[math] = [t.cpu() for t in hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)]
-    d_rgb_s = linf(out["bf16x6"][3], out["f32"][3])
-    d_sigma = linf(out["bf16x6"][4], out["f32"][4])
-    d_rgb = linf(out["bf16x6"][0], out["f32"][0])
-    e16, e32 = linf(out["bf16x6"][3], g["rgb_samples"]), linf(out["f32"][3], g["rgb_samples"])
-    print(f"\n[{name}] bf16x6 vs f32-MFMA: rgb_s {d_rgb_s:.2e} sigma {d_sigma:.2e} rgb {d_rgb:.2e};"
-          f" vs reference rgb_s: bf16x6 {e16:.2e}, f32 {e32:.2e}")
-    assert d_rgb_s < 5e-6 and d_rgb < 1e-5
-    assert d_sigma < 1e-5 * max(1.0, float(out["f32"][4].abs().max()))
-    assert e16 < max(2.0 * e32, 2e-6)
+    e32 = linf(out["f32"][3], g["rgb_samples"])
+    for math, tol_s, tol_r in (("bf16x6", 5e-6, 1e-5), ("f16x3", 1e-5, 2e-5)):
+        d_rgb_s = linf(out[math][3], out["f32"][3])
+        d_sigma = linf(out[math][4], out["f32"][4])
+        d_rgb = linf(out[math][0], out["f32"][0])
+        e = linf(out[math][3], g["rgb_samples"])
+        print(f"\n[{name}] {math} vs f32-MFMA: rgb_s {d_rgb_s:.2e} sigma {d_sigma:.2e} rgb {d_rgb:.2e};"
+              f" vs reference rgb_s: {math} {e:.2e}, f32 {e32:.2e}")
+        assert d_rgb_s < tol_s and d_rgb < tol_r
+        assert d_sigma < 2 * tol_s * max(1.0, float(out["f32"][4].abs().max()))
+        assert e < max(2.0 * e32, 2e-6) * (1 if math == "bf16x6" else 2.5)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_decoder_math_variants_agree_on_rescaled_weights(hip, seed):
-    """Robustness of the three-term bf16 split: every decoder tensor rescaled by a random factor in
-    [0.25, 4] (activations then span several orders of magnitude through the FiLM-modulated trunk);
-    the split-bf16 path must track the exact-f32 MFMA path to fp32 noise relative to the magnitudes
-    involved, for the per-sample colours and the unbounded density."""
+    """Robustness of the operand splits: every decoder tensor rescaled by a random factor in [0.25, 4]
+    (activations then span several orders of magnitude through the FiLM-modulated trunk - the case the
+    per-sample fp16 gains exist for); the split paths must track the float64 evaluation of the same network as
+    well as the exact-f32 MFMA path does, for the per-sample colours and the unbounded density."""
     g, cfg, sd, batch, _, _ = _case_on_gpu("c1_default")
     rng = np.random.default_rng(seed)
     sd2 = {k: (v * float(2.0 ** rng.uniform(-2, 2)) if k.startswith("nerf_dec.") and v.dtype.is_floating_point else v)
@@ -185,28 +191,77 @@ def test_decoder_math_variants_agree_on_rescaled_weights(hip, seed):
     view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
                           float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
     out = {}
-    for math in ("bf16x6", "f32"):
+    for math in ("f16x3", "bf16x6", "f32"):
         dec, keep = make_decoder_struct(cfg, sd2, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
         cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
         out[math] = [t.cpu() for t in hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)]
-    # judge both paths against the same network evaluated in float64 (the oracle is dtype-generic): with
-    # magnitudes blown up like this fp32 itself is only good to ~1e-5, and the split path must not be worse
+    # judge all paths against the same network evaluated in float64 (the oracle is dtype-generic): with
+    # magnitudes blown up like this fp32 itself is only good to ~1e-5, and the split paths must not be worse
     with torch.no_grad():
         sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd2.items()}
         cond64 = torch.from_numpy(g["cond"]).double()
         rgb64, sig64 = O.decoder(cfg, sd64, torch.from_numpy(g["x_ref"]).double(), torch.from_numpy(g["dir_ref"]).double(),
                                  cond64, cond64[..., -cfg.n_src_views:])
-    assert torch.isfinite(out["bf16x6"][3]).all() and torch.isfinite(out["bf16x6"][4]).all()
     e_rgb = {m: linf(out[m][3].double(), rgb64) for m in out}
     e_sig = {m: linf(out[m][4].double(), sig64) for m in out}
-    print(f"\n[seed {seed}] vs float64: rgb_s bf16x6 {e_rgb['bf16x6']:.2e} / f32 {e_rgb['f32']:.2e};"
-          f" sigma bf16x6 {e_sig['bf16x6']:.2e} / f32 {e_sig['f32']:.2e} (max sigma {float(sig64.abs().max()):.2e})")
-    assert e_rgb["bf16x6"] < 2.0 * e_rgb["f32"] + 1e-6
-    assert e_sig["bf16x6"] < 2.0 * e_sig["f32"] + 1e-6 * max(1.0, float(sig64.abs().max()))
+    print(f"\n[seed {seed}] vs float64: rgb_s " + " / ".join(f"{m} {e_rgb[m]:.2e}" for m in out) +
+          "; sigma " + " / ".join(f"{m} {e_sig[m]:.2e}" for m in out) + f" (max sigma {float(sig64.abs().max()):.2e})")
+    for math, slack in (("bf16x6", 2.0), ("f16x3", 3.0)):
+        assert torch.isfinite(out[math][3]).all() and torch.isfinite(out[math][4]).all()
+        assert e_rgb[math] < slack * e_rgb["f32"] + 1e-6
+        assert e_sig[math] < slack * e_sig["f32"] + 1e-6 * max(1.0, float(sig64.abs().max()))
+
+
+def test_split_fp16_gains_cover_extreme_magnitudes(hip):
+    """fp16 has a 5-bit exponent: the per-sample activation gains and per-tensor weight scales must keep the
+    split-fp16 path finite and accurate when whole tensors are scaled by 2^+-12 (hidden activations around
+    1e4 .. 1e-4), where an unscaled fp16 operand would overflow to inf or lose its low term."""
+    g, cfg, sd, batch, _, _ = _case_on_gpu("c1_default")
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    n, s, dc = g["cond"].shape
+    view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                          float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+    for big, small in (("nerf_dec.pts_linears.0.", "nerf_dec.pts_linears.3."), ("nerf_dec.pts_linears.2.", "nerf_dec.pts_linears.0.")):
+        sd2 = dict(sd)
+        for k in sd:
+            if k.startswith(big):
+                sd2[k] = sd[k] * 4096.0          # exact power-of-two rescale: ReLU / FiLM are positively homogeneous,
+            if k.startswith(small):
+                sd2[k] = sd[k] / 4096.0          # so the network function is unchanged up to rounding
+        res = {}
+        for math in ("f16x3", "f32"):
+            dec, keep = make_decoder_struct(cfg, sd2, math=math)
+            cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
+            res[math] = hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)
+        assert torch.isfinite(res["f16x3"][3]).all() and torch.isfinite(res["f16x3"][4]).all()
+        # biases break exact homogeneity, so compare the two matrix paths on the SAME rescaled network
+        assert linf(res["f16x3"][3], res["f32"][3]) < 1e-5
+        assert linf(res["f16x3"][4], res["f32"][4]) < 2e-5 * max(1.0, float(res["f32"][4].abs().max()))
+
+
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy"])
+def test_decoder_samples_matches_reference(hip, name):
+    """mnerf_decoder_samples = CondNeRF.forward on caller-supplied inputs (cond_nerf.py:52-100): fed with the
+    reference's own pts_3D_ref_ndc / ray_unit_ref / cond_info it must reproduce the reference's per-sample outputs."""
+    g, cfg, sd, batch, _, _ = _case_on_gpu(name)
+    dec, keep = make_decoder_struct(cfg, sd)
+    n, s, dc = g["cond"].shape
+    cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
+    x = torch.from_numpy(g["x_ref"]).cuda().contiguous()
+    d = torch.from_numpy(g["dir_ref"])[:, None, :].expand(n, s, 3).contiguous().cuda()
+    rgb_s, sigma = hip.decoder_samples(dec, x, d, cond, legacy_coord=cfg.legacy_coord)
+    assert linf(rgb_s, g["rgb_samples"]) < 5e-5
+    assert linf(sigma, g["sigma"]) < 5e-5
+    # a ragged tail (rays not a multiple of the tile) and the empty call
+    r2, s2 = hip.decoder_samples(dec, x[:5].contiguous(), d[:5].contiguous(), cond[:5 * s].contiguous(), legacy_coord=cfg.legacy_coord)
+    assert torch.equal(r2, rgb_s[:5]) and torch.equal(s2, sigma[:5])
+    e = hip.decoder_samples(dec, x[:0].contiguous(), d[:0].contiguous(), cond[:0].contiguous())
+    assert e[0].shape == (0, s, 3)
 
 
 @pytest.mark.parametrize("name,chunk", [("c1_default", 1024), ("c1_default", 4096), ("rect_wide", 1000),
-                                        ("nonlegacy", 1536), ("v4", 37)])
+                                        ("nonlegacy", 1536), ("v4", 37), ("inverse_depth", 1024)])
 def test_render_chunk_full_frame_matches_reference(hip, name, chunk):
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
     sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)

@@ -15,7 +15,7 @@ from helpers import golden_case, linf, split_poses
 from matchnerf_amd import synthetic as syn
 from oracle import matchnerf_oracle as O
 
-CASES = ["c1_default", "rect_wide", "nonlegacy", "v4"]
+CASES = ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -104,9 +104,9 @@ def test_composite_properties():
     sigma = torch.rand(50, 64, generator=gen) * 0.2
     rgb = torch.rand(50, 64, 3, generator=gen)
     depth = torch.linspace(2, 4, 64)[None].expand(50, 64)
-    out_rgb, out_depth, op = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth)
+    out_rgb, out_depth, op, prob = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth)
     assert float(op.max()) <= 1 + 1e-6 and float(op.min()) >= 0
     # closed form: opacity = 1 - exp(-sum sigma)
     assert linf(op[:, 0], 1 - torch.exp(-sigma.sum(1))) < 1e-5
-    bg, _, _ = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth, setbg_opaque=True)
+    bg, _, _, _ = O.composite(cfg, torch.ones(50, 3), rgb, sigma, depth, setbg_opaque=True)
     assert linf(bg, out_rgb + (1 - op)) < 1e-6

@@ -13,6 +13,7 @@ Fixtures (all float32 unless noted):
   rect_wide.npz     64x96 images, wide baseline, IBRNet-style decoder switches + white background
   nonlegacy.npz     legacy_coord=false, wo_render_interval=false
   v4.npz            4 source views (6 pairs), 32 samples
+  inverse_depth.npz nerf.depth.param=inverse (samples at 1/(d+1e-8), matchnerf.py:177-180)
   window_attn.npz   single_head_split_window_attention in/out, shifted and not, + full attention
   options.json      merged option trees of every shipped YAML + CLI-grammar cases
   video_paths.npz   interpolate / spiral render paths for fixed c2w inputs
@@ -224,6 +225,10 @@ def main():
     if want("v4"):
         run_case("v4", dict(height=32, width=32, n_src_views=4, seed=7),
                  {"nerf.sample_intvs": 32, "nerf.rand_rays_test": 1024, "n_src_views": 4},
+                 stage_rays=list(range(0, 1024, 16)), keep_feats=False)
+    if want("inverse_depth"):
+        run_case("inverse_depth", dict(height=32, width=32, n_src_views=3, seed=8),
+                 {"nerf.sample_intvs": 32, "nerf.rand_rays_test": 1024, "nerf.depth.param": "inverse"},
                  stage_rays=list(range(0, 1024, 16)), keep_feats=False)
     if want("window_attn"):
         window_attention_case()
