@@ -139,6 +139,10 @@ def cpu_baseline(weights, scene, n_threads):
                 render_only_rays_per_s=round(CPU_RAYS / t_chunk, 2))
 
 
+def _per_frame(ksum, name, frames):
+    return round(ksum[name]["total_ms"] / frames, 3) if name in ksum else None
+
+
 def secondary_workload(device, name, n_views, n_samples, height, width, bg, **scene_kw):
     """One of the other BASELINE configs at full size, outside the timed region: frame time incl. encoder."""
     import torch
@@ -167,8 +171,8 @@ def secondary_workload(device, name, n_views, n_samples, height, width, bg, **sc
     torch.cuda.empty_cache()
     n = height * width
     return {"workload": name, "rays_per_s": round(n / (ms * 1e-3), 1), "ms_per_frame": round(ms, 3),
-            "encoder_ms": round(enc_ms, 3), "cost_volume_ms": round(k["cost_volume"]["total_ms"] / 2, 3),
-            "decoder_ms": round(k["decoder"]["total_ms"] / 2, 3), "finite": ok}
+            "encoder_ms": round(enc_ms, 3), "cost_volume_ms": _per_frame(k, "cost_volume", 2),
+            "decoder_ms": _per_frame(k, "decoder", 2), "fused_ray_chunk_ms": _per_frame(k, "render_fused", 2), "finite": ok}
 
 
 def respawn_under_launcher(args):
@@ -269,7 +273,8 @@ def main():
                 torch.cuda.synchronize()
                 msm = (time.perf_counter() - t1) / 2 * 1e3
                 other_math[m] = {"rays_per_s": round(n_rays / (msm * 1e-3), 1), "ms_per_step": round(msm, 3),
-                                 "decoder_ms_per_frame": round(tm.summary()["decoder"]["total_ms"] / 2, 3),
+                                 "decoder_ms_per_frame": _per_frame(tm.summary(), "decoder", 2),
+                                 "fused_ray_chunk_ms_per_frame": _per_frame(tm.summary(), "render_fused", 2),
                                  "rgb_linf_vs_default_math": float((fullm[:, :3] - rgb_default).abs().max())}
         finally:
             if keep is None:
@@ -290,10 +295,30 @@ def main():
                                             "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
                                             10, 64, 512, 640, False, seed=32))
 
+    # the same frame through the staged two-launch form (cost volume -> HBM -> decoder) when the default is the fused one
+    staged_form = None
+    if world == 1 and "render_fused" in ksum:
+        model.staged_render = True
+        step()
+        ts = hip.KernelTimer()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step(ts)
+        torch.cuda.synchronize()
+        mss = (time.perf_counter() - t1) / 2 * 1e3
+        model.staged_render, model.kernel_timer = False, None
+        ks = ts.summary()
+        staged_form = {"ms_per_step": round(mss, 3), "rays_per_s": round(n_rays / (mss * 1e-3), 1),
+                       "cost_volume_ms_per_frame": round(ks["cost_volume"]["total_ms"] / 2, 3),
+                       "decoder_ms_per_frame": round(ks["decoder"]["total_ms"] / 2, 3)}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * n_rays * args.steps / elapsed
-        dec = ksum["decoder"]
+        fused = "render_fused" in ksum
+        dec = ksum["render_fused"] if fused else ksum["decoder"]
+        cv_ms = None if fused else ksum["cost_volume"]["total_ms"] / args.steps
         launch_rays = dec["rays"] / dec["launches"]
         samples_launch = launch_rays * S
         flops_launch = samples_launch * flops_per_sample(S)
@@ -301,7 +326,7 @@ def main():
         algorithmic = flops_launch / secs / 1e12
         ppm = PRODUCTS_PER_MAC[math]
         issued_launch = samples_launch * (ppm * MLP_FLOPS_PER_SAMPLE + (flops_per_sample(S) - MLP_FLOPS_PER_SAMPLE))
-        render_ms = (dec["total_ms"] + ksum["cost_volume"]["total_ms"]) / args.steps
+        render_ms = dec["total_ms"] / args.steps + (cv_ms or 0.0)
         render_rate = n_rays / (render_ms * 1e-3)
         counters = measured_counters("decoder_kernel") if math == decoder_math() else None
         fresh = bool(counters) and not counters.get("stale")
@@ -324,12 +349,19 @@ def main():
                 "parallelism": f"target views x{world}" if world > 1 else "single GPU",
                 "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
                 "render_only_rays_per_s_per_gpu": round(render_rate, 1),
-                "cost_volume_ms_per_frame": round(ksum["cost_volume"]["total_ms"] / args.steps, 3),
-                "decoder_ms_per_frame": round(dec["total_ms"] / args.steps, 3),
+                "ray_chunk_form": ("fused: cost volume + decoder + compositing in ONE launch per 65536 rays, conditioning rows "
+                                   "produced and consumed in LDS (no HBM hand-off)") if fused else
+                                  "staged: cost volume -> [rays*S, cond_stride] rows in HBM -> decoder (two launches)",
+                "cost_volume_ms_per_frame": None if fused else round(cv_ms, 3),
+                "decoder_ms_per_frame": None if fused else round(dec["total_ms"] / args.steps, 3),
+                "fused_ray_chunk_ms_per_frame": round(dec["total_ms"] / args.steps, 3) if fused else None,
+                "staged_two_launch_form": staged_form,
                 "secondary_workloads": secondary or None,
             },
             "roofline": {
-                "bound": "mfma", "kernel": "decoder_kernel<4,64> (fused MLP + ray transformer + compositing)",
+                "bound": "mfma",
+                "kernel": ("decoder_kernel<4,64,2,1> (ONE launch: cost volume + MLP + ray transformer + compositing)" if fused
+                           else "decoder_kernel<4,64> (fused MLP + ray transformer + compositing)"),
                 "achieved": round(algorithmic, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
                 "what": "ALGORITHMIC FLOPs (SURVEY.md 8d: 258336 + 64 S per sample) / measured launch time vs the f32-MFMA "
@@ -343,7 +375,8 @@ def main():
                                   f"{'2.5 PFLOP/s dense 16-bit' if math != 'f32' else '157.3 TFLOP/s f32'} MFMA peak",
                 "mfma_busy_measured": counters.get("mfma_busy_frac") if fresh else None,
                 "traffic": counters.get("hbm_bytes_per_launch") if fresh else None,
-                "traffic_algorithmic_bytes": int(samples_launch * 96 + launch_rays * 20),
+                "traffic_algorithmic_bytes": (int(launch_rays * 296) if fused else  # 8d: compulsory bytes per ray
+                                              int(samples_launch * 96 + launch_rays * 20)),
                 "counters_source": (counters.get("source") if fresh else
                                     ("profiles/decoder_counters.json is stale or absent: re-run tools/profile_round.sh" if
                                      counters is None or counters.get("stale") else None)),

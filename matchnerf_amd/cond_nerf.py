@@ -372,7 +372,7 @@ def pack_wstream16(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_
 # sample's largest feature lose their lo term to fp16 underflow, an absolute error below 2^-25 of that maximum.
 # Stream unit = (K16-step, block): [hi | lo] fragments of 1 KiB (64 lanes x 8 fp16), same (lane, j) -> k map as
 # format 1.  A stage's first segment starts with a 1 KiB fp32 header: floats [0,128) = bias in accumulator order
-# (UNscaled; the kernel multiplies it by the operand gain), float [128] = 2^-ew.
+# (UNscaled; the kernel multiplies it by the operand gain), float [128] = 2^-ew, float [129] = ew.
 
 F16_TARGET_EXP = 14  # weights: max |W 2^ew| in [2^13, 2^14); activations: max in [2^14, 2^15)
 H_SEG_STEPS = 4      # K16-steps per segment of a 4-block stage: 4 x 4 x 2 KiB + 1 KiB header = 33 KiB
@@ -489,6 +489,7 @@ def pack_wstream_h(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_
         if hdr:
             out[off:off + 128] = _bias_fragment(b, m)[:128]
             out[off + 128] = np.ldexp(np.float32(1.0), -ew)
+            out[off + 129] = np.float32(ew)   # the kernel reads the exponent (scales are tracked as integers)
             off += FRAG_FLOATS
         a = frag_cache[name][first:first + steps]
         out16[2 * off:2 * off + a.size] = a.reshape(-1)

@@ -37,10 +37,17 @@ struct mnerf_tuning {
   int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
   int wa_min4;
+  int render_fused;  // MNERF_RENDER_FUSED (default 1): mnerf_render_chunk uses the one-launch form where it applies
 };
 const mnerf_tuning& mnerf_tune();
 // true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device
 bool mnerf_once_per_device(std::atomic<unsigned long long>& mask);
+// argument checks of the scene / rays structs (cost_volume.hip)
+int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char* who);
+// fused ray-chunk form (decoder.hip), used by mnerf_render_chunk (render_chunk.hip)
+bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays);
+int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays, float* rgb,
+                              float* depth, float* opacity, void* stream);
 
 // ------------------------------------------------------------------ device: geometry
 // The positional encoding multiplies the projected coordinate by up to 2^9 (x pi), so a

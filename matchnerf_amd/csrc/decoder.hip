@@ -38,7 +38,7 @@
 // overlap the other's MFMA phases.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "cv_walk.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -479,12 +479,21 @@ struct Smem {
   static constexpr int TOTAL_FLOATS = W_FLOATS + RS_FLOATS + LN_FLOATS;
 };
 
-template <int NW, int SP, int FMT>
+// CVF = 1: the FUSED ray-chunk form (K1..K5 in one launch): the workgroup first produces the conditioning rows of
+// its own tile with the register-quad walk of cv_walk.hpp (8-sample walks, one per 16-lane slot) straight into LDS
+// — no [rays*S, cond_stride] hand-off through HBM — and only then starts the MFMA trunk.  The walk is texture /
+// VALU work with no matrix instruction; with two workgroups per CU one workgroup's walk runs under the other's MFMA
+// stages.  LDS: walk scratch in weight buffer 1, the tile's rows in the part of weight buffer 0 above segment 0
+// (the FiLM weights: 17 KiB at <= 32 conditioning inputs); both are dead before the weight pipeline needs them.
+#define CVF_SEG 8
+#define CVF_COND_OFF_FLOATS (17 * 256)
+template <int NW, int SP, int FMT, int CVF>
 __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     mnerf_decoder D, DecSched sch, mnerf_view view0, mnerf_rays R,
     const float* __restrict__ cond, float* __restrict__ out_rgb, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma,
-    const float* __restrict__ ext_ndc, const float* __restrict__ ext_dir) {
+    const float* __restrict__ ext_ndc, const float* __restrict__ ext_dir, mnerf_scene scene) {
+  static_assert(!CVF || (FMT == 2 && NW == 4), "the fused form is built for the split-fp16 trunk");
   constexpr int Sp = SP;
   using SM = Smem<NW, SP>;
   constexpr int TILE = SM::TILE;
@@ -541,21 +550,24 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     const int j_p = s_l - r_t * Sp;
     int r = t * rays_per_tile + r_t;
     if (r >= R.n_rays) r = R.n_rays - 1;
-    const size_t g_s = (size_t)r * S + (j_p < S ? j_p : (S - 1));
+    // row of this lane's sample: in the staged form a row of the [rays*S, CS] buffer in global memory, in the fused
+    // form a row of the tile's [TILE, CS] block in LDS (written by this workgroup a moment ago)
+    const float* crow_base = CVF ? (wbuf0 + CVF_COND_OFF_FLOATS) + (size_t)(r_t * Sp + (j_p < S ? j_p : (S - 1))) * CS
+                                 : cond + ((size_t)r * S + (j_p < S ? j_p : (S - 1))) * CS;
     if constexpr (FMT >= 1) {  // K16 steps 0,1: cond[16 t + 8 hl + 4 q .. +4), q = i & 1, t = i >> 1
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
-        cpre[i] = (o + 4 <= CS && (i >> 1) < sch.film_steps) ? *reinterpret_cast<const float4*>(cond + g_s * CS + o)
+        cpre[i] = (o + 4 <= CS && (i >> 1) < sch.film_steps) ? *reinterpret_cast<const float4*>(crow_base + o)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
-      const float4* crow4 = reinterpret_cast<const float4*>(cond + g_s * CS + (size_t)hl * sch.film_steps);
+      const float4* crow4 = reinterpret_cast<const float4*>(crow_base + (size_t)hl * sch.film_steps);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         cpre[i] = (4 * i < sch.film_steps) ? crow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float* mrow = cond + g_s * CS + (D.cond_dim - D.n_views);
+    const float* mrow = crow_base + (D.cond_dim - D.n_views);
     float nv = 0.0f;
     for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
     n_valid = nv;
@@ -567,7 +579,17 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
   // record blocks [0,64) and their presumed CU partners [256,320)
   const int tl_slot = blockIdx.x < 64 ? (int)blockIdx.x : ((blockIdx.x >= 256 && blockIdx.x < 320) ? (int)blockIdx.x - 192 : -1);
 #endif
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // Tile -> workgroup mapping.  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): XCD x takes the
+  // contiguous tile range [x n/8, (x+1) n/8) and its workgroups step through it together, so the epipolar texels
+  // the fused form gathers for concurrently processed tiles sit in that XCD's own L2.
+  int tile_begin = blockIdx.x, tile_end = n_tiles, tile_step = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int xcd = blockIdx.x & 7;
+    tile_begin = (int)((long long)n_tiles * xcd / 8) + (int)(blockIdx.x >> 3);
+    tile_end = (int)((long long)n_tiles * (xcd + 1) / 8);
+    tile_step = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups with this b % 8
+  }
+  for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
 #ifdef MNERF_TIMELINE
     ++tl_tile;
     if (sch.tl && lane == 0 && tl_slot >= 0 && tl_tile < 4)
@@ -612,13 +634,32 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
     }
 
-    load_tile_inputs(tile);  // issued before the geometry below is consumed: latency overlaps it
-    const bool q_valid = n_valid > 1.0f;
-
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
     if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
+    if constexpr (CVF) {
+      // ---- K1+K2 for this tile: slot = 16 lanes, unit = CVF_SEG consecutive samples of one ray
+      const int nv_ = scene.n_views;
+      const int sumG_ = scene.n_group[0] + (scene.n_scales > 1 ? scene.n_group[1] : 0);
+      const int per_slot = cv_slot_lds_floats(CVF_SEG, nv_, sumG_);
+      const int slot = tid >> 4, sub = tid & 15;
+      float* sl = wbuf1 + slot * per_slot;
+      float* cond_lds = wbuf0 + CVF_COND_OFF_FLOATS;
+      for (int unit = slot; unit < TILE / CVF_SEG; unit += NW * 4) {
+        const int ls0 = unit * CVF_SEG;             // first local sample of the unit
+        const int r_t = ls0 / Sp, jp0 = ls0 - r_t * Sp;
+        const int rr = tile * rays_per_tile + r_t;
+        const bool live = rr < R.n_rays;
+        cv_walk_unit<8, CVF_SEG>(scene, R, live ? rr : R.n_rays - 1, live, jp0,
+                                 cond_lds + (size_t)(r_t * Sp + (jp0 < S ? jp0 : S - 1)) * CS, CS, sl,
+                                 reinterpret_cast<float4*>(sl + CVF_SEG * nv_ * 2), sl + CVF_SEG * (nv_ * 2 + 16), sub);
+      }
+      __syncthreads();  // the tile's rows are complete
+    }
+    load_tile_inputs(tile);  // issued before the geometry above is consumed: latency overlaps it
+    const bool q_valid = n_valid > 1.0f;
     segment_wait();
-    __syncthreads();
+    __syncthreads();  // publishes weight segment 0; in the fused form also: every lane holds its FiLM inputs, so
+                      // weight buffer 1 (walk scratch) and the rows above segment 0 may be overwritten from here on
 
 #define CUR_BUF ((seg & 1) ? wbuf1 : wbuf0)
 #define NXT_BUF ((seg & 1) ? wbuf0 : wbuf1)
@@ -1318,7 +1359,10 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         a_jq = lane & 31;
       }
       const int s_q = a_ray * Sp + a_jq;
-#pragma unroll
+      // the scores of one head take SP registers per lane: at SP = 128 the two heads must not be unrolled into one
+      // schedule (their score sets would be live together: 300 spilled VGPRs)
+      constexpr int HEAD_UNROLL = SP >= 128 ? 1 : 2;
+#pragma unroll HEAD_UNROLL
       for (int hh = 0; hh < 2; ++hh) {
         const int head = 2 * a_hp + hh;
         const float4 q4 = *reinterpret_cast<const float4*>(q_lds + s_q * 16 + head * 4);
@@ -1486,8 +1530,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // every weight / scratch read of this tile is complete: start the DMA of the next tile's first
     // weight segment now, under the compositing
     {
-      const int next_tile = tile + (int)gridDim.x;
-      seg0_in_flight = next_tile < n_tiles;
+      seg0_in_flight = tile + tile_step < tile_end;
       if (seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
     }
 
@@ -1686,8 +1729,8 @@ static int pick_padded_samples(int S) {
 // (caller-supplied sample coordinates / directions, per-sample outputs only).
 static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf_view* view0, const mnerf_rays* rays,
                           const float* cond, float* rgb, float* depth, float* opacity, float* rgb_s, float* sigma,
-                          const float* ext_ndc, const float* ext_dir, void* stream) {
-  MNERF_REQUIRE(dec->wstream && dec->small_ && cond, MNERF_E_NULL, "%s: NULL buffer", who);
+                          const float* ext_ndc, const float* ext_dir, const mnerf_scene* fused_scene, void* stream) {
+  MNERF_REQUIRE(dec->wstream && dec->small_ && (cond || fused_scene), MNERF_E_NULL, "%s: NULL buffer", who);
   MNERF_REQUIRE(mnerf_aligned16(dec->wstream) && mnerf_aligned16(cond), MNERF_E_ALIGN,
                 "%s: wstream / cond must be 16-byte aligned", who);
   MNERF_REQUIRE(dec->L_3D >= 0 && dec->L_3D <= 16, MNERF_E_RANGE, "%s: L_3D=%d", who, dec->L_3D);
@@ -1712,7 +1755,9 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   if (rays->n_rays == 0) return MNERF_OK;
   hipStream_t st = (hipStream_t)stream;
   const int resident = mnerf_tune().decoder_grid;  // persistent: 2 workgroups per CU x 256 CUs
-#define MNERF_LAUNCH_DECODER(NW_, SP_, FMT_)                                                         \
+  static const mnerf_scene no_scene = {};
+  const mnerf_scene* scn = fused_scene ? fused_scene : &no_scene;
+#define MNERF_LAUNCH_DECODER(NW_, SP_, FMT_, CVF_)                                                   \
   do {                                                                                               \
     const int rpt = (NW_ * 32) / SP_;                                                                \
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
@@ -1720,29 +1765,31 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     const size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                 \
     static std::atomic<unsigned long long> attr_set{0};                                              \
     if (mnerf_once_per_device(attr_set))                                                             \
-      (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_>,                         \
+      (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_, CVF_>,                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-    hipLaunchKernelGGL((decoder_kernel<NW_, SP_, FMT_>), dim3(grid), dim3(NW_ * 64), lds, st, *dec,  \
-                       sch, *view0, *rays, cond, rgb, depth, opacity, rgb_s, sigma, ext_ndc,         \
-                       ext_dir);                                                                     \
+    hipLaunchKernelGGL((decoder_kernel<NW_, SP_, FMT_, CVF_>), dim3(grid), dim3(NW_ * 64), lds, st,  \
+                       *dec, sch, *view0, *rays, cond, rgb, depth, opacity, rgb_s, sigma, ext_ndc,   \
+                       ext_dir, *scn);                                                               \
   } while (0)
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_)                                   \
   do {                                                                       \
-    if (dec->wstream_format == MNERF_WSTREAM_F16X2)                          \
-      MNERF_LAUNCH_DECODER(NW_, SP_, 2);                                     \
+    if (fused_scene)                                                         \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1);                                  \
+    else if (dec->wstream_format == MNERF_WSTREAM_F16X2)                     \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 2, 0);                                  \
     else if (dec->wstream_format == MNERF_WSTREAM_BF16X3)                    \
-      MNERF_LAUNCH_DECODER(NW_, SP_, 1);                                     \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 1, 0);                                  \
     else                                                                     \
-      MNERF_LAUNCH_DECODER(NW_, SP_, 0);                                     \
+      MNERF_LAUNCH_DECODER(NW_, SP_, 0, 0);                                  \
   } while (0)
   switch (Sp) {
     case 32: MNERF_LAUNCH_DECODER_FMT(4, 32); break;
     case 64: MNERF_LAUNCH_DECODER_FMT(4, 64); break;
     case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
     default:
-      MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32, MNERF_E_UNSUPPORTED,
+      MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32 && !fused_scene, MNERF_E_UNSUPPORTED,
                     "%s: sample_intvs=%d > 128 needs the MNERF_WSTREAM_F32 weight stream", who, rays->n_samples);
-      MNERF_LAUNCH_DECODER(8, 256, 0);
+      MNERF_LAUNCH_DECODER(8, 256, 0, 0);
       break;
   }
 #undef MNERF_LAUNCH_DECODER_FMT
@@ -1750,16 +1797,40 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   return mnerf_check_launch(who);
 }
 
+// The fused ray-chunk form (one launch, no workspace) exists for the shipped configuration class: split-fp16
+// stream, S <= 128, at most 32 conditioning inputs (<= 5 views), cosine groups of at most 8 lanes (G >= 2) and
+// walk scratch that fits one weight buffer.
+bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays) {
+  if (!mnerf_tune().render_fused) return false;
+  if (dec->wstream_format != MNERF_WSTREAM_F16X2 || rays->n_samples > 128) return false;
+  if (dec->cond_stride > 32 || (dec->cond_dim + 15) / 16 > 2) return false;
+  if (sc->n_views < 2 || sc->n_views != dec->n_views) return false;
+  int sumG = 0;
+  for (int s = 0; s < sc->n_scales; ++s) {
+    if (sc->n_group[s] < 2) return false;
+    sumG += sc->n_group[s];
+  }
+  if (sumG > 16) return false;
+  return 16 * cv_slot_lds_floats(CVF_SEG, sc->n_views, sumG) <= SEG_CAP_FLOATS &&
+         CVF_COND_OFF_FLOATS + 128 * dec->cond_stride <= SEG_CAP_FLOATS;
+}
+
+int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays, float* rgb,
+                              float* depth, float* opacity, void* stream) {
+  return launch_decoder("mnerf_render_chunk", dec, &sc->views[0], rays, nullptr, rgb, depth, opacity, nullptr, nullptr,
+                        nullptr, nullptr, sc, stream);
+}
+
 extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,
                                    const mnerf_rays* rays, const float* cond, float* rgb,
                                    float* depth, float* opacity, float* dbg_rgb_s,
                                    float* dbg_sigma, void* stream) {
   MNERF_REQUIRE(dec && view0 && rays, MNERF_E_NULL, "mnerf_decoder_chunk: NULL argument struct");
-  MNERF_REQUIRE(rgb && depth && opacity, MNERF_E_NULL, "mnerf_decoder_chunk: NULL output buffer");
+  MNERF_REQUIRE(rgb && depth && opacity && cond, MNERF_E_NULL, "mnerf_decoder_chunk: NULL buffer");
   MNERF_REQUIRE(rays->legacy_coord == 0 || rays->n_samples >= 2, MNERF_E_RANGE,
                 "mnerf_decoder_chunk: legacy depth sampling needs S >= 2");
   return launch_decoder("mnerf_decoder_chunk", dec, view0, rays, cond, rgb, depth, opacity, dbg_rgb_s, dbg_sigma,
-                        nullptr, nullptr, stream);
+                        nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, int32_t n_samples,
@@ -1773,6 +1844,7 @@ extern "C" int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, i
   rays.height = rays.width = 2;
   rays.legacy_coord = legacy_coord ? 1 : 0;  // here it only selects the positional-encoding frequency factor (1 | pi)
   const mnerf_view none = {};
+  MNERF_REQUIRE(cond, MNERF_E_NULL, "mnerf_decoder_samples: cond is NULL");
   return launch_decoder("mnerf_decoder_samples", dec, &none, &rays, cond, nullptr, nullptr, nullptr, rgb_s, sigma,
-                        x_ndc, dir, stream);
+                        x_ndc, dir, nullptr, stream);
 }

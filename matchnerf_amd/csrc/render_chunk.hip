@@ -1,7 +1,11 @@
 // a7 — one render chunk: MatchNeRF.render (/root/reference/models/matchnerf.py:88-143)
-// = cost volume (K1+K2) -> conditioning vectors in `workspace` -> decoder + compositing (K3-K5).
-// Staged form: the hand-off is cond_stride floats per sample through HBM (96 B at 3 views,
-// against 24.7 KB of gathered features per sample), both launches on the caller's stream.
+// = cost volume (K1+K2) -> conditioning vectors -> decoder + compositing (K3-K5).
+// Two forms, same results bit for bit:
+//   fused   ONE launch of the ray-chunk kernel (decoder.hip, CVF = 1): every workgroup produces the conditioning rows
+//           of its own tile in LDS and consumes them there; `workspace` is not touched.  Taken whenever the
+//           configuration fits (split-fp16 stream, S <= 128, <= 5 views: mnerf_fused_render_applies);
+//   staged  mnerf_cost_volume -> [rays*S, cond_stride] rows in `workspace` (HBM) -> mnerf_decoder_chunk, two launches
+//           on the caller's stream: every other configuration, and MNERF_RENDER_FUSED=0.
 #include "common.hpp"
 
 extern "C" int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_samples,
@@ -10,12 +14,8 @@ extern "C" int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_sample
   return (int64_t)n_rays * n_samples * cond_stride * (int64_t)sizeof(float);
 }
 
-extern "C" int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec,
-                                  const mnerf_rays* rays, void* workspace, float* rgb,
-                                  float* depth, float* opacity, void* stream) {
+static int check_render_args(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays) {
   MNERF_REQUIRE(scene && dec && rays, MNERF_E_NULL, "mnerf_render_chunk: NULL argument struct");
-  MNERF_REQUIRE(workspace, MNERF_E_NULL, "mnerf_render_chunk: workspace is NULL");
-  MNERF_REQUIRE(mnerf_aligned16(workspace), MNERF_E_ALIGN, "mnerf_render_chunk: workspace not 16B aligned");
   MNERF_REQUIRE(dec->n_views == scene->n_views, MNERF_E_RANGE,
                 "mnerf_render_chunk: decoder packed for %d views, scene has %d", dec->n_views,
                 scene->n_views);
@@ -23,8 +23,30 @@ extern "C" int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder*
   MNERF_REQUIRE(dec->cond_dim == sumG + 4 * scene->n_views, MNERF_E_RANGE,
                 "mnerf_render_chunk: cond_dim=%d != sum(cos_n_group)+4V=%d", dec->cond_dim,
                 sumG + 4 * scene->n_views);
+  return MNERF_OK;
+}
+
+extern "C" int32_t mnerf_render_chunk_is_fused(const mnerf_scene* scene, const mnerf_decoder* dec,
+                                               const mnerf_rays* rays) {
+  if (check_render_args(scene, dec, rays)) return 0;
+  return mnerf_fused_render_applies(scene, dec, rays) ? 1 : 0;
+}
+
+extern "C" int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec,
+                                  const mnerf_rays* rays, void* workspace, float* rgb,
+                                  float* depth, float* opacity, void* stream) {
+  int rc = check_render_args(scene, dec, rays);
+  if (rc) return rc;
+  MNERF_REQUIRE(rgb && depth && opacity, MNERF_E_NULL, "mnerf_render_chunk: NULL output buffer");
+  if (mnerf_fused_render_applies(scene, dec, rays)) {
+    rc = mnerf_scene_check(scene, rays, "mnerf_render_chunk");
+    if (rc) return rc;
+    return mnerf_fused_render_launch(scene, dec, rays, rgb, depth, opacity, stream);
+  }
+  MNERF_REQUIRE(workspace, MNERF_E_NULL, "mnerf_render_chunk: workspace is NULL");
+  MNERF_REQUIRE(mnerf_aligned16(workspace), MNERF_E_ALIGN, "mnerf_render_chunk: workspace not 16B aligned");
   float* cond = (float*)workspace;
-  int rc = mnerf_cost_volume(scene, rays, dec->cond_stride, cond, stream);
+  rc = mnerf_cost_volume(scene, rays, dec->cond_stride, cond, stream);
   if (rc) return rc;
   return mnerf_decoder_chunk(dec, &scene->views[0], rays, cond, rgb, depth, opacity, nullptr,
                              nullptr, stream);

@@ -283,6 +283,46 @@ def test_render_chunk_full_frame_matches_reference(hip, name, chunk):
     assert mse < 1e-10  # => PSNR delta vs any ground truth far below 0.01 dB
 
 
+@pytest.mark.parametrize("name,n_rays,S", [("c1_default", 1000, None), ("rect_wide", 777, None), ("nonlegacy", 1536, None),
+                                           ("v4", 37, None), ("inverse_depth", 513, None), ("c1_default", 301, 128),
+                                           ("c1_default", 200, 100), ("c1_default", 64, 17)])
+def test_fused_render_chunk_equals_staged(hip, name, n_rays, S):
+    """mnerf_render_chunk as ONE launch (conditioning rows produced and consumed in LDS by the ray-chunk kernel, no
+    workspace) against the staged form through its own entry points (mnerf_cost_volume -> HBM -> mnerf_decoder_chunk):
+    identical bits — same arithmetic, different data path — for every option set, ragged ray counts, padded sample
+    counts and 4 views."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
+    if S is not None:
+        cfg.sample_intvs = S
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math="f16x3")
+    rays = make_rays_struct(cfg, batch, n_rays, ray_begin=11)
+    assert hip.render_is_fused(sc, dec, rays)
+    fused = [torch.full((n_rays, 3), -1.0, device="cuda"), torch.full((n_rays,), -1.0, device="cuda"),
+             torch.full((n_rays,), -1.0, device="cuda")]
+    hip.render_chunk(sc, dec, rays, None, *fused)                       # no workspace at all
+    cond = hip.cost_volume(sc, rays, dec.cond_stride)
+    staged = hip.decoder_chunk(dec, sc.views[0], rays, cond)
+    for a, b in zip(fused, staged):
+        assert torch.equal(a, b)
+    if S is None:
+        h, w = batch["images"].shape[-2:]
+        assert linf(fused[0], g["rgb"][0, 11:11 + n_rays]) < 1e-4
+
+
+def test_fused_form_is_not_taken_where_it_does_not_fit(hip):
+    """10 views (50 conditioning inputs) and the strict matrix paths keep the staged two-launch form."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    rays = make_rays_struct(cfg, batch, 64)
+    for math in ("bf16x6", "f32"):
+        dec, keep = make_decoder_struct(cfg, sd, math=math)
+        assert not hip.render_is_fused(sc, dec, rays)
+    dec, keep = make_decoder_struct(cfg, sd, math="f16x3")
+    cfg.sample_intvs = 200
+    assert not hip.render_is_fused(sc, dec, make_rays_struct(cfg, batch, 64))
+
+
 def test_odd_sample_counts_match_oracle(hip):
     """S not a power of two (padded ray slots inside the fused kernel) vs the oracle."""
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")

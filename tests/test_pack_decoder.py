@@ -307,6 +307,7 @@ def emulate_stage_h(ws, segs, names, v, gain):
         for _, first, steps, m, off, fl, hdr in mine:
             if hdr:
                 winv = float(ws[off + 128])
+                assert winv == 2.0 ** -int(ws[off + 129]) and float(ws[off + 129]) == int(ws[off + 129])  # what the kernel reads
                 bias = ws[off:off + 128].astype(np.float64)
                 for h in range(2):
                     for mb in range(m):

@@ -14,7 +14,7 @@ for line in sys.stdin:
     k, v = m.group(1), m.group(2)
     if k == "Function Name":
         flush(cur)
-        v = re.sub(r"_Z14decoder_kernelILi(\d+)ELi(\d+)ELi(\d+)E.*", r"decoder_kernel<\1,\2,\3>", v)
+        v = re.sub(r"_Z14decoder_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E.*", r"decoder_kernel<\1,\2,\3,\4>", v)
         cur = {"fn": v[:40]}
     else:
         cur[k] = v
