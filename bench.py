@@ -295,23 +295,26 @@ def main():
                                             "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
                                             10, 64, 512, 640, False, seed=32))
 
-    # the same frame through the staged two-launch form (cost volume -> HBM -> decoder) when the default is the fused one
-    staged_form = None
-    if world == 1 and "render_fused" in ksum:
-        model.staged_render = True
-        step()
-        ts = hip.KernelTimer()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step(ts)
-        torch.cuda.synchronize()
-        mss = (time.perf_counter() - t1) / 2 * 1e3
-        model.staged_render, model.kernel_timer = False, None
-        ks = ts.summary()
-        staged_form = {"ms_per_step": round(mss, 3), "rays_per_s": round(n_rays / (mss * 1e-3), 1),
-                       "cost_volume_ms_per_frame": round(ks["cost_volume"]["total_ms"] / 2, 3),
-                       "decoder_ms_per_frame": round(ks["decoder"]["total_ms"] / 2, 3)}
+    # the same frame through the one-launch (fused) form of the ray chunk: built, bit-identical, slower
+    fused_form = None
+    if world == 1 and math == "f16x3":
+        model.fused_render = True
+        try:
+            ffull = step()
+            tf_ = hip.KernelTimer()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                ffull = step(tf_)
+            torch.cuda.synchronize()
+            msf = (time.perf_counter() - t1) / 2 * 1e3
+            kf = tf_.summary()
+            if "render_fused" in kf:
+                fused_form = {"ms_per_step": round(msf, 3), "rays_per_s": round(n_rays / (msf * 1e-3), 1),
+                              "fused_ray_chunk_ms_per_frame": round(kf["render_fused"]["total_ms"] / 2, 3),
+                              "identical_to_staged": bool(torch.equal(ffull, full))}
+        finally:
+            model.fused_render, model.kernel_timer = False, None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -355,7 +358,7 @@ def main():
                 "cost_volume_ms_per_frame": None if fused else round(cv_ms, 3),
                 "decoder_ms_per_frame": None if fused else round(dec["total_ms"] / args.steps, 3),
                 "fused_ray_chunk_ms_per_frame": round(dec["total_ms"] / args.steps, 3) if fused else None,
-                "staged_two_launch_form": staged_form,
+                "fused_one_launch_form": fused_form,
                 "secondary_workloads": secondary or None,
             },
             "roofline": {

@@ -187,16 +187,22 @@ int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, int32_t n_sa
                           const float* cond, float* rgb_s, float* sigma, void* stream);
 
 /* a7 — one full render chunk = cost volume + decoder + compositing
- * (MatchNeRF.render, models/matchnerf.py:88-143).
- * Fused form (ONE launch, conditioning rows produced and consumed in LDS by the ray-chunk kernel, `workspace`
- * untouched and allowed to be NULL) whenever mnerf_render_chunk_is_fused() says 1: split-fp16 weight stream,
- * S <= 128, at most 5 views / 32 conditioning inputs, cos_n_group entries >= 2.  Otherwise the staged form:
- * mnerf_cost_volume -> `workspace` -> mnerf_decoder_chunk (two launches); `workspace` must then hold
- * mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride) bytes.  Both forms give identical bits. */
+ * (MatchNeRF.render, models/matchnerf.py:88-143).  Two forms with identical results, bit for bit:
+ *   mnerf_render_chunk        staged: mnerf_cost_volume -> `workspace` -> mnerf_decoder_chunk (two launches);
+ *                             `workspace` must hold mnerf_render_workspace_bytes(n_rays, n_samples, cond_stride)
+ *                             bytes.  The default because it is the faster one on MI355X.
+ *   mnerf_render_chunk_fused  ONE launch: the ray-chunk kernel produces the conditioning rows of each tile in LDS
+ *                             and consumes them there (no HBM hand-off, no workspace).  Available where
+ *                             mnerf_render_chunk_is_fused() returns 1: split-fp16 weight stream, S <= 128, at most
+ *                             5 views / 32 conditioning inputs, cos_n_group entries >= 2; MNERF_E_UNSUPPORTED
+ *                             otherwise.  MNERF_RENDER_FUSED=1 (read at load) makes mnerf_render_chunk take this
+ *                             form wherever it is available (`workspace` may then be NULL). */
 int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_samples, int32_t cond_stride);
 int32_t mnerf_render_chunk_is_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays);
 int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,
                        void* workspace, float* rgb, float* depth, float* opacity, void* stream);
+int mnerf_render_chunk_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,
+                             float* rgb, float* depth, float* opacity, void* stream);
 
 /* K6 — GMFlow single-head (shifted-)window attention, flash style (no score matrix).
  * Replaces single_head_split_window_attention / single_head_full_attention and the

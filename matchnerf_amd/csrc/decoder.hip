@@ -388,7 +388,9 @@ __device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
 // exponent em with 2^em * m in [2^14, 2^15) (m > 0; clamped so that every scale stays a normal fp32 number)
 __device__ __forceinline__ int gain_exp(float m) {
   int e = __builtin_amdgcn_frexp_expf(m);  // m = f 2^e, f in [0.5, 1); 0 for m = 0 / inf / nan
-  e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  // (register-unit magnitudes sit around 2^57: accumulator 2^29 x un-normalised FiLM 2^28; the clamp only keeps
+  // 2^(15-e) a normal fp32 number for denormal / near-overflow inputs)
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
   return H16_TARGET_EXP - e;
 }
 __device__ __forceinline__ float pow2i(int e) { return ldexpf(1.0f, e); }
@@ -697,6 +699,11 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       // ------------------------------------------------------------ FiLM = pts_bias(cond); inputs in [-1, 1]
       f32x16 film[4];
       int ecf = 0;  // film_true = film * 2^ecf (never multiplied out: it rides in the exponent of each layer)
+      // (defined on every path before the segment loop: a value that is only assigned under `done == 0` inside the loop
+      // looks possibly-undefined to the register allocator, which then keeps its 64 registers reserved from the top of
+      // the tile loop - across the whole fused cost-volume phase)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) film[m] = (f32x16)(0.0f);
       {
         int done = 0;
         while (done < sch.film_steps) {
@@ -755,6 +762,8 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
           }
           SEG_END();
         } else {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
           int done = 0;
           while (done < sch.enc_steps) {
             const int ns = sch.seg_steps[seg];
@@ -1801,7 +1810,6 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
 // stream, S <= 128, at most 32 conditioning inputs (<= 5 views), cosine groups of at most 8 lanes (G >= 2) and
 // walk scratch that fits one weight buffer.
 bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays) {
-  if (!mnerf_tune().render_fused) return false;
   if (dec->wstream_format != MNERF_WSTREAM_F16X2 || rays->n_samples > 128) return false;
   if (dec->cond_stride > 32 || (dec->cond_dim + 15) / 16 > 2) return false;
   if (sc->n_views < 2 || sc->n_views != dec->n_views) return false;
@@ -1837,6 +1845,8 @@ extern "C" int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, i
                                      int32_t legacy_coord, const float* x_ndc, const float* dir,
                                      const float* cond, float* rgb_s, float* sigma, void* stream) {
   MNERF_REQUIRE(dec, MNERF_E_NULL, "mnerf_decoder_samples: dec is NULL");
+  MNERF_REQUIRE(n_rays >= 0 && n_samples >= 1, MNERF_E_RANGE, "mnerf_decoder_samples: n_rays=%d S=%d", n_rays, n_samples);
+  if (n_rays == 0) return MNERF_OK;  // empty chunk: nothing to read or write
   MNERF_REQUIRE(x_ndc && dir && rgb_s && sigma, MNERF_E_NULL, "mnerf_decoder_samples: NULL buffer");
   mnerf_rays rays = {};
   rays.n_rays = n_rays;

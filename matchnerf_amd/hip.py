@@ -24,7 +24,7 @@ _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
-           "mnerf_render_chunk", "mnerf_render_chunk_is_fused", "mnerf_window_attention")
+           "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention")
 
 
 class MnerfError(RuntimeError):
@@ -104,6 +104,8 @@ def load():
     lib.mnerf_render_workspace_bytes.argtypes = [i32, i32, i32]
     lib.mnerf_render_chunk_is_fused.restype = i32
     lib.mnerf_render_chunk_is_fused.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays)]
+    lib.mnerf_render_chunk_fused.restype = C.c_int
+    lib.mnerf_render_chunk_fused.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), fp, fp, fp, vp]
     lib.mnerf_render_chunk.restype = C.c_int
     lib.mnerf_render_chunk.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), vp, fp, fp, fp, vp]
     lib.mnerf_window_attention.restype = C.c_int
@@ -311,33 +313,33 @@ class KernelTimer:
 
 
 def render_is_fused(scene, dec, rays):
-    """True when mnerf_render_chunk runs this configuration as ONE launch (no workspace)."""
+    """True when the one-launch form of the ray chunk (mnerf_render_chunk_fused) exists for this configuration."""
     return bool(load().mnerf_render_chunk_is_fused(C.byref(scene), C.byref(dec), C.byref(rays)))
 
 
-def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None, timer=None, staged=False):
-    """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place.  ``workspace`` may be None
-    when ``render_is_fused``.  With ``timer`` the launch(es) are bracketed by events: one span "render_fused" for the
-    one-launch form; for the staged form the two kernels are enqueued through their own entry points (same work,
-    same stream) with spans "cost_volume" and "decoder".  ``staged=True`` takes the two-launch form through those
-    entry points even where the one-launch form applies (measurements, tests)."""
+def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None, timer=None, fused=False):
+    """a7 (matchnerf.py:88-143): writes rgb [R,3], depth [R], opacity [R] in place.
+    ``fused=False`` (default, the faster form on MI355X): cost volume -> ``workspace`` -> decoder, two launches;
+    with ``timer`` they go through their own entry points with spans "cost_volume" and "decoder".
+    ``fused=True``: mnerf_render_chunk_fused, ONE launch, conditioning rows stay in LDS, ``workspace`` may be None
+    (span "render_fused"); raises MnerfError where that form does not exist (``render_is_fused``)."""
     import torch
     lib = load()
     with _on(rgb.device, stream) as st:
-        fused = (not staged) and render_is_fused(scene, dec, rays)
-        if fused or (timer is None and not staged):
+        tst = stream if stream is not None else torch.cuda.current_stream(rgb.device)
+        if fused:
             if timer is not None:
-                tst = stream if stream is not None else torch.cuda.current_stream(rgb.device)
                 e0, e1 = timer.span("render_fused", rays.n_rays)
                 e0.record(tst)
-            check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
-                                         _ptr(depth), _ptr(opacity), st), "mnerf_render_chunk")
+            check(lib.mnerf_render_chunk_fused(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(rgb), _ptr(depth),
+                                               _ptr(opacity), st), "mnerf_render_chunk_fused")
             if timer is not None:
                 e1.record(tst)
             return
         if timer is None:
-            timer = KernelTimer()  # spans of a throw-away timer: forced staged form without measurement
-        tst = stream if stream is not None else torch.cuda.current_stream(rgb.device)
+            check(lib.mnerf_render_chunk(C.byref(scene), C.byref(dec), C.byref(rays), _ptr(workspace), _ptr(rgb),
+                                         _ptr(depth), _ptr(opacity), st), "mnerf_render_chunk")
+            return
         a0, a1 = timer.span("cost_volume", rays.n_rays)
         a0.record(tst)
         check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), dec.cond_stride, _ptr(workspace), st),

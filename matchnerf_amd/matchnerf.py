@@ -52,7 +52,7 @@ class MatchNeRF(torch.nn.Module):
         self._ws = None
         self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
-        self.staged_render = False  # True: ray chunks always take the two-launch form (measurements)
+        self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
 
     def _dec(self):
         """the CondNeRF module, also when the reference's coach wrapped it in nn.DataParallel (coach.py:83-85)"""
@@ -211,7 +211,7 @@ class MatchNeRF(torch.nn.Module):
                                           ref_feats_list, images_cl, n_rays, n_samples, img_h, img_w)
         dec = self._decoder(n_samples, device)
         chunk = min(n_rays, MAX_RAYS_PER_LAUNCH)
-        ws = None  # [rays*S, cond_stride] hand-off buffer: only the staged (two-launch) form of the ray chunk needs it
+        ws = None  # [rays*S, cond_stride] hand-off buffer of the staged form
         rgb = torch.empty(batch_size, n_rays, 3, device=device)
         depth = torch.empty(batch_size, n_rays, 1, device=device)
         opacity = torch.empty(batch_size, n_rays, 1, device=device)
@@ -226,10 +226,11 @@ class MatchNeRF(torch.nn.Module):
                     depth_inverse=(opt.nerf.depth.param == "inverse"),
                     ray_idx_ptr=None if idx32 is None else idx32[c:].data_ptr(),
                     strat_u_ptr=None if strat is None else strat[c:].data_ptr())
-                if ws is None and (self.staged_render or not hip.render_is_fused(sc, dec, rays)):
+                fused = self.fused_render and hip.render_is_fused(sc, dec, rays)
+                if ws is None and not fused:
                     ws = self._workspace(hip.render_workspace_bytes(chunk, n_samples, dec.cond_stride) // 4, device)
                 hip.render_chunk(sc, dec, rays, ws, rgb[b, c:c + m], depth[b, c:c + m], opacity[b, c:c + m],
-                                 timer=self.kernel_timer, staged=self.staged_render)
+                                 timer=self.kernel_timer, fused=fused)
         return edict(rgb=rgb, depth=depth, opacity=opacity)
 
     def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,

@@ -283,7 +283,7 @@ def test_render_chunk_full_frame_matches_reference(hip, name, chunk):
     assert mse < 1e-10  # => PSNR delta vs any ground truth far below 0.01 dB
 
 
-@pytest.mark.parametrize("name,n_rays,S", [("c1_default", 1000, None), ("rect_wide", 777, None), ("nonlegacy", 1536, None),
+@pytest.mark.parametrize("name,n_rays,S", [("c1_default", 1000, None), ("rect_wide", 777, None), ("nonlegacy", 1500, None),
                                            ("v4", 37, None), ("inverse_depth", 513, None), ("c1_default", 301, 128),
                                            ("c1_default", 200, 100), ("c1_default", 64, 17)])
 def test_fused_render_chunk_equals_staged(hip, name, n_rays, S):
@@ -300,7 +300,7 @@ def test_fused_render_chunk_equals_staged(hip, name, n_rays, S):
     assert hip.render_is_fused(sc, dec, rays)
     fused = [torch.full((n_rays, 3), -1.0, device="cuda"), torch.full((n_rays,), -1.0, device="cuda"),
              torch.full((n_rays,), -1.0, device="cuda")]
-    hip.render_chunk(sc, dec, rays, None, *fused)                       # no workspace at all
+    hip.render_chunk(sc, dec, rays, None, *fused, fused=True)           # one launch, no workspace at all
     cond = hip.cost_volume(sc, rays, dec.cond_stride)
     staged = hip.decoder_chunk(dec, sc.views[0], rays, cond)
     for a, b in zip(fused, staged):
@@ -310,8 +310,8 @@ def test_fused_render_chunk_equals_staged(hip, name, n_rays, S):
         assert linf(fused[0], g["rgb"][0, 11:11 + n_rays]) < 1e-4
 
 
-def test_fused_form_is_not_taken_where_it_does_not_fit(hip):
-    """10 views (50 conditioning inputs) and the strict matrix paths keep the staged two-launch form."""
+def test_fused_form_is_not_offered_where_it_does_not_fit(hip):
+    """the strict matrix paths and S > 128 only have the staged two-launch form; asking for the fused one fails loudly"""
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
     sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
     rays = make_rays_struct(cfg, batch, 64)
@@ -320,7 +320,11 @@ def test_fused_form_is_not_taken_where_it_does_not_fit(hip):
         assert not hip.render_is_fused(sc, dec, rays)
     dec, keep = make_decoder_struct(cfg, sd, math="f16x3")
     cfg.sample_intvs = 200
-    assert not hip.render_is_fused(sc, dec, make_rays_struct(cfg, batch, 64))
+    rays200 = make_rays_struct(cfg, batch, 64)
+    assert not hip.render_is_fused(sc, dec, rays200)
+    out = [torch.empty(64, 3, device="cuda"), torch.empty(64, device="cuda"), torch.empty(64, device="cuda")]
+    with pytest.raises(hip.MnerfError, match="one-launch form"):
+        hip.render_chunk(sc, dec, rays200, None, *out, fused=True)
 
 
 def test_odd_sample_counts_match_oracle(hip):
