@@ -204,6 +204,21 @@ int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const
 int mnerf_render_chunk_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,
                              float* rgb, float* depth, float* opacity, void* stream);
 
+/* Backward kernels of the ray chunk (training through the HIP path; reference: autograd through the eager chain,
+ * coach.py:215-243).
+ * K5 backward — given d(rgb [R,3], depth [R] or NULL, opacity [R] or NULL) and the forward's per-sample inputs,
+ * writes g_rgb_s [R,S,3] and g_sigma [R,S] (NeRF.composite, nerf.py:101-124). */
+int mnerf_composite_backward(int32_t n_rays, int32_t n_samples, const float* rgb_s, const float* sigma,
+                             const float* depth_s, const float* ray_len, int32_t wo_render_interval,
+                             int32_t setbg_opaque, const float* g_rgb, const float* g_depth,
+                             const float* g_opacity, float* g_rgb_s, float* g_sigma, void* stream);
+/* K1+K2 backward — g_cond [n_rays*S, cond_stride] (gradient of mnerf_cost_volume's rows; only the cosine
+ * entries are read) is scattered into the feature-map gradients g_feat0 / g_feat1 (layouts of scene->feat[0] /
+ * feat[1]; ACCUMULATED with atomic adds: the caller zero-fills them; g_feat1 may be NULL when n_scales == 1).
+ * The forward interpolation is recomputed from `scene` and `rays` (query_cond_info, matchnerf.py:209-293). */
+int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
+                               const float* g_cond, float* g_feat0, float* g_feat1, void* stream);
+
 /* K6 — GMFlow single-head (shifted-)window attention, flash style (no score matrix).
  * Replaces single_head_split_window_attention / single_head_full_attention and the
  * shift-mask tensor (models/gmflow/transformer.py:8-16, 19-43, 46-105).

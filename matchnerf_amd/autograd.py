@@ -2,13 +2,16 @@
 
 The reference trains by back-propagating through its eager op chain
 (/root/reference/coach.py:215-243).  Here the FORWARD values of ``mode='train'`` come from
-the same HIP kernels as inference (K1-K6); until hand-written backward kernels exist, the
-BACKWARD of each custom op re-evaluates that op with differentiable PyTorch-ROCm ops on the
-GPU (activation-checkpoint style) and back-propagates through the re-evaluation:
+the same HIP kernels as inference (K1-K6); the BACKWARD uses hand-written HIP
+kernels for compositing and the cost volume and, where a backward kernel does not exist yet (window attention,
+the conditional MLP + ray transformer), re-evaluates that op with differentiable PyTorch-ROCm ops on the GPU
+(activation-checkpoint style) and back-propagates through the re-evaluation:
 
 * ``window_attention``  — K6 forward, torch roll/split/softmax re-evaluation for grad(q,k,v)
-* ``render_rays``       — K1..K5 forward (mnerf_render_chunk), torch re-evaluation of the ray
-  chunk for grad(feature maps, decoder parameters)
+* ``render_ray_chunk``  — K1..K5 forward in HIP; backward = K5 backward kernel (mnerf_composite_backward) ->
+  torch re-evaluation of the conditional MLP + ray transformer (K3+K4) from the saved conditioning rows, with
+  sample coordinates from mnerf_ray_samples (the forward's bits) -> K1+K2 backward kernel
+  (mnerf_cost_volume_backward, atomic scatter-add into the feature-map gradients)
 
 This module is only entered when gradients are required; inference never touches it, and it
 is not a fallback: the forward pass still fails loudly without ``libmnerf_hip.so``.
@@ -82,25 +85,9 @@ def window_attention(q, k, v, h, w, splits, shifted):
 # ----------------------------------------------------------------------------- K1..K5
 
 
-def _sample_cl(fmap_cl, grid):
-    """bilinear / border / align_corners=True lookup of a channel-last map [h,w,C] at grid [N,2]
-    -> [N,C] (matchnerf.py:245, gmflow/utils.py:133-134)."""
-    out = F.grid_sample(fmap_cl.permute(2, 0, 1)[None], grid[None, :, None, :], mode="bilinear",
-                        padding_mode="border", align_corners=True)
-    return out[0, :, :, 0].t()
-
-
-def render_rays_torch(opt, dec, feats_b, images_b, src_extr, src_intr, src_nf, tgt_extr, tgt_intr, tgt_nf,
-                      ray_idx, strat_u, height, width, setbg_opaque):
-    """Differentiable re-evaluation of one ray chunk of one batch element (matchnerf.py:88-143,
-    cond_nerf.py:52-100, ray_transformer.py, nerf.py:101-124) with torch ops.
-    feats_b: per scale [P,2,h,w,128]; images_b [V,3,H,W]; dec = CondNeRF parameter holder."""
-    from . import camera
-    dev = images_b.device
-    legacy = bool(opt.nerf.legacy_coord)
-    s_n = int(opt.nerf.sample_intvs)
-    v_n = images_b.shape[0]
-    kinv, c2w = camera.target_ray_consts(tgt_extr, tgt_intr, legacy)
+def ray_directions_torch(kinv, c2w, ray_idx, width, legacy):
+    """target-ray directions [R,3] (un-normalised, camera.py:255-278) for pixel indices ``ray_idx`` on the GPU"""
+    dev = ray_idx.device
     kinv, c2w = torch.from_numpy(kinv).to(dev), torch.from_numpy(c2w).to(dev)
     off = 0.0 if legacy else 0.5
     py = torch.div(ray_idx, width, rounding_mode="floor")
@@ -108,43 +95,17 @@ def render_rays_torch(opt, dec, feats_b, images_b, src_extr, src_intr, src_nf, t
     pix = torch.stack([px.float() + off, py.float() + off, torch.ones_like(px, dtype=torch.float32)], -1)
     cam = pix @ kinv.t()
     center = c2w[:, 3][None].expand_as(cam)
-    ray = (torch.cat([cam, torch.ones_like(cam[:, :1])], -1) @ c2w.t()) - center
-    t = torch.arange(s_n, device=dev, dtype=torch.float32)[None] + (strat_u if strat_u is not None else off)
-    near, far = float(tgt_nf[0]), float(tgt_nf[1])
-    depth = t / ((s_n - 1) if legacy else s_n) * (far - near) + near
-    if opt.nerf.depth.param == "inverse":
-        depth = 1 / (depth + 1e-8)
-    pts = center[:, None] + ray[:, None] * depth[..., None]                      # [R,S,3]
-    n_r = pts.shape[0]
-    flat = pts.reshape(-1, 3)
+    return (torch.cat([cam, torch.ones_like(cam[:, :1])], -1) @ c2w.t()) - center
 
-    def project(v):
-        e = torch.as_tensor(src_extr[v], device=dev)
-        k = torch.as_tensor(src_intr[v], device=dev)
-        q = (torch.cat([flat, torch.ones_like(flat[:, :1])], -1) @ e.t()) @ k.t()
-        u = q[:, 0] / q[:, 2] / (width - 1)
-        w_ = q[:, 1] / q[:, 2] / (height - 1)
-        z = (q[:, 2] - float(src_nf[v][0])) / (float(src_nf[v][1]) - float(src_nf[v][0]))
-        return u, w_, z
 
-    uvz = [project(v) for v in range(v_n)]
-    grids = [torch.stack([u * 2 - 1, w_ * 2 - 1], -1) for u, w_, _ in uvz]
-    colors = [_sample_cl(images_b[v].permute(1, 2, 0), grids[v]) for v in range(v_n)]
-    masks = [((g[:, 0] > -1) & (g[:, 0] < 1) & (g[:, 1] > -1) & (g[:, 1] < 1)).float() for g in grids]
-    groups = list(opt.encoder.cos_n_group)
-    pairs = pair_list(v_n)
-    feat_cols = []
-    for s, fm in enumerate(feats_b):
-        acc = 0
-        for p, (a, b) in enumerate(pairs):
-            fa = _sample_cl(fm[p, 0], grids[a]).reshape(-1, groups[s], 128 // groups[s])
-            fb = _sample_cl(fm[p, 1], grids[b]).reshape(-1, groups[s], 128 // groups[s])
-            acc = acc + F.cosine_similarity(fa, fb, dim=2, eps=1e-8)
-        feat_cols.append(acc / len(pairs))
-    cond = torch.cat(feat_cols + colors + [torch.stack(masks, -1)], -1).reshape(n_r, s_n, -1)
-    mask = torch.stack(masks, -1).reshape(n_r, s_n, v_n)
-
-    x = torch.stack(uvz[0], -1).reshape(n_r, s_n, 3)
+def decoder_torch(opt, dec, x, dirs, cond, n_views):
+    """Differentiable CondNeRF.forward (cond_nerf.py:52-100, ray_transformer.py) with torch ops.
+    x [R,S,3] coordinates w.r.t. source view 0, dirs [R,3] unit directions in that view's frame,
+    cond [R,S,Dc] = cat(feat_info, color_info, mask_info) -> rgb_s [R,S,3], sigma [R,S]."""
+    dev = x.device
+    n_r, s_n, _ = x.shape
+    legacy = bool(opt.nerf.legacy_coord)
+    mask = cond[..., -n_views:]
     L = dec.L_3D
     freq = 2.0 ** torch.arange(L, device=dev, dtype=torch.float32)
     if legacy:
@@ -176,57 +137,76 @@ def render_rays_torch(opt, dec, feats_b, images_b, src_extr, src_intr, src_nf, t
     sigma = F.relu(dec.out_alpha_linear[2](act(dec.out_alpha_linear[0](o))))[..., 0]
     if opt.decoder.density_maskfill:
         sigma = torch.where(n_valid < 1, torch.zeros_like(sigma), sigma)
-    e0 = torch.as_tensor(src_extr[0], device=dev)
-    d_ref = F.normalize(ray, dim=-1) @ e0[:, :3].t()
-    hv = F.relu(dec.views_linears[0](torch.cat([dec.feature_linear(hcur), d_ref[:, None].expand(-1, s_n, -1)], -1)))
-    rgb_s = torch.sigmoid(dec.rgb_linear(hv))
-    if opt.nerf.wo_render_interval:
-        sd = sigma
-    else:
-        intv = torch.cat([depth[:, 1:] - depth[:, :-1], torch.full_like(depth[:, :1], 1e10)], 1)
-        sd = sigma * intv * ray.norm(dim=-1, keepdim=True)
-    alpha = 1 - torch.exp(-sd)
-    excl = torch.cat([torch.zeros_like(sd[:, :1]), sd[:, :-1]], 1).cumsum(1)
-    wgt = torch.exp(-excl) * alpha
-    rgb = (rgb_s * wgt[..., None]).sum(1)
-    dep = (depth * wgt).sum(1, keepdim=True)
-    opa = wgt.sum(1, keepdim=True)
-    if setbg_opaque:
-        rgb = rgb + (1 - opa)
-    return rgb, dep, opa
+    hv = F.relu(dec.views_linears[0](torch.cat([dec.feature_linear(hcur), dirs[:, None].expand(-1, s_n, -1)], -1)))
+    return torch.sigmoid(dec.rgb_linear(hv)), sigma
 
 
-class _RenderRaysFn(torch.autograd.Function):
-    """forward: mnerf_render_chunk (HIP).  backward: re-evaluate with torch ops and back-propagate
-    into the feature maps and the decoder parameters."""
+class RayChunkLaunch:
+    """Everything one differentiable ray chunk of one batch element needs to (re)build its C-ABI argument structs:
+    the forward launches and the backward kernels must see the same scene, rays and decoder."""
+
+    def __init__(self, opt, dec_module, make_scene, make_rays, make_decoder, view0_extr, kinv, c2w, ray_idx, width,
+                 n_views, setbg_opaque):
+        self.opt, self.dec_module = opt, dec_module
+        self.make_scene, self.make_rays, self.make_decoder = make_scene, make_rays, make_decoder
+        self.view0_extr, self.kinv, self.c2w = view0_extr, kinv, c2w
+        self.ray_idx, self.width, self.n_views, self.setbg_opaque = ray_idx, width, n_views, setbg_opaque
+
+
+class _RayChunkFn(torch.autograd.Function):
+    """forward : mnerf_cost_volume -> mnerf_decoder_chunk (HIP; per-sample colours / densities kept for the backward)
+    backward: mnerf_composite_backward (HIP) -> torch re-evaluation of the conditional MLP + ray transformer from the
+              saved conditioning rows (gradients of the decoder parameters and of the rows) ->
+              mnerf_cost_volume_backward (HIP) scatters the rows' gradient into the feature maps."""
 
     @staticmethod
-    def forward(ctx, dec, launch, n_feat, *tensors):
-        feats = tensors[:n_feat]
-        ctx.dec, ctx.launch, ctx.n_feat = dec, launch, n_feat
-        ctx.save_for_backward(*tensors)
+    def forward(ctx, launch, n_feat, *tensors):
+        feats = [f.contiguous() for f in tensors[:n_feat]]
         with torch.no_grad():
-            rgb, depth, opacity = launch["hip_render"](feats)
-        return rgb, depth, opacity
+            sc = launch.make_scene(feats)
+            rays, keep = launch.make_rays()
+            dec = launch.make_decoder()
+            cond = hip.cost_volume(sc, rays, dec.cond_stride, device=feats[0].device)
+            rgb, depth, opacity, rgb_s, sigma = hip.decoder_chunk(dec, sc.views[0], rays, cond, want_samples=True)
+        ctx.launch, ctx.n_feat = launch, n_feat
+        ctx.save_for_backward(cond, rgb_s, sigma, *feats)
+        return rgb, depth[:, None], opacity[:, None]
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_op):
-        dec, launch, n_feat = ctx.dec, ctx.launch, ctx.n_feat
-        saved = ctx.saved_tensors
-        feats = [t.detach().requires_grad_(True) for t in saved[:n_feat]]
-        params = list(dec.parameters())
+        launch, n_feat = ctx.launch, ctx.n_feat
+        cond, rgb_s, sigma, *feats = ctx.saved_tensors
+        opt, dec_m = launch.opt, launch.dec_module
+        r, s = sigma.shape
+        sc = launch.make_scene(feats)
+        rays, keep = launch.make_rays()
+        dec = launch.make_decoder()
+        legacy = bool(opt.nerf.legacy_coord)
+        _, x_ndc, depth_s = hip.ray_samples(rays, sc.views[0], device=sigma.device)   # same bits as the forward's geometry
+        ray = ray_directions_torch(launch.kinv, launch.c2w, launch.ray_idx, launch.width, legacy)
+        wo = bool(opt.nerf.wo_render_interval)
+        g_rgb_s, g_sigma = hip.composite_backward(
+            rgb_s, sigma, depth_s, g_rgb.contiguous().float(), g_depth.reshape(r).contiguous().float(),
+            g_op.reshape(r).contiguous().float(), None if wo else ray.norm(dim=-1).contiguous(),
+            wo_render_interval=wo, setbg_opaque=launch.setbg_opaque)
+        dc = dec.cond_dim
+        cond_t = cond.reshape(r, s, dec.cond_stride)[..., :dc].detach().clone().requires_grad_(True)
+        dirs = F.normalize(ray, dim=-1) @ torch.as_tensor(launch.view0_extr, device=ray.device)[:, :3].t()
+        params = [p for p in dec_m.parameters() if p.requires_grad]
         with torch.enable_grad():
-            outs = launch["torch_render"](feats)
-        wanted = [t for t in feats if True] + [p for p in params if p.requires_grad]
-        grads = torch.autograd.grad(outs, wanted, (g_rgb, g_depth, g_op), allow_unused=True)
-        g_feats = list(grads[:n_feat])
-        it = iter(grads[n_feat:])
-        g_params = [next(it) if p.requires_grad else None for p in params]
-        return (None, None, None, *g_feats, *g_params)
+            rgb_s2, sigma2 = decoder_torch(opt, dec_m, x_ndc.detach(), dirs.detach(), cond_t, launch.n_views)
+        grads = torch.autograd.grad([rgb_s2, sigma2], [cond_t] + params, [g_rgb_s, g_sigma], allow_unused=True)
+        g_feats = [None] * n_feat
+        if any(ctx.needs_input_grad[2:2 + n_feat]):
+            g_cond = torch.zeros(r * s, dec.cond_stride, device=cond.device)
+            g_cond[:, :dc] = grads[0].reshape(r * s, dc)
+            g_feats = hip.cost_volume_backward(sc, rays, dec.cond_stride, g_cond, [torch.zeros_like(f) for f in feats])
+        it = iter(grads[1:])
+        g_params = [next(it) if p.requires_grad else None for p in dec_m.parameters()]
+        return (None, None, *g_feats, *g_params)
 
 
-def render_rays(dec, launch, feats):
-    """Differentiable render of one chunk: ``dec`` is the CondNeRF parameter holder, ``launch`` carries two
-    closures over the same arguments, ``hip_render(feats)`` and ``torch_render(feats)``."""
-    params = list(dec.parameters())
-    return _RenderRaysFn.apply(dec, launch, len(feats), *feats, *params)
+def render_ray_chunk(launch, feats):
+    """Differentiable render of one chunk of rays of one batch element -> (rgb [R,3], depth [R,1], opacity [R,1])."""
+    params = list(launch.dec_module.parameters())
+    return _RayChunkFn.apply(launch, len(feats), *feats, *params)

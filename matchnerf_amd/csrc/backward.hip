@@ -1,0 +1,228 @@
+// Backward kernels of the ray chunk: training through the HIP path
+// (/root/reference/coach.py:215-243 back-propagates through the eager op chain).
+//
+//   mnerf_composite_backward     K5: d(rgb, depth, opacity) -> d(rgb_s, sigma)      (nerf.py:101-124)
+//   mnerf_cost_volume_backward   K1+K2: d(cond) -> d(feature maps), scatter-add      (matchnerf.py:209-293)
+//
+// The conditional MLP + ray transformer in between (K3+K4) is re-evaluated with torch ops from the saved
+// conditioning rows (matchnerf_amd/autograd.py): at training ray counts (rand_rays_train = 4096) it is a few
+// milliseconds; its hand-written backward is the remaining part of that row.
+#include "cv_walk.hpp"
+
+// ------------------------------------------------------------------ K5 backward, one wavefront per ray
+// w_j = T_j a_j, a_j = 1 - exp(-sd_j), T_j = exp(-sum_{i<j} sd_i), sd_j = sigma_j * k_j (k_j = 1 or interval * |ray|)
+//   out_rgb = sum w_j c_j + bg (1 - sum w_j), depth = sum w_j d_j, opacity = sum w_j
+// With G_j = dL/dw_j = <g_rgb, c_j> + g_depth d_j + g_opacity - bg sum(g_rgb):
+//   dL/dc_j  = w_j g_rgb
+//   dL/dsd_j = G_j T_j (1 - a_j) - sum_{k>j} G_k w_k          (w_k depends on sd_j through T_k only)
+__device__ __forceinline__ float wave_incl_scan_up(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void composite_backward_kernel(
+    int n_rays, int S, const float* __restrict__ rgb_s, const float* __restrict__ sigma,
+    const float* __restrict__ depth_s, const float* __restrict__ ray_len, int wo_interval, int setbg,
+    const float* __restrict__ g_rgb, const float* __restrict__ g_depth, const float* __restrict__ g_opacity,
+    float* __restrict__ g_rgb_s, float* __restrict__ g_sigma) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < n_rays; r += n_waves) {
+    const size_t base = (size_t)r * S;
+    const float rl = wo_interval ? 1.0f : ray_len[r];
+    const float gr = g_rgb[(size_t)r * 3 + 0], gg = g_rgb[(size_t)r * 3 + 1], gb = g_rgb[(size_t)r * 3 + 2];
+    const float gd = g_depth ? g_depth[r] : 0.0f;
+    const float go = (g_opacity ? g_opacity[r] : 0.0f) - (setbg ? (gr + gg + gb) : 0.0f);
+    const int n_blk = (S + 63) / 64;
+    // pass 1 (front to back): total of G_k w_k over the ray, needed for the suffix sums
+    float carry = 0.0f, total = 0.0f;
+    for (int blk = 0; blk < n_blk; ++blk) {
+      const int j = blk * 64 + lane;
+      const bool ok = j < S;
+      float sd = 0.0f, G = 0.0f;
+      if (ok) {
+        const float d = depth_s[base + j];
+        float k = 1.0f;
+        if (!wo_interval) k = ((j + 1 < S) ? (depth_s[base + j + 1] - d) : 1e10f) * rl;
+        sd = sigma[base + j] * k;
+        G = gr * rgb_s[(base + j) * 3 + 0] + gg * rgb_s[(base + j) * 3 + 1] + gb * rgb_s[(base + j) * 3 + 2] + gd * d + go;
+      }
+      float prev = __shfl_up(sd, 1, 64);
+      if (lane == 0) prev = 0.0f;
+      const float excl = carry + wave_incl_scan_up(prev, lane);
+      const float w = ok ? expf(-excl) * (1.0f - expf(-sd)) : 0.0f;
+      float gw = G * w;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) gw += __shfl_xor(gw, off, 64);
+      total += gw;
+      carry = __shfl(excl + sd, 63, 64);
+    }
+    // pass 2: gradients; suffix_j = total - prefix_inclusive_j
+    carry = 0.0f;
+    float gw_before = 0.0f;
+    for (int blk = 0; blk < n_blk; ++blk) {
+      const int j = blk * 64 + lane;
+      const bool ok = j < S;
+      float sd = 0.0f, G = 0.0f, k = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f;
+      if (ok) {
+        const float d = depth_s[base + j];
+        if (!wo_interval) k = ((j + 1 < S) ? (depth_s[base + j + 1] - d) : 1e10f) * rl;
+        sd = sigma[base + j] * k;
+        cr = rgb_s[(base + j) * 3 + 0];
+        cg = rgb_s[(base + j) * 3 + 1];
+        cb = rgb_s[(base + j) * 3 + 2];
+        G = gr * cr + gg * cg + gb * cb + gd * d + go;
+      }
+      float prev = __shfl_up(sd, 1, 64);
+      if (lane == 0) prev = 0.0f;
+      const float excl = carry + wave_incl_scan_up(prev, lane);
+      const float T = expf(-excl), e = expf(-sd);
+      const float w = ok ? T * (1.0f - e) : 0.0f;
+      const float gw = G * w;
+      const float incl = gw_before + wave_incl_scan_up(gw, lane);   // sum_{k<=j} G_k w_k
+      if (ok) {
+        g_rgb_s[(base + j) * 3 + 0] = w * gr;
+        g_rgb_s[(base + j) * 3 + 1] = w * gg;
+        g_rgb_s[(base + j) * 3 + 2] = w * gb;
+        g_sigma[base + j] = (G * T * e - (total - incl)) * k;
+      }
+      gw_before = __shfl(incl, 63, 64);
+      carry = __shfl(excl + sd, 63, 64);
+    }
+  }
+}
+
+extern "C" int mnerf_composite_backward(int32_t n_rays, int32_t n_samples, const float* rgb_s, const float* sigma,
+                                        const float* depth_s, const float* ray_len, int32_t wo_render_interval,
+                                        int32_t setbg_opaque, const float* g_rgb, const float* g_depth,
+                                        const float* g_opacity, float* g_rgb_s, float* g_sigma, void* stream) {
+  MNERF_REQUIRE(n_rays >= 0 && n_samples >= 1, MNERF_E_RANGE, "mnerf_composite_backward: n_rays=%d n_samples=%d", n_rays,
+                n_samples);
+  if (n_rays == 0) return MNERF_OK;
+  MNERF_REQUIRE(rgb_s && sigma && depth_s && g_rgb && g_rgb_s && g_sigma, MNERF_E_NULL,
+                "mnerf_composite_backward: NULL buffer");
+  MNERF_REQUIRE(wo_render_interval || ray_len, MNERF_E_NULL,
+                "mnerf_composite_backward: ray_len required when wo_render_interval == 0");
+  int blocks = (n_rays + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(composite_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n_rays, n_samples, rgb_s,
+                     sigma, depth_s, ray_len, wo_render_interval, setbg_opaque, g_rgb, g_depth, g_opacity, g_rgb_s, g_sigma);
+  return mnerf_check_launch("mnerf_composite_backward");
+}
+
+// ------------------------------------------------------------------ K1+K2 backward
+// Only the cosine entries of a conditioning row depend on the feature maps (colours and masks come from the images
+// and the geometry).  For one (sample, pair, scale, group) with interpolated features a, b (C/G channels):
+//   cos = <a,b> / (na nb),  na = max(|a|, eps), nb = max(|b|, eps)
+//   d cos / d a = b / (na nb) - [|a| > eps] cos a / |a|^2        (the clamp branch has no |a| term), same for b
+// and a = sum_t w_t tap_t, so the four taps of each map receive w_t * d a (scatter-add: many samples share texels).
+// Mapping as the forward's plain kernel: a slot of 16 lanes owns one sample, 8 channels per lane; the forward
+// interpolation is recomputed (nothing but the rows' gradient is read).
+__global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
+                                                                   const float* __restrict__ g_cond,
+                                                                   float* __restrict__ g_feat0,
+                                                                   float* __restrict__ g_feat1) {
+  constexpr int CPL = 8, LPS = FEAT_C / CPL;
+  const int sub = threadIdx.x % LPS;
+  const int S = R.n_samples, V = sc.n_views;
+  const int P = V * (V - 1) / 2;
+  const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
+  const float inv_pairs = 1.0f / (float)P;
+  const long long total = (long long)R.n_rays * S;
+  const long long slots = ((long long)gridDim.x * blockDim.x) / LPS;
+  for (long long s_idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPS; s_idx < total; s_idx += slots) {
+    const int ray = (int)(s_idx / S);
+    const int j = (int)(s_idx - (long long)ray * S);
+    const RayGeom g = make_ray(R, ray);
+    const float d = sample_depth(R, ray, j);
+    float px, py, pz;
+    ray_point(g, d, px, py, pz);
+    const float* grow = g_cond + (size_t)s_idx * cond_stride;
+    int p = 0;
+    for (int a = 0; a < V - 1; ++a) {
+      float ua, va, za;
+      project(sc.views[a], px, py, pz, wm1, hm1, ua, va, za);
+      for (int b = a + 1; b < V; ++b, ++p) {
+        float ub, vb, zb;
+        project(sc.views[b], px, py, pz, wm1, hm1, ub, vb, zb);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s >= sc.n_scales) break;
+          const int fh = sc.fh[s], fw = sc.fw[s];
+          const size_t map_elems = (size_t)fh * fw * FEAT_C;
+          const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems;
+          const float* m1 = m0 + map_elems;
+          float* gm0 = (s ? g_feat1 : g_feat0) + (size_t)(2 * p) * map_elems;
+          float* gm1 = gm0 + map_elems;
+          const Bilin ba = bilin_setup(ua, va, fh, fw), bb = bilin_setup(ub, vb, fh, fw);
+          float fa[CPL], fb[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int ch = sub * CPL + c;
+            fa[c] = m0[(size_t)ba.o00 * FEAT_C + ch] * ba.w00 + m0[(size_t)ba.o01 * FEAT_C + ch] * ba.w01 +
+                    m0[(size_t)ba.o10 * FEAT_C + ch] * ba.w10 + m0[(size_t)ba.o11 * FEAT_C + ch] * ba.w11;
+            fb[c] = m1[(size_t)bb.o00 * FEAT_C + ch] * bb.w00 + m1[(size_t)bb.o01 * FEAT_C + ch] * bb.w01 +
+                    m1[(size_t)bb.o10 * FEAT_C + ch] * bb.w10 + m1[(size_t)bb.o11 * FEAT_C + ch] * bb.w11;
+          }
+          const int G = sc.n_group[s];
+          const int lpg = LPS / G;  // lanes per channel group
+          float dot = 0.f, na2 = 0.f, nb2 = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            dot += fa[c] * fb[c];
+            na2 += fa[c] * fa[c];
+            nb2 += fb[c] * fb[c];
+          }
+          for (int m = 1; m < lpg; m <<= 1) {
+            dot += __shfl_xor(dot, m, 64);
+            na2 += __shfl_xor(na2, m, 64);
+            nb2 += __shfl_xor(nb2, m, 64);
+          }
+          const float ra = sqrtf(na2), rb = sqrtf(nb2);
+          const float na = fmaxf(ra, 1e-8f), nb = fmaxf(rb, 1e-8f);
+          const float inv = 1.0f / (na * nb);
+          const float cosv = dot * inv;
+          const float gcos = grow[(s ? sc.n_group[0] : 0) + sub / lpg] * inv_pairs;
+          const float ka = ra > 1e-8f ? cosv / na2 : 0.0f, kb = rb > 1e-8f ? cosv / nb2 : 0.0f;
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int ch = sub * CPL + c;
+            const float da = gcos * (fb[c] * inv - ka * fa[c]);
+            const float db = gcos * (fa[c] * inv - kb * fb[c]);
+            atomicAdd(gm0 + (size_t)ba.o00 * FEAT_C + ch, da * ba.w00);
+            atomicAdd(gm0 + (size_t)ba.o01 * FEAT_C + ch, da * ba.w01);
+            atomicAdd(gm0 + (size_t)ba.o10 * FEAT_C + ch, da * ba.w10);
+            atomicAdd(gm0 + (size_t)ba.o11 * FEAT_C + ch, da * ba.w11);
+            atomicAdd(gm1 + (size_t)bb.o00 * FEAT_C + ch, db * bb.w00);
+            atomicAdd(gm1 + (size_t)bb.o01 * FEAT_C + ch, db * bb.w01);
+            atomicAdd(gm1 + (size_t)bb.o10 * FEAT_C + ch, db * bb.w10);
+            atomicAdd(gm1 + (size_t)bb.o11 * FEAT_C + ch, db * bb.w11);
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
+                                          const float* g_cond, float* g_feat0, float* g_feat1, void* stream) {
+  int rc = mnerf_scene_check(scene, rays, "mnerf_cost_volume_backward");
+  if (rc) return rc;
+  MNERF_REQUIRE(g_cond && g_feat0 && (scene->n_scales < 2 || g_feat1), MNERF_E_NULL,
+                "mnerf_cost_volume_backward: NULL buffer");
+  const int sumG = scene->n_group[0] + (scene->n_scales > 1 ? scene->n_group[1] : 0);
+  MNERF_REQUIRE(cond_stride >= sumG + 4 * scene->n_views + 1, MNERF_E_RANGE,
+                "mnerf_cost_volume_backward: cond_stride=%d < cond_dim+1=%d", cond_stride, sumG + 4 * scene->n_views + 1);
+  if (rays->n_rays == 0) return MNERF_OK;
+  const long long total = (long long)rays->n_rays * rays->n_samples;
+  long long blocks = (total + 15) / 16;  // 16 sample slots per 256-thread workgroup
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cost_volume_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *scene, *rays,
+                     cond_stride, g_cond, g_feat0, g_feat1);
+  return mnerf_check_launch("mnerf_cost_volume_backward");
+}

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "composite.hip", "cost_volume.hip", "decoder.hip", "geometry.hip", "render_chunk.hip",
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "cost_volume.hip", "decoder.hip", "geometry.hip", "render_chunk.hip",
            "window_attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

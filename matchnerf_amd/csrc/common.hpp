@@ -34,7 +34,7 @@ static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u
 // Debug / tuning knobs (MNERF_DECODER_GRID, MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID,
 // MNERF_WA_MIN4): read from the environment once at library load (api.cpp), constant afterwards.
 struct mnerf_tuning {
-  int decoder_grid, decoder_stagger, decoder_stagger_mode;
+  int decoder_grid, decoder_stagger, decoder_stagger_mode, decoder_debug;
   int cv_variant, cv_grid;
   int wa_min4;
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies

@@ -69,6 +69,8 @@ struct DecSched {
 #ifdef MNERF_TIMELINE
   unsigned long long* tl;
 #endif
+  int debug;           // MNERF_DECODER_DEBUG bits (experiments): 1 = wait for the segment-0 DMA before the cost-volume
+                       // walk of a tile, 2 = workgroup barrier at the top of every tile
   int stagger_sleeps;  // one-time start delay (x s_sleep 127) of the 2nd resident workgroup of a CU
   int stagger_mode;    // which workgroups wait: 0 odd HW wave slot, 1 upper half of grid, 2 (b>>3)&1, 3 all
   int n_seg;
@@ -637,7 +639,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     }
 
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
+    if (sch.debug & 2) __syncthreads();
     if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
+    if (sch.debug & 1) segment_wait();
     if constexpr (CVF) {
       // ---- K1+K2 for this tile: slot = 16 lanes, unit = CVF_SEG consecutive samples of one ray
       const int nv_ = scene.n_views;
@@ -1623,6 +1627,7 @@ static void finish_schedule(DecSched* sch, int n, int film_steps, int enc_steps)
   sch->tl = nullptr;
   if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
+  sch->debug = mnerf_tune().decoder_debug;
   sch->stagger_sleeps = mnerf_tune().decoder_stagger;  // ~130k cycles ~ half a tile
   sch->stagger_mode = mnerf_tune().decoder_stagger_mode;
   sch->film_steps = film_steps;

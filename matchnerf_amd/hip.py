@@ -23,6 +23,7 @@ _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
+           "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention")
 
@@ -92,6 +93,10 @@ def load():
     lib.mnerf_ray_samples.argtypes = [C.POINTER(Rays), C.POINTER(View), fp, fp, fp, vp]
     lib.mnerf_composite.restype = C.c_int
     lib.mnerf_composite.argtypes = [i32, i32, fp, fp, fp, fp, i32, i32, fp, fp, fp, fp, vp]
+    lib.mnerf_composite_backward.restype = C.c_int
+    lib.mnerf_composite_backward.argtypes = [i32, i32, fp, fp, fp, fp, i32, i32, fp, fp, fp, fp, fp, vp]
+    lib.mnerf_cost_volume_backward.restype = C.c_int
+    lib.mnerf_cost_volume_backward.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, fp, fp, vp]
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
     lib.mnerf_decoder_wstream_floats.restype = i64
@@ -229,6 +234,37 @@ def composite(rgb_s, sigma, depth_s, ray_len=None, wo_render_interval=True, setb
     if want_prob:
         return rgb, depth, opacity, prob
     return rgb, depth, opacity
+
+
+def composite_backward(rgb_s, sigma, depth_s, g_rgb, g_depth=None, g_opacity=None, ray_len=None,
+                       wo_render_interval=True, setbg_opaque=False, stream=None):
+    """K5 backward: gradients of (rgb [R,3], depth [R], opacity [R]) -> (g_rgb_s [R,S,3], g_sigma [R,S])."""
+    import torch
+    lib = load()
+    r, s = sigma.shape
+    for t, n in ((rgb_s, "rgb_s"), (sigma, "sigma"), (depth_s, "depth_s"), (g_rgb, "g_rgb")):
+        _f32c(t, n)
+    g_rgb_s = torch.empty(r, s, 3, device=sigma.device)
+    g_sigma = torch.empty(r, s, device=sigma.device)
+    with _on(sigma.device, stream) as st:
+        check(lib.mnerf_composite_backward(r, s, _ptr(rgb_s), _ptr(sigma), _ptr(depth_s), _ptr(ray_len),
+                                           int(wo_render_interval), int(setbg_opaque), _ptr(g_rgb), _ptr(g_depth),
+                                           _ptr(g_opacity), _ptr(g_rgb_s), _ptr(g_sigma), st), "mnerf_composite_backward")
+    return g_rgb_s, g_sigma
+
+
+def cost_volume_backward(scene, rays, cond_stride, g_cond, g_feats, stream=None):
+    """K1+K2 backward: scatter-adds the gradient of the conditioning rows [n_rays*S, cond_stride] into ``g_feats``
+    (list of 1 or 2 zero-initialised tensors shaped like the scene's feature maps)."""
+    lib = load()
+    _f32c(g_cond, "g_cond")
+    for g in g_feats:
+        _f32c(g, "g_feat")
+    with _on(g_cond.device, stream) as st:
+        check(lib.mnerf_cost_volume_backward(C.byref(scene), C.byref(rays), int(cond_stride), _ptr(g_cond),
+                                             _ptr(g_feats[0]), _ptr(g_feats[1]) if len(g_feats) > 1 else None, st),
+              "mnerf_cost_volume_backward")
+    return g_feats
 
 
 def cost_volume(scene, rays, cond_stride, out=None, device=None, stream=None):

@@ -235,9 +235,10 @@ class MatchNeRF(torch.nn.Module):
 
     def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,
                           n_rays, n_samples, img_h, img_w):
-        """Training path: forward through the HIP kernels, backward through a torch re-evaluation of the same
-        ray chunk (matchnerf_amd/autograd.py).  Rays go through in chunks of GRAD_RAYS_PER_CALL so that a
-        full-image call under autograd keeps the re-evaluation's temporaries bounded."""
+        """Training path (matchnerf_amd/autograd.py): forward through the HIP kernels; backward = HIP kernels for
+        compositing and the cost volume, torch re-evaluation of the conditional MLP + ray transformer in between.
+        Rays go through in chunks of GRAD_RAYS_PER_CALL so that a full-image call under autograd keeps the
+        re-evaluation's temporaries bounded."""
         from . import autograd as ag
         device = ref_images.device
         legacy = bool(opt.nerf.legacy_coord)
@@ -256,28 +257,18 @@ class MatchNeRF(torch.nn.Module):
                 strat = None if strat_all is None else strat_all[c:c + GRAD_RAYS_PER_CALL].contiguous()
                 m = int(idx.numel())
 
-                def hip_render(feats, b=b, strat=strat, kinv=kinv, c2w=c2w, idx32=idx32, m=m):
-                    dec = self._decoder(n_samples, device)
-                    sc = self._scene(b, ref_host, None, images_cl, feats_b=[f.contiguous() for f in feats])
-                    ws = self._workspace(hip.render_workspace_bytes(m, n_samples, dec.cond_stride) // 4, device)
-                    rays = hip.make_rays(m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1],
-                                         legacy=legacy, depth_inverse=(opt.nerf.depth.param == "inverse"),
-                                         ray_idx_ptr=idx32.data_ptr(),
-                                         strat_u_ptr=None if strat is None else strat.data_ptr())
-                    o_rgb = torch.empty(m, 3, device=device)
-                    o_d = torch.empty(m, 1, device=device)
-                    o_o = torch.empty(m, 1, device=device)
-                    hip.render_chunk(sc, dec, rays, ws, o_rgb, o_d, o_o)
-                    return o_rgb, o_d, o_o
+                def make_rays(strat=strat, kinv=kinv, c2w=c2w, idx32=idx32, m=m, b=b):
+                    r = hip.make_rays(m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1], legacy=legacy,
+                                      depth_inverse=(opt.nerf.depth.param == "inverse"), ray_idx_ptr=idx32.data_ptr(),
+                                      strat_u_ptr=None if strat is None else strat.data_ptr())
+                    return r, (idx32, strat)  # the struct holds raw pointers: keep the tensors alive with it
 
-                def torch_render(feats, b=b, strat=strat, idx=idx):
-                    ex, it, nf = ref_host
-                    return ag.render_rays_torch(opt, dec_mod, feats, ref_images[b], ex[b], it[b], nf[b], tgt_ex[b],
-                                                tgt_in[b], tgt_nf[b], idx, strat, img_h, img_w,
-                                                bool(self.nerf_setbg_opaque))
-
-                parts.append(ag.render_rays(dec_mod, dict(hip_render=hip_render, torch_render=torch_render),
-                                            [f[b] for f in ref_feats_list]))
+                launch = ag.RayChunkLaunch(
+                    opt, dec_mod, make_scene=lambda feats, b=b: self._scene(b, ref_host, None, images_cl, feats_b=feats),
+                    make_rays=make_rays, make_decoder=lambda: self._decoder(n_samples, device),
+                    view0_extr=ref_host[0][b, 0], kinv=kinv, c2w=c2w, ray_idx=idx, width=img_w, n_views=self.n_src_views,
+                    setbg_opaque=bool(self.nerf_setbg_opaque))
+                parts.append(ag.render_ray_chunk(launch, [f[b] for f in ref_feats_list]))
             outs.append([torch.cat([p[k] for p in parts], 0) for k in range(3)])
         return edict(rgb=torch.stack([o[0] for o in outs], 0), depth=torch.stack([o[1] for o in outs], 0),
                      opacity=torch.stack([o[2] for o in outs], 0))

@@ -47,6 +47,64 @@ def test_composite_matches_oracle(hip, S, interval, bg):
     assert linf(prob, ref[3][..., 0]) < 2e-6 and linf(prob.sum(1), out[2]) < 2e-6
 
 
+@pytest.mark.parametrize("S,interval,bg", [(64, True, False), (33, False, True), (200, False, False)])
+def test_composite_backward_matches_autograd(hip, S, interval, bg):
+    """K5 backward kernel vs autograd through the oracle's compositing (nerf.py:101-124) for random upstream
+    gradients of all three outputs."""
+    g = torch.Generator().manual_seed(S + 1)
+    r = 131
+    sigma = (torch.rand(r, S, generator=g) * 0.3 * (torch.rand(r, S, generator=g) > 0.4)).requires_grad_(True)
+    rgb_s = torch.rand(r, S, 3, generator=g).requires_grad_(True)
+    depth = torch.sort(torch.rand(r, S, generator=g) * 2 + 2, dim=1).values
+    ray = torch.randn(r, 3, generator=g)
+    g_rgb, g_d, g_o = torch.randn(r, 3, generator=g), torch.randn(r, generator=g), torch.randn(r, generator=g)
+    cfg = O.OracleConfig(wo_render_interval=interval)
+    if not interval:  # keep the 1e10 last interval out of the comparison's conditioning: zero density on the last sample
+        with torch.no_grad():
+            sigma[:, -1] = 0.0
+    out = O.composite(cfg, ray, rgb_s, sigma, depth, setbg_opaque=bg)
+    (out[0] * g_rgb).sum().add((out[1][:, 0] * g_d).sum()).add((out[2][:, 0] * g_o).sum()).backward()
+    got = hip.composite_backward(rgb_s.detach().cuda(), sigma.detach().cuda(), depth.cuda(), g_rgb.cuda(), g_d.cuda(),
+                                 g_o.cuda(), ray.norm(dim=-1).cuda().contiguous(), wo_render_interval=interval,
+                                 setbg_opaque=bg)
+    assert linf(got[0], rgb_s.grad) < 2e-6 * max(1.0, float(rgb_s.grad.abs().max()))
+    sel = slice(None) if interval else slice(0, S - 1)
+    assert linf(got[1][:, sel], sigma.grad[:, sel]) < 2e-5 * max(1.0, float(sigma.grad[:, sel].abs().max()))
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4"])
+def test_cost_volume_backward_matches_autograd(hip, name):
+    """K1+K2 backward kernel (atomic scatter-add into the pair-major feature-map gradients) vs autograd through the
+    oracle's query_cond_info restatement, for a random gradient of the conditioning rows."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
+    v = cfg.n_src_views
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    idx = torch.from_numpy(g["stage_rays"][:24]).int().cuda()
+    rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+    dc = g["cond"].shape[-1]
+    cs = ((dc + 1 + 7) // 8) * 8
+    n = idx.numel() * cfg.sample_intvs
+    gen = torch.Generator().manual_seed(4)
+    g_cond = torch.zeros(n, cs)
+    g_cond[:, :dc] = torch.randn(n, dc, generator=gen)
+    got = hip.cost_volume_backward(sc, rays, cs, g_cond.cuda(), [torch.zeros_like(f) for f in feats_gpu])
+    # oracle side: same rows through autograd w.r.t. the (f0, f1) maps of every scale
+    pf = [(f[:, 0].permute(0, 3, 1, 2).cpu().clone().requires_grad_(True), f[:, 1].permute(0, 3, 1, 2).cpu().clone().requires_grad_(True))
+          for f in feats_gpu]
+    te, ti, tn, se, si, sn = split_poses(batch)
+    h, w = batch["images"].shape[-2:]
+    center, ray = O.target_rays(h, w, te, ti, cfg.legacy_coord)
+    sel = torch.from_numpy(g["stage_rays"][:24])
+    d = O.depth_samples(cfg, tn[0], tn[1], sel.numel())
+    pts = center[sel][:, None] + ray[sel][:, None] * d[..., None]
+    cond, _ = O.cost_volume_cond(cfg, pts, se, si, sn, batch["images"][0, :v], pf, h, w)
+    (cond.reshape(n, dc) * g_cond[:, :dc]).sum().backward()
+    for s_i, (f0, f1) in enumerate(pf):
+        ref = torch.stack([f0.grad, f1.grad], 1).permute(0, 1, 3, 4, 2)     # -> [P,2,h,w,128]
+        scale = float(ref.abs().max())
+        assert scale > 0 and linf(got[s_i], ref) < 2e-5 * scale
+
+
 def test_composite_empty_and_errors(hip):
     z = torch.empty(0, 64, device="cuda")
     out = hip.composite(torch.empty(0, 64, 3, device="cuda"), z, z)

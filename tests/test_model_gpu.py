@@ -114,9 +114,10 @@ def test_random_ray_mode_matches_oracle():
 
 
 def test_train_mode_gradients_match_oracle_autograd():
-    """mode='train' under autograd: forward values from the HIP kernels, gradients from the torch
-    re-evaluation in matchnerf_amd/autograd.py — compared with autograd through the CPU oracle."""
-    g, cfg, sd, batch_cpu = golden_case("nonlegacy")
+    """mode='train' under autograd: forward values from the HIP kernels; backward = HIP kernels for compositing and the
+    cost volume + torch re-evaluation of the MLP on the forward's own sample coordinates (matchnerf_amd/autograd.py)
+    — compared with autograd through the CPU oracle on all nine probe parameters."""
+    g, cfg, sd, batch_cpu = golden_case("c1_default")
     opt, model = build_model(g["meta"])
     model.train()
     opt.nerf.rand_rays_train = 96
@@ -126,7 +127,7 @@ def test_train_mode_gradients_match_oracle_autograd():
     out = model(batch, mode="train")
     idx = out.ray_idx
     gt = batch.images[:, -1].reshape(1, 3, -1).permute(0, 2, 1)[:, idx]
-    loss = ((out.rgb - gt) ** 2).mean() + 0.1 * out.opacity.mean()
+    loss = ((out.rgb - gt) ** 2).mean() + 0.1 * out.opacity.mean() + 0.05 * out.depth.mean()
     loss.backward()
 
     sd_req = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -134,7 +135,7 @@ def test_train_mode_gradients_match_oracle_autograd():
     feats = O.encode_pairs(cfg, sd_req, batch_cpu["images"][0, :v])
     ref = O.render_rays(cfg, sd_req, idx.cpu(), *split_poses(batch_cpu), batch_cpu["images"][0, :v], feats)
     gt_c = batch_cpu["images"][0, -1].reshape(3, -1).t()[idx.cpu()]
-    loss_ref = ((ref[0] - gt_c) ** 2).mean() + 0.1 * ref[2].mean()
+    loss_ref = ((ref[0] - gt_c) ** 2).mean() + 0.1 * ref[2].mean() + 0.05 * ref[1].mean()
     loss_ref.backward()
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
     params = dict(model.named_parameters())
@@ -150,9 +151,9 @@ def test_train_mode_gradients_match_oracle_autograd():
         print(f"grad {name}: max|ref| {scale:.3e} rel err {rel:.2e}")
         worst = max(worst, rel)
         checked += 1
-    # head parameters agree to ~1e-5; parameters upstream of the positional encoding / bilinear taps to
-    # < 1 % of the gradient's max (torch-GPU vs torch-CPU coordinates differ by ulps, amplified 2^9 x)
-    assert checked == 9 and worst < 2e-2, worst
+    # decoder parameters: the re-evaluation runs on the forward's own (bit-exact) sample coordinates, so they agree to
+    # fp32 noise; encoder parameters go through library convolutions / GEMMs in a different summation order
+    assert checked == 9 and worst < 1e-3, worst
 
 
 def test_stratified_depths_match_oracle():
@@ -183,9 +184,11 @@ def test_stratified_depths_match_oracle():
 
 
 def test_video_mode_renders_each_pose():
-    """render_video: every streamed frame against the CPU ORACLE rendering the same pose (two poses in full),
-    plus shape / device / distinctness checks for all frames."""
-    g, cfg, sd, batch_cpu = golden_case("nonlegacy")
+    """render_video: streamed frames against the CPU ORACLE rendering the same pose (two poses in full), plus shape /
+    device / distinctness checks for all frames.  (Legacy-coordinate case: with render intervals the reference's
+    1e10 last interval turns fp32 noise in the last density into 1e-4-class colour changes at some poses — in every
+    matrix path alike — which makes that variant a poor oracle target away from its golden pose.)"""
+    g, cfg, sd, batch_cpu = golden_case("c1_default")
     opt, model = build_model(g["meta"])
     opt.nerf.video_n_frames = 6
     batch = to_batch(g)
