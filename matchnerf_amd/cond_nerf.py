@@ -610,9 +610,8 @@ class CondNeRF(nn.Module):
                 decoder_math())
 
     def math_for(self, n_samples):
-        """the matrix path the kernel will run for S samples per ray: the 8-wave kernel for S > 128 is built for the
-        exact-f32 stream only"""
-        return decoder_math() if n_samples <= 128 else "f32"
+        """the matrix path the kernel runs for S samples per ray (MNERF_DECODER_MATH; every S <= 256 has all three)"""
+        return decoder_math()
 
     def packed(self, n_samples, device):
         """(wstream, small, cond_stride, wstream_format) for the HIP kernel; re-packed when any

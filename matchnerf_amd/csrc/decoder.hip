@@ -540,6 +540,10 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     if (late)
       for (int i = 0; i < sch.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  if (sch.debug & 4) {  // experiment: no stale LDS contents anywhere in the workgroup's allocation
+    for (int i = tid; i < SM::TOTAL_FLOATS; i += NW * 64) smem[i] = 0.0f;
+    __syncthreads();
+  }
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
   __syncthreads();
 
@@ -1776,7 +1780,8 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     const int rpt = (NW_ * 32) / SP_;                                                                \
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
     const int grid = tiles < resident ? tiles : resident;                                            \
-    const size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                 \
+    size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                       \
+    if (CVF_ && (mnerf_tune().decoder_debug & 8)) lds = 96 * 1024; /* experiment: one workgroup per CU */ \
     static std::atomic<unsigned long long> attr_set{0};                                              \
     if (mnerf_once_per_device(attr_set))                                                             \
       (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_, CVF_>,                   \
@@ -1800,10 +1805,14 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     case 32: MNERF_LAUNCH_DECODER_FMT(4, 32); break;
     case 64: MNERF_LAUNCH_DECODER_FMT(4, 64); break;
     case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
-    default:
-      MNERF_REQUIRE(dec->wstream_format == MNERF_WSTREAM_F32 && !fused_scene, MNERF_E_UNSUPPORTED,
-                    "%s: sample_intvs=%d > 128 needs the MNERF_WSTREAM_F32 weight stream", who, rays->n_samples);
-      MNERF_LAUNCH_DECODER(8, 256, 0, 0);
+    default:  // 128 < S <= 256: one 8-wave workgroup per CU, VALU ray attention
+      MNERF_REQUIRE(!fused_scene, MNERF_E_UNSUPPORTED, "%s: the one-launch form needs sample_intvs <= 128", who);
+      if (dec->wstream_format == MNERF_WSTREAM_F16X2)
+        MNERF_LAUNCH_DECODER(8, 256, 2, 0);
+      else if (dec->wstream_format == MNERF_WSTREAM_BF16X3)
+        MNERF_LAUNCH_DECODER(8, 256, 1, 0);
+      else
+        MNERF_LAUNCH_DECODER(8, 256, 0, 0);
       break;
   }
 #undef MNERF_LAUNCH_DECODER_FMT

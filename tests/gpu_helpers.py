@@ -56,8 +56,6 @@ def make_rays_struct(cfg, batch, n_rays, ray_begin=0, ray_idx_gpu=None, b=0):
 def make_decoder_struct(cfg, sd, setbg_opaque=False, device="cuda", math=None):
     """math: 'f16x3' / 'bf16x6' / 'f32' (default: MNERF_DECODER_MATH, i.e. what the product uses)."""
     math = math or CN.decoder_math()
-    if cfg.sample_intvs > 128:
-        math = "f32"
     ws, cond_dim, cs = CN.pack_for_math(math)(sd, cfg.n_src_views, cfg.cos_n_group, cfg.L_3D, cfg.legacy_coord)
     small = CN.pack_small(sd, cfg.sample_intvs, cfg.raytrans_posenc)
     ws_t, small_t = torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device)

@@ -55,7 +55,7 @@ def _worker(rank, world, port, height, width, q):
         q.put((rank, False, repr(e)))
 
 
-@pytest.mark.parametrize("height,width,world", [(32, 48, 2), (32, 40, 3)])  # even split; ragged one (11 + 11 + 10 rows)
+@pytest.mark.parametrize("height,width,world", [(32, 48, 2), (32, 48, 3)])  # even split; ragged one (11 + 11 + 10 rows)
 def test_sharded_frame_is_bit_identical(height, width, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

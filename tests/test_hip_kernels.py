@@ -272,30 +272,40 @@ def test_decoder_math_variants_agree_on_rescaled_weights(hip, seed):
 
 def test_split_fp16_gains_cover_extreme_magnitudes(hip):
     """fp16 has a 5-bit exponent: the per-sample activation gains and per-tensor weight scales must keep the
-    split-fp16 path finite and accurate when whole tensors are scaled by 2^+-12 (hidden activations around
-    1e4 .. 1e-4), where an unscaled fp16 operand would overflow to inf or lose its low term."""
+    split-fp16 path finite and fp32-grade when whole tensors are scaled by 2^+-12 (hidden activations around
+    1e4 .. 1e-4 and beyond), where an unscaled fp16 operand would overflow to inf or lose its low term.  Judge: the
+    same rescaled network evaluated in float64; the split path may not be materially worse than the exact-f32 MFMA."""
     g, cfg, sd, batch, _, _ = _case_on_gpu("c1_default")
     idx = torch.from_numpy(g["stage_rays"]).int().cuda()
     rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
     n, s, dc = g["cond"].shape
     view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
                           float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
-    for big, small in (("nerf_dec.pts_linears.0.", "nerf_dec.pts_linears.3."), ("nerf_dec.pts_linears.2.", "nerf_dec.pts_linears.0.")):
+    for big, small in (("nerf_dec.pts_linears.0.", "nerf_dec.pts_linears.3."), ("nerf_dec.pts_linears.2.", "nerf_dec.pts_linears.0."),
+                       ("nerf_dec.feature_linear.", "nerf_dec.pts_linears.1.")):
         sd2 = dict(sd)
         for k in sd:
             if k.startswith(big):
-                sd2[k] = sd[k] * 4096.0          # exact power-of-two rescale: ReLU / FiLM are positively homogeneous,
+                sd2[k] = sd[k] * 4096.0
             if k.startswith(small):
-                sd2[k] = sd[k] / 4096.0          # so the network function is unchanged up to rounding
+                sd2[k] = sd[k] / 4096.0
         res = {}
         for math in ("f16x3", "f32"):
             dec, keep = make_decoder_struct(cfg, sd2, math=math)
             cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(n * s, dc), dec.cond_stride).cuda()
-            res[math] = hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)
+            res[math] = [t.cpu() for t in hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)]
+        with torch.no_grad():
+            sd64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in sd2.items()}
+            cond64 = torch.from_numpy(g["cond"]).double()
+            rgb64, sig64 = O.decoder(cfg, sd64, torch.from_numpy(g["x_ref"]).double(), torch.from_numpy(g["dir_ref"]).double(),
+                                     cond64, cond64[..., -cfg.n_src_views:])
         assert torch.isfinite(res["f16x3"][3]).all() and torch.isfinite(res["f16x3"][4]).all()
-        # biases break exact homogeneity, so compare the two matrix paths on the SAME rescaled network
-        assert linf(res["f16x3"][3], res["f32"][3]) < 1e-5
-        assert linf(res["f16x3"][4], res["f32"][4]) < 2e-5 * max(1.0, float(res["f32"][4].abs().max()))
+        e_rgb = {m: linf(res[m][3].double(), rgb64) for m in res}
+        e_sig = {m: linf(res[m][4].double(), sig64) for m in res}
+        print(f"\n[{big} x4096, {small} /4096] vs float64: rgb_s f16x3 {e_rgb['f16x3']:.2e} / f32 {e_rgb['f32']:.2e}; "
+              f"sigma f16x3 {e_sig['f16x3']:.2e} / f32 {e_sig['f32']:.2e} (max sigma {float(sig64.abs().max()):.2e})")
+        assert e_rgb["f16x3"] < 3.0 * e_rgb["f32"] + 2e-6
+        assert e_sig["f16x3"] < 3.0 * e_sig["f32"] + 2e-6 * max(1.0, float(sig64.abs().max()))
 
 
 @pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy"])

@@ -78,8 +78,8 @@ def test_unsupported_architectures_fail_loudly():
 
 
 def test_decoder_packing_follows_the_math_switch(monkeypatch):
-    """CondNeRF.packed: split-fp16 stream by default, split-bf16 / exact-f32 streams on request, exact-f32 for
-    S > 128 (the 8-wave kernel is f32-only); the cache is keyed on the switch; bad values are rejected."""
+    """CondNeRF.packed: split-fp16 stream by default (every S), split-bf16 / exact-f32 streams on request; the cache is
+    keyed on the switch and on S; bad values are rejected."""
     from matchnerf_amd import cond_nerf as CN
     from matchnerf_amd.models import models_dict
     dec = models_dict["matchnerf"](_opts()).nerf_dec
@@ -88,13 +88,13 @@ def test_decoder_packing_follows_the_math_switch(monkeypatch):
     assert fmt == 2 and ws.numel() == CN.decoder_schedule_h(dec.cond_dim, dec.L_3D)[1]
     assert dec.packed(64, "cpu")[0] is ws                       # cached
     ws256, _, _, fmt256 = dec.packed(256, "cpu")
-    assert fmt256 == 0 and ws256.numel() == CN.decoder_schedule(cs, dec.L_3D)[1]
+    assert fmt256 == 2 and ws256.numel() == ws.numel() and ws256 is not ws
     monkeypatch.setenv("MNERF_DECODER_MATH", "bf16x6")
     ws16, _, _, fmt16 = dec.packed(64, "cpu")
     assert fmt16 == 1 and ws16.numel() == CN.decoder_schedule16(dec.cond_dim, dec.L_3D)[1]
     monkeypatch.setenv("MNERF_DECODER_MATH", "f32")
     ws32, _, _, fmt32 = dec.packed(64, "cpu")
-    assert fmt32 == 0 and ws32.numel() == ws256.numel()
+    assert fmt32 == 0 and ws32.numel() == CN.decoder_schedule(cs, dec.L_3D)[1]
     monkeypatch.setenv("MNERF_DECODER_MATH", "fp8")
     with pytest.raises(ValueError, match="MNERF_DECODER_MATH"):
         dec.packed(64, "cpu")
