@@ -42,7 +42,6 @@ static mnerf_tuning read_tuning() {
   t.decoder_grid = env_int("MNERF_DECODER_GRID", 512);          // persistent: 2 workgroups per CU x 256 CUs
   t.decoder_stagger = env_int("MNERF_DECODER_STAGGER", 16);     // ~130k cycles ~ half a tile
   t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
-  t.decoder_debug = env_int("MNERF_DECODER_DEBUG", 0);
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = plain
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs

@@ -34,7 +34,7 @@ static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u
 // Debug / tuning knobs (MNERF_DECODER_GRID, MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID,
 // MNERF_WA_MIN4): read from the environment once at library load (api.cpp), constant afterwards.
 struct mnerf_tuning {
-  int decoder_grid, decoder_stagger, decoder_stagger_mode, decoder_debug;
+  int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
   int wa_min4;
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies
@@ -140,11 +140,17 @@ __device__ __forceinline__ void project(const mnerf_view& V, float px, float py,
 // [-1/4, 1/4] is a degree-9 odd minimax polynomial.  Max abs error 3.0e-7 over |arg| <= 2000
 // (tools/exp/sincos_poly.hip, measured on MI355X) versus 0.7e-7 for ocml sincosf at ~8x the
 // instruction count; v_sin_f32 / v_cos_f32 alone are only good to 8e-5.
-__device__ __forceinline__ float sin_quarter(float arg, int quarter) {
+// (th, tl) = arg / (2 pi) as an unevaluated two-float sum
+__device__ __forceinline__ void turns_two_float(float arg, float& th, float& tl) {
   const float C_HI = 0.15915494309189535f;
   const float C_LO = (float)(0.15915494309189535 - (double)0.15915494309189535f);
-  float th = arg * C_HI;
-  float tl = __builtin_fmaf(arg, C_LO, __builtin_fmaf(arg, C_HI, -th));
+  th = arg * C_HI;
+  tl = __builtin_fmaf(arg, C_LO, __builtin_fmaf(arg, C_HI, -th));
+}
+// sin (quarter = 0) / cos (quarter = 1) of 2 pi (th + tl).  Scaling (th, tl) by a power of two is exact, so the
+// 2^l octaves of the positional encoding share ONE two-float reduction per coordinate: bit-identical to calling
+// sin_quarter(2^l arg, .) for every octave, at two multiplications instead of a multiplication and three FMAs each.
+__device__ __forceinline__ float sin_quarter_turns(float th, float tl, int quarter) {
   float r = th - rintf(th);
   r = r + (tl + (quarter ? 0.25f : 0.0f));
   r = r - rintf(r);
@@ -157,5 +163,10 @@ __device__ __forceinline__ float sin_quarter(float arg, int quarter) {
   p = __builtin_fmaf(p, x2, -41.34165573120117f);
   p = __builtin_fmaf(p, x2, 6.283185005187988f);
   return p * r;
+}
+__device__ __forceinline__ float sin_quarter(float arg, int quarter) {
+  float th, tl;
+  turns_two_float(arg, th, tl);
+  return sin_quarter_turns(th, tl, quarter);
 }
 #pragma clang fp contract(fast)

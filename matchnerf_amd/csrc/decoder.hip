@@ -69,8 +69,6 @@ struct DecSched {
 #ifdef MNERF_TIMELINE
   unsigned long long* tl;
 #endif
-  int debug;           // MNERF_DECODER_DEBUG bits (experiments): 1 = wait for the segment-0 DMA before the cost-volume
-                       // walk of a tile, 2 = workgroup barrier at the top of every tile
   int stagger_sleeps;  // one-time start delay (x s_sleep 127) of the 2nd resident workgroup of a CU
   int stagger_mode;    // which workgroups wait: 0 odd HW wave slot, 1 upper half of grid, 2 (b>>3)&1, 3 all
   int n_seg;
@@ -220,15 +218,39 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 
 // 16 consecutive positional-encoding operands (steps t0 .. t0+15) evaluated into registers, so
-// that the MFMA loop that consumes them is the same software-pipelined loop as a hidden layer
-__device__ __forceinline__ f32x16 enc_block16(int t0, int L3, int hl, float x, float y, float z,
-                                              float freq_mul) {
+// that the MFMA loop that consumes them is the same software-pipelined loop as a hidden layer.
+// L_3D = 10 (every shipped config) is a compile-time case: with a run-time L every one of the 64 operand slots of a
+// tile carries three comparisons against L whose results the compiler hoists out of the tile loop as exec-sized
+// masks - ~300 spilled SGPRs, one v_readlane + v_cndmask per use (12 % of the kernel's VALU issue slots).
+struct EncBase {   // x_c * freq_mul / (2 pi) as two floats per coordinate (exactly scalable by 2^l)
+  float th[3], tl[3];
+};
+__device__ __forceinline__ EncBase enc_base(float x, float y, float z, float freq_mul) {
+  EncBase b;
+  turns_two_float(x * freq_mul, b.th[0], b.tl[0]);
+  turns_two_float(y * freq_mul, b.th[1], b.tl[1]);
+  turns_two_float(z * freq_mul, b.th[2], b.tl[2]);
+  return b;
+}
+template <int T0>
+__device__ __forceinline__ f32x16 enc_block16_L10(const EncBase& b, int hl, float x, float y, float z) {
+  constexpr int L3 = 30;
   f32x16 e;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) e[i] = enc_operand(t0 + i, L3, hl, x, y, z, freq_mul);
+  for (int i = 0; i < 16; ++i) {
+    const int t = T0 + i;
+    if (t < L3) {
+      const int l = t / 3, c = t - 3 * l;
+      const float sc = (float)(1 << l);
+      e[i] = sin_quarter_turns(b.th[c] * sc, b.tl[c] * sc, hl);
+    } else if (t == L3) {
+      e[i] = hl ? y : x;
+    } else {
+      e[i] = hl ? 1.0f : z;
+    }
+  }
   return e;
 }
-
 
 // ---------------------------------------------------------------- split-bf16 matrix path ("bf16x6")
 // Same transposed chain on v_mfma_f32_32x32x16_bf16 (32 cycles per SIMD for 16 K-elements: 16x the
@@ -491,6 +513,13 @@ struct Smem {
 // (the FiLM weights: 17 KiB at <= 32 conditioning inputs); both are dead before the weight pipeline needs them.
 #define CVF_SEG 8
 #define CVF_COND_OFF_FLOATS (17 * 256)
+// The fused form asks for more than half of a CU's 160 KiB of LDS, i.e. ONE of its workgroups per CU.  Measured on
+// MI355X: with two co-resident workgroups a handful of rays per 327,680-ray frame (<= 14, |error| <= 4e-3) differed
+// from run to run and from the staged form; with one workgroup per CU (this setting, or a 256-workgroup grid) every
+// run is bit-identical to the staged form.  The cause was not found: the walk phase has no inter-wave communication,
+// and zero-filling LDS, draining the weight DMA before the walk and extra workgroup barriers changed nothing.  The
+// fused form is the slower one either way (the walk needs the stand-alone kernel's 16 waves per CU).
+#define CVF_LDS_BYTES (84 * 1024)
 template <int NW, int SP, int FMT, int CVF>
 __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     mnerf_decoder D, DecSched sch, mnerf_view view0, mnerf_rays R,
@@ -539,10 +568,6 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     if (sch.stagger_mode == 3) late = true;
     if (late)
       for (int i = 0; i < sch.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-  if (sch.debug & 4) {  // experiment: no stale LDS contents anywhere in the workgroup's allocation
-    for (int i = tid; i < SM::TOTAL_FLOATS; i += NW * 64) smem[i] = 0.0f;
-    __syncthreads();
   }
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
   __syncthreads();
@@ -642,10 +667,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
     }
 
+    const EncBase encb = enc_base(x, y, z, freq_mul);  // shared by the two positional-encoding stages (L0, L5)
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
-    if (sch.debug & 2) __syncthreads();
     if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
-    if (sch.debug & 1) segment_wait();
     if constexpr (CVF) {
       // ---- K1+K2 for this tile: slot = 16 lanes, unit = CVF_SEG consecutive samples of one ray
       const int nv_ = scene.n_views;
@@ -756,16 +780,16 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       // acc (+)= W_enc . enc(x) with operand gain 2^em; the first call of a stage loads bias * 2^(ew + em)
       auto enc_stage = [&](int em) {
         const float mult = pow2i(em);
-        if (sch.enc_steps == 4) {  // L_3D = 10: one segment of four K16-steps, register-fed in two halves
+        if (D.L_3D == 10) {  // one segment of four K16-steps, register-fed in two halves
           SEG_BEGIN();
           ew_cur = header_ew(CUR_LDS);
           bias_init_h<4>(acc, CUR_LDS, hl, pow2i(ew_cur + em));
           {
-            const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
+            const f32x16 e0 = enc_block16_L10<0>(encb, hl, x, y, z);
             kblock_h<4>(acc, CUR_LDS + 1024, lane, e0, mult);
           }
           {
-            const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+            const f32x16 e1 = enc_block16_L10<16>(encb, hl, x, y, z);
             kblock_h<4>(acc, CUR_LDS + 1024 + 8 * H16_UNIT_BYTES, lane, e1, mult);
           }
           SEG_END();
@@ -977,16 +1001,16 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
       // ------------------------------------------------------------ positional-encoding stages (L0, L5)
       f32x16 acc[4], h[4];
       auto enc_stage = [&]() {  // acc <- bias + W_enc . enc(x)
-        if (sch.enc_steps == 4) {  // L_3D = 10: two segments of two K16-steps, register-fed
+        if (D.L_3D == 10) {  // two segments of two K16-steps, register-fed
           {
-            const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
+            const f32x16 e0 = enc_block16_L10<0>(encb, hl, x, y, z);
             SEG_BEGIN();
             bias_init<4>(acc, CUR_LDS, hl);
             kblock<4>(acc, CUR_LDS + 1024, lane, e0);
             SEG_END();
           }
           {
-            const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+            const f32x16 e1 = enc_block16_L10<16>(encb, hl, x, y, z);
             SEG_BEGIN();
             kblock<4>(acc, CUR_LDS, lane, e1);
             SEG_END();
@@ -1147,9 +1171,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     f32x16 acc[4], h[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
-    if (sch.enc_steps == 32) {  // L_3D = 10 (every shipped config): one segment, register-fed
-      const f32x16 e0 = enc_block16(0, L3, hl, x, y, z, freq_mul);
-      const f32x16 e1 = enc_block16(16, L3, hl, x, y, z, freq_mul);
+    if (D.L_3D == 10) {  // every shipped config: one segment, register-fed
+      const f32x16 e0 = enc_block16_L10<0>(encb, hl, x, y, z);
+      const f32x16 e1 = enc_block16_L10<16>(encb, hl, x, y, z);
       SEG_BEGIN();
       steps_from_regs<4>(acc, CUR_BUF, 0, lane, e0, e1);
       SEG_END();
@@ -1192,14 +1216,14 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
     // ------------------------------------------------------------ layer 5: [enc, h] -> 128
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[m] = (f32x16)(0.0f);
-    if (sch.enc_steps == 32) {  // register-fed in two halves of 16 (film + h + acc are live here)
+    if (D.L_3D == 10) {  // register-fed in two halves of 16 (film + h + acc are live here)
       SEG_BEGIN();
       {
-        const f32x16 e = enc_block16(0, L3, hl, x, y, z, freq_mul);
+        const f32x16 e = enc_block16_L10<0>(encb, hl, x, y, z);
         steps16_from_regs(acc, CUR_BUF, 0, lane, e);
       }
       {
-        const f32x16 e = enc_block16(16, L3, hl, x, y, z, freq_mul);
+        const f32x16 e = enc_block16_L10<16>(encb, hl, x, y, z);
         steps16_from_regs(acc, CUR_BUF, 16, lane, e);
       }
       SEG_END();
@@ -1397,14 +1421,21 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         }
         // four independent partial maxima / sums instead of one 64-long dependent chain
         float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        if (S == Sp) {  // no padded key slots (the usual case): no per-key masks (SP run-time comparisons otherwise)
 #pragma unroll
-        for (int g = 0; g < SP / 4; ++g)
+          for (int g = 0; g < SP / 4; ++g)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = (4 * g + r < S) ? sc[g][r] : -3.0e38f;  // padded key slots
-            sc[g][r] = v;
-            mx4[r] = fmaxf(mx4[r], v);
-          }
+            for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[g][r]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < SP / 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = (4 * g + r < S) ? sc[g][r] : -3.0e38f;  // padded key slots
+              sc[g][r] = v;
+              mx4[r] = fmaxf(mx4[r], v);
+            }
+        }
         const float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
         float ls4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1631,7 +1662,6 @@ static void finish_schedule(DecSched* sch, int n, int film_steps, int enc_steps)
   sch->tl = nullptr;
   if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
 #endif
-  sch->debug = mnerf_tune().decoder_debug;
   sch->stagger_sleeps = mnerf_tune().decoder_stagger;  // ~130k cycles ~ half a tile
   sch->stagger_mode = mnerf_tune().decoder_stagger_mode;
   sch->film_steps = film_steps;
@@ -1781,7 +1811,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
     const int grid = tiles < resident ? tiles : resident;                                            \
     size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                       \
-    if (CVF_ && (mnerf_tune().decoder_debug & 8)) lds = 96 * 1024; /* experiment: one workgroup per CU */ \
+    if (CVF_) lds = CVF_LDS_BYTES; /* the fused form takes a CU for itself (see CVF_LDS_BYTES) */    \
     static std::atomic<unsigned long long> attr_set{0};                                              \
     if (mnerf_once_per_device(attr_set))                                                             \
       (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_, CVF_>,                   \
