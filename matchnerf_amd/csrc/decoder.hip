@@ -386,18 +386,30 @@ struct PartsH {
   f16x8 hi, lo;
 };
 
-// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual
+// residual v * mult - half(hpk) in one VALU op: v_fma_mix_f32 reads the fp16 operand straight out of the packed
+// register (no v_cvt_f32_f16), fp32 FMA, one rounding (the product is exact: mult is a power of two)
+__device__ __forceinline__ float resid_lo(float v, float mult, unsigned hpk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(mult), "v"(hpk));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(float v, float mult, unsigned hpk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(mult), "v"(hpk));
+  return r;
+}
+
+// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: 5 VALU ops per pair of values
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32)
 __device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
   u32x4 H, L;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i] * mult, b = v[2 * i + 1] * mult;
-    const f32x2 ab = {a, b};
-    const f16x2 h = __builtin_convertvector(ab, f16x2);  // v_cvt_pk_f16_f32
-    const f32x2 r = {a - (float)h[0], b - (float)h[1]};
-    const f16x2 l = __builtin_convertvector(r, f16x2);
-    H[i] = __builtin_bit_cast(unsigned, h);
-    L[i] = __builtin_bit_cast(unsigned, l);
+    const f32x2 ab = {v[2 * i] * mult, v[2 * i + 1] * mult};
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2));  // v_cvt_pk_f16_f32
+    const f32x2 r = {resid_lo(v[2 * i], mult, h), resid_hi(v[2 * i + 1], mult, h)};
+    H[i] = h;
+    L[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
   }
   PartsH p;
   p.hi = __builtin_bit_cast(f16x8, H);
@@ -520,8 +532,11 @@ struct Smem {
 // and zero-filling LDS, draining the weight DMA before the walk and extra workgroup barriers changed nothing.  The
 // fused form is the slower one either way (the walk needs the stand-alone kernel's 16 waves per CU).
 #define CVF_LDS_BYTES (84 * 1024)
+#ifndef MNERF_DECODER_MINBLOCKS
+#define MNERF_DECODER_MINBLOCKS 2  // experiments: 1 = 512 registers per wave (one workgroup per CU), no spills
+#endif
 template <int NW, int SP, int FMT, int CVF>
-__global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
+__global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kernel(
     mnerf_decoder D, DecSched sch, mnerf_view view0, mnerf_rays R,
     const float* __restrict__ cond, float* __restrict__ out_rgb, float* __restrict__ out_depth,
     float* __restrict__ out_opacity, float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma,
@@ -1360,7 +1375,9 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
 #pragma unroll
     for (int r = 0; r < 8; ++r) step2(qkv, tail + TAIL_QKV, r, lane, av[r]);
     TL_STAMP(18);
-    const float qs = q_valid ? 0.5f : 0.0f;  // temperature sqrt(d_k) = 2; masked query row -> uniform
+    // temperature sqrt(d_k) = 2; masked query row -> uniform.  The MFMA form keeps its scores in the log2 domain
+    // (log2 e folded into the query scale): the softmax numerator is then one v_exp_f32 per key
+    const float qs = q_valid ? (SM::MFMA_ATT ? 0.5f * 1.4426950408889634f : 0.5f) : 0.0f;
 
     float ofc[8];  // attention output features [8*hl, 8*hl+8) of this lane's sample (head-major)
     if constexpr (SM::MFMA_ATT) {
@@ -1442,7 +1459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void decoder_kernel(
         for (int g = 0; g < SP / 4; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = __expf(sc[g][r] - mx);
+            const float pr = __builtin_amdgcn_exp2f(sc[g][r] - mx);
             sc[g][r] = pr;
             ls4[r] += pr;
           }
