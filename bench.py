@@ -284,17 +284,6 @@ def main():
             model.kernel_timer = None
         assert decoder_math() == math or S > 128
 
-    secondary = []
-    if world == 1 and not args.no_secondary:
-        del full
-        torch.cuda.empty_cache()
-        secondary.append(secondary_workload(device, "BASELINE config[2]: Blender-like 3-view 800x800, 128 samples/ray, "
-                                            "white background, full frame incl. encoder", 3, 128, 800, 800, True,
-                                            seed=31, wide=True, focal_scale=1.389, near_far=(2.0, 6.0)))
-        secondary.append(secondary_workload(device, "BASELINE config[4]: 10 source views 512x640, 64 samples/ray "
-                                            "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
-                                            10, 64, 512, 640, False, seed=32))
-
     # the same frame through the one-launch (fused) form of the ray chunk: built, bit-identical, slower
     fused_form = None
     if world == 1 and math == "f16x3":
@@ -312,9 +301,22 @@ def main():
             if "render_fused" in kf:
                 fused_form = {"ms_per_step": round(msf, 3), "rays_per_s": round(n_rays / (msf * 1e-3), 1),
                               "fused_ray_chunk_ms_per_frame": round(kf["render_fused"]["total_ms"] / 2, 3),
-                              "identical_to_staged": bool(torch.equal(ffull, full))}
+                              # (bit-identical given the same feature maps: tests/test_hip_kernels.py; here each step
+                              # re-runs the encoder, whose library kernels are not bitwise reproducible)
+                              "rgb_linf_vs_staged": float((ffull[:, :3] - full[:, :3]).abs().max())}
         finally:
             model.fused_render, model.kernel_timer = False, None
+
+    secondary = []
+    if world == 1 and not args.no_secondary:
+        del full
+        torch.cuda.empty_cache()
+        secondary.append(secondary_workload(device, "BASELINE config[2]: Blender-like 3-view 800x800, 128 samples/ray, "
+                                            "white background, full frame incl. encoder", 3, 128, 800, 800, True,
+                                            seed=31, wide=True, focal_scale=1.389, near_far=(2.0, 6.0)))
+        secondary.append(secondary_workload(device, "BASELINE config[4]: 10 source views 512x640, 64 samples/ray "
+                                            "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
+                                            10, 64, 512, 640, False, seed=32))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
