@@ -232,6 +232,27 @@ int mnerf_window_attention(const float* q, const float* k, const float* v, float
                            int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                            int32_t shifted, int32_t math, void* stream);
 
+/* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
+ * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):
+ *   message = norm1(merge(attn));  [ffn:] message = norm2(mlp.2(GELU(mlp.0(cat[source, message]))));  out = source + message
+ * attn, source, out: [n_tokens, 128] fp32 (out may alias neither input).  The three bias-free Linears travel as one
+ * split-fp16 MFMA A-fragment stream (matchnerf_amd/gmflow.py: pack_encoder_block; layout in DESIGN.md section 5):
+ * 32 KiB segments = 4 K16-steps x 4 row blocks x [hi | lo]; merge (2 segments), then per 128-unit hidden chunk
+ * mlp.0 (4 segments: source features, then the message in accumulator order) and mlp.2 (2 segments).
+ * ew_*: exponent of the power-of-two scale each weight tensor was packed with; ln: [4][128] = norm1 weight | norm1
+ * bias | norm2 weight | norm2 bias (norm2 ignored when ffn == 0).  fp32-grade results (same arithmetic as the
+ * decoder's MNERF_WSTREAM_F16X2 path). */
+typedef struct mnerf_encoder_layer {
+  const float* wstream;
+  int64_t wstream_floats;  /* mnerf_encoder_block_wstream_floats(ffn) */
+  const float* ln;
+  int32_t ffn;             /* 0: self-attention layer (no FFN), 1: cross-attention + FFN layer */
+  int32_t ew_merge, ew_w1, ew_w2;
+} mnerf_encoder_layer;
+int64_t mnerf_encoder_block_wstream_floats(int32_t ffn);
+int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
+                        int32_t n_tokens, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "backward.hip", "composite.hip", "cost_volume.hip", "decoder.hip", "geometry.hip", "render_chunk.hip",
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "cost_volume.hip", "decoder.hip", "encoder_block.hip", "geometry.hip", "render_chunk.hip",
            "window_attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -20,7 +20,7 @@ def source_hash():
     (profiles/decoder_counters.json) belong to, so that bench.py can tell when they have gone stale."""
     import hashlib
     h = hashlib.sha256()
-    for name in sorted(SOURCES + ["common.hpp"]):
+    for name in sorted(SOURCES + ["common.hpp", "cv_walk.hpp", "split_f16.hpp"]):
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     with open(os.path.join(PKG, "..", "include", "mnerf.h"), "rb") as f:
@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
         hipcc = "hipcc"
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    deps = [os.path.join(HERE, "common.hpp"), os.path.join(PKG, "..", "include", "mnerf.h")]
+    deps = [os.path.join(HERE, h) for h in ("common.hpp", "cv_walk.hpp", "split_f16.hpp")] + [os.path.join(PKG, "..", "include", "mnerf.h")]
     objs = []
     for src in SOURCES:
         sp = os.path.join(HERE, src)

@@ -39,8 +39,8 @@
 #include <stdlib.h>
 
 #include "cv_walk.hpp"
+#include "split_f16.hpp"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SEG_CAP_FLOATS (33 * 256)  // one LDS weight buffer: 33 KiB
 #define MAX_SEGS 64
@@ -81,29 +81,6 @@ struct DecSched {
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-
-// ---- weight-segment DMA: each wave copies 1 KiB pieces, LDS dest = uniform base + lane*16.
-// The LDS-DMA is issued from inline asm on purpose: hipcc tracks a builtin global_load_lds as a
-// pending LDS write and puts `s_waitcnt vmcnt(0)` in front of the NEXT ds_read — which would
-// drain the prefetch of segment i+1 before segment i has issued a single MFMA (seen in the
-// ISA: the DMA was fully exposed 18x per tile).  An asm load is invisible to that bookkeeping
-// (cdna_hip_programming.md 5.7); segment_wait() below is the one place that waits for it,
-// right before the barrier that publishes the buffer.  M0 (LDS base) is written and restored
-// inside the same statement.
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_byte_addr)
-      : "memory");
-}
-
-__device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int NW>
 __device__ __forceinline__ void prefetch_segment(const float* __restrict__ wstream,
@@ -264,8 +241,6 @@ __device__ __forceinline__ f32x16 enc_block16_L10(const EncBase& b, int hl, floa
 // the previous layer is consumed as two K16-steps (registers 0-7, 8-15) with no data movement.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE)
   const f32x2 v = {a, b};
@@ -303,9 +278,6 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
 // accumulators <- fp32 bias fragment [half][4][16] (exact fp32 biases, no K-step spent on them)
 // LDS operands of the split-bf16 path are addressed by LDS byte offset through explicit address_space(3)
 // pointers made from integers.
-typedef float v4f32 __attribute__((ext_vector_type(4)));
-typedef const u32x4 __attribute__((address_space(3)))* lds_u32x4_cptr;
-typedef const v4f32 __attribute__((address_space(3)))* lds_v4f32_cptr;
 
 template <int NMB>
 __device__ __forceinline__ void bias_init(f32x16 (&acc)[NMB], unsigned frag_lds, int hl) {
@@ -366,141 +338,6 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
   ksteps<NMB, 2>(acc, base_lds, lane, v);
 }
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
-
-
-// ---------------------------------------------------------------- split-fp16 matrix path ("f16x3", FMT = 2)
-// Same chain on v_mfma_f32_32x32x16_f16 with TWO fp16 terms per operand and THREE products per MAC
-// (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is < 2^-22 of the product): half the matrix instructions of
-// bf16x6 and about half its operand-split VALU work (gfx950 has v_cvt_pk_f16_f32; the residual is one
-// v_pk_fma_f32 per pair).  fp16 has 11 significand bits but a 5-bit exponent, so both operands are range-managed
-// with exact power-of-two scales (cond_nerf.py: pack_wstream_h): weights carry one scale 2^ew per tensor (host),
-// activations one gain per SAMPLE and stage, taken from the running maximum of the sample's features (in-lane
-// max + one cross-half shuffle) so that the largest operand lands in [2^14, 2^15).  The accumulator then holds
-// 2^(ew+eg) (W x); scales are tracked as integer exponents per lane and multiplied back in exactly.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#define H16_UNIT_BYTES 2048  // one (step, block): hi | lo fragments
-#define H16_TARGET_EXP 15    // largest operand of a sample is scaled into [2^14, 2^15)
-
-struct PartsH {
-  f16x8 hi, lo;
-};
-
-// residual v * mult - half(hpk) in one VALU op: v_fma_mix_f32 reads the fp16 operand straight out of the packed
-// register (no v_cvt_f32_f16), fp32 FMA, one rounding (the product is exact: mult is a power of two)
-__device__ __forceinline__ float resid_lo(float v, float mult, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(mult), "v"(hpk));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float v, float mult, unsigned hpk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(mult), "v"(hpk));
-  return r;
-}
-
-// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: 5 VALU ops per pair of values
-// (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32)
-__device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
-  u32x4 H, L;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x2 ab = {v[2 * i] * mult, v[2 * i + 1] * mult};
-    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2));  // v_cvt_pk_f16_f32
-    const f32x2 r = {resid_lo(v[2 * i], mult, h), resid_hi(v[2 * i + 1], mult, h)};
-    H[i] = h;
-    L[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-  }
-  PartsH p;
-  p.hi = __builtin_bit_cast(f16x8, H);
-  p.lo = __builtin_bit_cast(f16x8, L);
-  return p;
-}
-
-__device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// exponent em with 2^em * m in [2^14, 2^15) (m > 0; clamped so that every scale stays a normal fp32 number)
-__device__ __forceinline__ int gain_exp(float m) {
-  int e = __builtin_amdgcn_frexp_expf(m);  // m = f 2^e, f in [0.5, 1); 0 for m = 0 / inf / nan
-  // (register-unit magnitudes sit around 2^57: accumulator 2^29 x un-normalised FiLM 2^28; the clamp only keeps
-  // 2^(15-e) a normal fp32 number for denormal / near-overflow inputs)
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
-  return H16_TARGET_EXP - e;
-}
-__device__ __forceinline__ float pow2i(int e) { return ldexpf(1.0f, e); }
-
-typedef const float __attribute__((address_space(3)))* lds_f32_cptr;
-// stage header (1 KiB): floats [0,128) bias in accumulator order, [128] 2^-ew, [129] (float)ew
-__device__ __forceinline__ int header_ew(unsigned frag_lds) {
-  return __builtin_amdgcn_readfirstlane((int)((lds_f32_cptr)(size_t)frag_lds)[129]);
-}
-
-// accumulators <- bias * bmult (bmult = 2^(ew + operand-gain exponent): the accumulator's scale)
-template <int NMB>
-__device__ __forceinline__ void bias_init_h(f32x16 (&acc)[NMB], unsigned frag_lds, int hl, float bmult) {
-  lds_v4f32_cptr p = (lds_v4f32_cptr)(size_t)frag_lds + hl * 16;
-#pragma unroll
-  for (int m = 0; m < NMB; ++m)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const v4f32 t = p[m * 4 + q];
-      acc[m][4 * q] = t.x * bmult;
-      acc[m][4 * q + 1] = t.y * bmult;
-      acc[m][4 * q + 2] = t.z * bmult;
-      acc[m][4 * q + 3] = t.w * bmult;
-    }
-}
-
-// NS K16-steps against NMB output blocks; v: the lane's 8*NS operand values, mult: their power-of-two gain.
-// A fragments of unit (step, block) i+1 are read before the three MFMAs of unit i.
-template <int NMB, int NS>
-__device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const float (&v)[8 * NS],
-                                         float mult) {
-  lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
-  u32x4 ch = a[0], cl = a[64];
-#pragma unroll
-  for (int u = 0; u < NS; ++u) {
-    float vv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) vv[j] = v[8 * u + j];
-    const PartsH b = split8h(vv, mult);
-#pragma unroll
-    for (int m = 0; m < NMB; ++m) {
-      const int i = u * NMB + m;
-      const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;  // the last unit re-reads itself
-      const u32x4 nh = a[nx], nl = a[nx + 64];
-      __builtin_amdgcn_sched_barrier(0);
-      const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
-      acc[m] = mfma16h(ah, b.lo, acc[m]);
-      acc[m] = mfma16h(al, b.hi, acc[m]);
-      acc[m] = mfma16h(ah, b.hi, acc[m]);
-      __builtin_amdgcn_sched_barrier(0);
-      ch = nh;
-      cl = nl;
-    }
-  }
-}
-
-template <int NMB>
-__device__ __forceinline__ void kblock_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const f32x16& h, float mult) {
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = h[r];
-  ksteps_h<NMB, 2>(acc, base_lds, lane, v, mult);
-}
-
-// largest |value| of a sample's features held in NB accumulator blocks of its two lanes
-template <int NB>
-__device__ __forceinline__ float sample_absmax(const f32x16 (&a)[NB]) {
-  float mx = 0.0f;
-#pragma unroll
-  for (int m = 0; m < NB; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(a[m][r]));
-  return fmaxf(mx, __shfl_xor(mx, 32, 64));
-}
 
 template <int NW, int SP>
 struct Smem {

@@ -73,8 +73,47 @@ class CNNEncoder(nn.Module):
         return self.conv2(x)
 
 
+EB_SEG_FLOATS = 32 * 256  # one weight segment of the encoder block kernel: 4 K16-steps x 4 blocks x [hi | lo] x 1 KiB
+EB_CHUNK = 128            # hidden units of the FFN produced and consumed at a time
+
+
+def pack_encoder_block(merge_w, mlp0_w=None, mlp2_w=None):
+    """Weights of one transformer layer's post-attention chain -> (wstream float32 words, (ew_merge, ew_w1, ew_w2)) in the
+    split-fp16 MFMA A-fragment layout consumed by ``mnerf_encoder_block`` (csrc/encoder_block.hip; same unit layout as
+    the decoder's stream, cond_nerf.pack_wstream_h).  Segment order: merge (2 segments: input features 0-63, 64-127 in
+    natural order), then for every 128-unit hidden chunk c: mlp.0 rows [128c, 128c+128) (4 segments: the 128 source
+    features in natural order, then the 128 message features in accumulator order) and mlp.2 columns [128c, 128c+128)
+    (2 segments, accumulator order)."""
+    import numpy as np
+    from . import cond_nerf as CN
+
+    def npf(w):
+        return (w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)).astype(np.float32)
+
+    natural = np.arange(128).reshape(8, 2, 8)          # K16-step t, half h, j -> feature 16 t + 8 h + j
+    acc_order = CN._reg_cols16(4)                      # accumulator-register order of a 128-row stage
+    merge_w = npf(merge_w)
+    ew_m = CN.f16_weight_exponent(merge_w)
+    parts = [CN._fragments_h(merge_w, natural, 4, ew_m)]                      # [8, 4, 2, 64, 8]
+    ews = [ew_m, 0, 0]
+    if mlp0_w is not None:
+        w1, w2 = npf(mlp0_w), npf(mlp2_w)
+        assert w1.shape == (1024, 256) and w2.shape == (128, 1024)
+        ews[1], ews[2] = CN.f16_weight_exponent(w1), CN.f16_weight_exponent(w2)
+        cols1 = np.concatenate([natural, 128 + acc_order], 0)                # 16 steps over cat[source, message]
+        for c in range(1024 // EB_CHUNK):
+            parts.append(CN._fragments_h(w1[EB_CHUNK * c:EB_CHUNK * (c + 1)], cols1, 4, ews[1]))
+            parts.append(CN._fragments_h(w2[:, EB_CHUNK * c:EB_CHUNK * (c + 1)], acc_order, 4, ews[2]))
+    halfs = np.concatenate([p.reshape(-1) for p in parts])                    # fp16, [steps][4][2][64][8] per stage
+    ws = halfs.view(np.float32).copy()
+    assert ws.size % EB_SEG_FLOATS == 0
+    return ws, tuple(int(e) for e in ews)
+
+
 class TransformerLayer(nn.Module):
-    """transformer.py:108-185 (single head, swin windows)."""
+    """transformer.py:108-185 (single head, swin windows).  Inference runs q/k/v projections (library GEMMs), the
+    window-attention kernel (K6) and ONE kernel for everything after it (K7, ``mnerf_encoder_block``: merge, LayerNorm,
+    concatenation, FFN with exact GELU, LayerNorm, residual); under autograd the reference's op chain is used."""
 
     def __init__(self, d_model=128, no_ffn=False, ffn_dim_expansion=4):
         super().__init__()
@@ -89,11 +128,30 @@ class TransformerLayer(nn.Module):
                                      nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
             self.norm2 = nn.LayerNorm(d_model)
 
+    def _packed_block(self, device):
+        """(wstream, ln, ews) of the post-attention chain for the K7 kernel; re-packed when a parameter changed"""
+        ps = [self.merge.weight, self.norm1.weight, self.norm1.bias]
+        if not self.no_ffn:
+            ps += [self.mlp[0].weight, self.mlp[2].weight, self.norm2.weight, self.norm2.bias]
+        key = (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(device))
+        if getattr(self, "_blk", None) is None or self._blk[0] != key:
+            ws, ews = pack_encoder_block(self.merge.weight, None if self.no_ffn else self.mlp[0].weight,
+                                         None if self.no_ffn else self.mlp[2].weight)
+            n2 = (self.norm1 if self.no_ffn else self.norm2)
+            ln = torch.stack([self.norm1.weight, self.norm1.bias, n2.weight, n2.bias], 0).detach().float().contiguous()
+            self._blk = (key, torch.from_numpy(ws).to(device), ln.to(device), ews)
+        return self._blk[1:]
+
     def forward(self, source, target, h, w, splits, shifted):
         q = self.q_proj(source)
         k = self.k_proj(target)
         v = self.v_proj(target)
         msg = window_attention(q, k, v, h, w, splits, shifted)  # HIP forward; torch re-evaluation backward
+        if not torch.is_grad_enabled() or not (msg.requires_grad or source.requires_grad or self.merge.weight.requires_grad):
+            ws, ln, ews = self._packed_block(source.device)
+            b, n, c = source.shape
+            out = hip.encoder_block(msg.reshape(b * n, c), source.reshape(b * n, c).contiguous(), ws, ln, not self.no_ffn, ews)
+            return out.reshape(b, n, c)
         msg = self.norm1(self.merge(msg))
         if not self.no_ffn:
             msg = self.norm2(self.mlp(torch.cat([source, msg], dim=-1)))

@@ -25,7 +25,8 @@ _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
-           "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention")
+           "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
+           "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -55,6 +56,11 @@ class Decoder(C.Structure):
                 ("L_3D", C.c_int32), ("raytrans_posenc", C.c_int32), ("raytrans_elu", C.c_int32),
                 ("density_maskfill", C.c_int32), ("wo_render_interval", C.c_int32),
                 ("setbg_opaque", C.c_int32), ("wstream_format", C.c_int32)]
+
+
+class EncoderLayer(C.Structure):
+    _fields_ = [("wstream", C.c_void_p), ("wstream_floats", C.c_int64), ("ln", C.c_void_p), ("ffn", C.c_int32),
+                ("ew_merge", C.c_int32), ("ew_w1", C.c_int32), ("ew_w2", C.c_int32)]
 
 
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
@@ -115,6 +121,10 @@ def load():
     lib.mnerf_render_chunk.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), vp, fp, fp, fp, vp]
     lib.mnerf_window_attention.restype = C.c_int
     lib.mnerf_window_attention.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_encoder_block_wstream_floats.restype = i64
+    lib.mnerf_encoder_block_wstream_floats.argtypes = [i32]
+    lib.mnerf_encoder_block.restype = C.c_int
+    lib.mnerf_encoder_block.argtypes = [C.POINTER(EncoderLayer), fp, fp, fp, i32, vp]
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
@@ -414,4 +424,23 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
         check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                          int(bool(shifted)), wa_math() if math is None else int(math), st),
               "mnerf_window_attention")
+    return out
+
+
+def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None):
+    """K7 (gmflow/transformer.py:176-185): out = source + norm2(mlp(cat[source, norm1(merge(attn))])) (or without the
+    FFN).  attn, source [N,128]; wstream / ews from gmflow.pack_encoder_block; ln [4,128]."""
+    import torch
+    lib = load()
+    _f32c(attn, "attn"), _f32c(source, "source"), _f32c(wstream, "wstream"), _f32c(ln, "ln")
+    n, c = source.shape
+    if c != 128 or tuple(attn.shape) != (n, c) or tuple(ln.shape) != (4, 128):
+        raise MnerfError(f"encoder_block: attn {tuple(attn.shape)}, source {tuple(source.shape)}, ln {tuple(ln.shape)}")
+    if out is None:
+        out = torch.empty_like(source)
+    blk = EncoderLayer()
+    blk.wstream, blk.wstream_floats, blk.ln = wstream.data_ptr(), wstream.numel(), ln.data_ptr()
+    blk.ffn, blk.ew_merge, blk.ew_w1, blk.ew_w2 = int(bool(ffn)), int(ews[0]), int(ews[1]), int(ews[2])
+    with _on(source.device, stream) as st:
+        check(lib.mnerf_encoder_block(C.byref(blk), _ptr(attn), _ptr(source), _ptr(out), n, st), "mnerf_encoder_block")
     return out

@@ -1,0 +1,161 @@
+"""K7 — the post-attention chain of a GMFlow transformer layer as one kernel (csrc/encoder_block.hip).
+
+CPU: a numpy emulation of the kernel's dataflow (same packed stream, same segment order, same operand rules:
+natural-order features from memory, accumulator-order features from registers, split-fp16 products with per-token
+gains, running rescale of the second Linear's accumulator) must reproduce the reference op chain
+(/root/reference/models/gmflow/transformer.py:176-185) — this pins ``gmflow.pack_encoder_block`` without a GPU.
+GPU: the kernel itself against the same torch op chain, and the encoder end to end through it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from matchnerf_amd import cond_nerf as CN
+from matchnerf_amd import gmflow as G
+
+
+def _layer(ffn, seed):
+    torch.manual_seed(seed)
+    layer = G.TransformerLayer(128, no_ffn=not ffn)
+    with torch.no_grad():
+        for p in layer.parameters():
+            if p.dim() > 1:
+                torch.nn.init.xavier_uniform_(p)
+        layer.norm1.weight.uniform_(0.5, 1.5)
+        layer.norm1.bias.uniform_(-0.3, 0.3)
+        if ffn:
+            layer.norm2.weight.uniform_(0.5, 1.5)
+            layer.norm2.bias.uniform_(-0.3, 0.3)
+    return layer
+
+
+def _reference(layer, attn, source):
+    """-> the message (what is added to the residual stream)"""
+    with torch.no_grad():
+        msg = layer.norm1(layer.merge(attn))
+        if not layer.no_ffn:
+            msg = layer.norm2(layer.mlp(torch.cat([source, msg], -1)))
+        return msg
+
+
+def _gain(m):
+    e = np.frexp(np.asarray(m, np.float32))[1]
+    return (CN.F16_TARGET_EXP + 1) - np.clip(e, -100, 100)          # exponent, as gain_exp() in the kernel
+
+
+def _split_products(frag, x_scaled):
+    """frag [T,4,2,64,8] fp16 (hi|lo of 2^ew W), x_scaled [T,2,8,N] fp32 -> Y [128, N] (hi.lo + lo.hi + hi.hi)"""
+    a = frag.astype(np.float64)
+    bh = x_scaled.astype(np.float16)
+    bl = (x_scaled - bh.astype(np.float32)).astype(np.float16)
+    bh, bl = bh.astype(np.float64), bl.astype(np.float64)
+    y = np.zeros((128, x_scaled.shape[-1]))
+    for wa, vb in ((a[:, :, 0], bl), (a[:, :, 1], bh), (a[:, :, 0], bh)):
+        for mb in range(4):
+            for h in range(2):
+                y[32 * mb:32 * mb + 32] += np.einsum("tlj,tjn->ln", wa[:, mb, 32 * h:32 * h + 32, :], vb[:, h])
+    return y
+
+
+def _ln(v, w, b):
+    mu = v.mean(0)
+    return (v - mu) / np.sqrt(((v - mu) ** 2).mean(0) + 1e-5) * w[:, None] + b[:, None]
+
+
+def emulate(ws, ews, ln, attn, source, ffn):
+    """attn, source [N,128] -> message [N,128] following csrc/encoder_block.hip stage by stage"""
+    from scipy.special import erf
+    n = attn.shape[0]
+    seg = ws.view(np.float16).reshape(-1, 4, 4, 2, 64, 8)             # [segment][step][block][hi|lo][lane][j]
+    nat = lambda x: x.T.reshape(8, 2, 8, n)                             # natural order operands [T,2,8,N]
+    acc_cols = CN._reg_cols16(4)
+    s_i = 0
+
+    def stage(n_seg):
+        nonlocal s_i
+        f = seg[s_i:s_i + n_seg].reshape(n_seg * 4, 4, 2, 64, 8)
+        s_i += n_seg
+        return f
+
+    em = _gain(np.abs(attn).max(1))
+    m1 = _split_products(stage(2), (nat(attn) * np.ldexp(np.float32(1), em)).astype(np.float32)) * np.ldexp(1.0, -(ews[0] + em))
+    m1 = _ln(m1, ln[0], ln[1])
+    if not ffn:
+        return m1.T
+    eg1 = _gain(np.maximum(np.abs(source).max(1), np.abs(m1).max(0)))
+    y = np.zeros((128, n))
+    eg2 = np.full(n, 127)
+    for c in range(8):
+        x = np.concatenate([nat(source), m1.astype(np.float32)[acc_cols]], 0)        # 16 steps
+        hd = _split_products(stage(4), (x * np.ldexp(np.float32(1), eg1)).astype(np.float32)) * np.ldexp(1.0, -(ews[1] + eg1))
+        hd = hd.astype(np.float32)
+        g = (0.5 * hd * (1.0 + erf(hd * np.float32(0.70710678)))).astype(np.float32)
+        egc = _gain(np.abs(g).max(0))
+        lower = egc < eg2
+        if c > 0:
+            y = np.where(lower[None], y * np.ldexp(1.0, np.where(lower, egc - eg2, 0))[None], y)
+        eg2 = np.where(lower, egc, eg2)
+        y += _split_products(stage(2), (g[acc_cols] * np.ldexp(np.float32(1), eg2)).astype(np.float32))
+    y = _ln(y * np.ldexp(1.0, -(ews[2] + eg2)), ln[2], ln[3])
+    assert s_i == seg.shape[0]
+    return y.T
+
+
+@pytest.mark.parametrize("ffn", [False, True])
+def test_emulated_encoder_block_matches_reference_chain(ffn):
+    layer = _layer(ffn, 3 + ffn)
+    g = torch.Generator().manual_seed(11)
+    attn = torch.randn(96, 128, generator=g) * 2.0
+    source = torch.randn(96, 128, generator=g) * 8.0
+    source[5] *= 300.0   # tokens of very different magnitude: per-token gains
+    attn[7] *= 1e-3
+    ws, ews = G.pack_encoder_block(layer.merge.weight, None if not ffn else layer.mlp[0].weight,
+                                   None if not ffn else layer.mlp[2].weight)
+    n2 = layer.norm2 if ffn else layer.norm1
+    ln = torch.stack([layer.norm1.weight, layer.norm1.bias, n2.weight, n2.bias]).detach().numpy().astype(np.float64)
+    msg = emulate(ws, ews, ln, attn.numpy(), source.numpy(), ffn)
+    ref = _reference(layer.double(), attn.double(), source.double()).numpy()
+    msg_err = np.abs(msg - ref).max()   # the message (|.| ~ 3) against the float64 evaluation of the op chain
+    print(f"encoder block emulation (ffn={ffn}): message err {msg_err:.2e}")
+    assert msg_err < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ffn,n_tokens", [(False, 300), (True, 300), (True, 128 * 40 + 17)])
+def test_encoder_block_kernel_matches_reference_chain(ffn, n_tokens):
+    from matchnerf_amd import hip
+    layer = _layer(ffn, 5 + ffn).cuda()
+    g = torch.Generator().manual_seed(12)
+    attn = (torch.randn(n_tokens, 128, generator=g) * 2.0).cuda()
+    source = (torch.randn(n_tokens, 128, generator=g) * 8.0).cuda()
+    source[5] *= 300.0
+    attn[7] *= 1e-3
+    ws, ln, ews = layer._packed_block(torch.device("cuda"))
+    out = hip.encoder_block(attn, source, ws, ln, ffn, ews)
+    ref = _reference(layer, attn, source)
+    # the residual add itself is exact to an ulp of |source| (rows up to 1e4): check it against torch's own sum,
+    # then judge the MESSAGE on rows of ordinary magnitude against a float64 evaluation of the chain
+    assert float((out - (source + ref)).abs().max()) < 2e-3 and torch.equal(out[5] != out[5], torch.zeros(128, dtype=torch.bool, device="cuda"))
+    rows = torch.ones(n_tokens, dtype=torch.bool)
+    rows[5] = False
+    l64 = _layer(ffn, 5 + ffn).double()
+    ref64 = _reference(l64, attn.double().cpu(), source.double().cpu())
+    msg = (out - source).double().cpu()
+    e_kernel = float((msg - ref64)[rows].abs().max())
+    e_torch = float((ref.double().cpu() - ref64)[rows].abs().max())
+    print(f"\nencoder block ffn={ffn} N={n_tokens}: message vs float64: kernel {e_kernel:.2e} (incl. the rounding of out - source), "
+          f"torch fp32 {e_torch:.2e}")
+    assert e_kernel < 3.0 * e_torch + 4e-6
+
+
+@pytest.mark.gpu
+def test_layer_forward_uses_the_kernel_and_matches_autograd_path():
+    """TransformerLayer.forward: the inference path (K6 + K7 kernels) equals the differentiable op chain."""
+    layer = _layer(True, 9).cuda()
+    g = torch.Generator().manual_seed(13)
+    src = (torch.randn(2, 8 * 12, 128, generator=g) * 3.0).cuda()
+    tgt = (torch.randn(2, 8 * 12, 128, generator=g) * 3.0).cuda()
+    with torch.no_grad():
+        fast = layer(src, tgt, 8, 12, 2, True)
+    slow = layer(src.requires_grad_(True), tgt, 8, 12, 2, True)
+    assert slow.requires_grad and float((fast - slow.detach()).abs().max()) < 2e-5
