@@ -12,7 +12,9 @@
 // W . X^T, on v_mfma_f32_32x32x16_f16 with fp32-grade split-fp16 operands (split_f16.hpp); a wave owns 32 tokens,
 // the accumulator layout of one stage is the operand layout of the next (weight columns permuted on the host:
 // matchnerf_amd/gmflow.py, pack_encoder_block), LayerNorm is an in-lane + one cross-half reduction, and the packed
-// weights stream through a 2 x 32 KiB LDS double buffer by LDS-DMA, one barrier per segment.
+// weights stream through a ring of 4 x 32 KiB LDS buffers by LDS-DMA (three segments in flight: the problem is small
+// — 30,720 tokens at 3 views are 960 wave-tiles for 1,024 SIMDs, one wave per SIMD — so a segment's 48 matrix
+// instructions are far too short to hide the copy of the next one), one barrier per segment.
 // The 1024 hidden units are produced and consumed 128 at a time (hidden chunk c: 16 K16-steps of mlp.0, GELU,
 // 8 K16-steps of mlp.2 accumulated into the 128 outputs), so the [tokens, 1024] activation never exists; the
 // per-token operand gain of the second Linear can grow from chunk to chunk, and the output accumulator is rescaled
@@ -24,6 +26,7 @@
 #define EB_HIDDEN 1024            // 2 * d_model * ffn_dim_expansion
 #define EB_CHUNKS (EB_HIDDEN / 128)
 #define EB_LN_EPS 1e-5f
+#define EB_NBUF 4                 // LDS ring: segment s lives in buffer s % 4, segments s+1 .. s+3 are in flight
 
 struct EbParams {
   const float* attn;
@@ -78,6 +81,31 @@ __device__ __forceinline__ void eb_layer_norm(f32x16 (&v)[4], const float* ln_w,
     }
 }
 
+// NS K16-steps against NMB output blocks with operands that are ALREADY split (mlp.0's operands are the same for
+// all eight hidden chunks: split once, 128 registers that the matrix instructions can read from the AGPR half)
+template <int NMB, int NS>
+__device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const PartsH* b) {
+  lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
+  u32x4 ch = a[0], cl = a[64];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) {
+      const int i = u * NMB + m;
+      const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;
+      const u32x4 nh = a[nx], nl = a[nx + 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
+      acc[m] = mfma16h(ah, b[u].lo, acc[m]);
+      acc[m] = mfma16h(al, b[u].hi, acc[m]);
+      acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+      __builtin_amdgcn_sched_barrier(0);
+      ch = nh;
+      cl = nl;
+    }
+  }
+}
+
 // nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2))
 __device__ __forceinline__ float eb_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -85,8 +113,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
   extern __shared__ __attribute__((aligned(16))) float eb_smem[];
   const unsigned wbuf0_lds = __builtin_amdgcn_groupstaticsize();
-  const unsigned wbuf1_lds = wbuf0_lds + EB_SEG_FLOATS * 4u;
-  float* ln_lds = eb_smem + 2 * EB_SEG_FLOATS;  // [4][128]
+  float* ln_lds = eb_smem + EB_NBUF * EB_SEG_FLOATS;  // [4][128]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hl = lane >> 5;
@@ -94,7 +121,9 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
 
   for (int i = tid; i < 4 * EB_C; i += NW * 64) ln_lds[i] = P.ln[i];
   int seg = 0;
-  eb_prefetch<NW>(P.wstream, 0, n_seg, wbuf0_lds, wave, lane);
+#pragma unroll
+  for (int i = 0; i < EB_NBUF - 1; ++i)
+    eb_prefetch<NW>(P.wstream, i, n_seg, wbuf0_lds + (unsigned)i * EB_SEG_FLOATS * 4u, wave, lane);
 
   const int tok_raw = (blockIdx.x * NW + wave) * 32 + n;
   const bool tok_ok = tok_raw < P.n_tokens;
@@ -102,13 +131,30 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
   const float* arow = P.attn + (size_t)tok * EB_C + 8 * hl;    // this lane's half of a K16-step: features 16 t + 8 hl + j
   const float* srow = P.source + (size_t)tok * EB_C + 8 * hl;
 
-#define EB_CUR ((seg & 1) ? wbuf1_lds : wbuf0_lds)
-#define EB_BEGIN() eb_prefetch<NW>(P.wstream, seg + 1, n_seg, (seg & 1) ? wbuf0_lds : wbuf1_lds, wave, lane)
-#define EB_END()      \
-  do {                \
-    segment_wait();   \
-    __syncthreads();  \
-    ++seg;            \
+  // A wave issues EB_SEG_FLOATS / 256 / NW = 8 DMA pieces per segment, and memory operations complete in order: with
+  // k later segments in flight, "at most 8 k operations outstanding" means the next segment has landed (other loads
+  // issued in between can only make the wait longer, never shorter).
+  constexpr int PIECES = EB_SEG_FLOATS / 256 / NW;
+  static_assert(PIECES * (EB_NBUF - 2) < 64, "vmcnt is a 6-bit counter");
+  auto eb_wait_next = [&](int s) {  // segment s + 1 complete (this wave's pieces)
+    const int last = n_seg - 1 < s + EB_NBUF - 1 ? n_seg - 1 : s + EB_NBUF - 1;  // newest segment issued so far
+    const int ahead = last - (s + 1);
+    if (ahead >= 2)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (ahead == 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#define EB_CUR (wbuf0_lds + (unsigned)(seg & (EB_NBUF - 1)) * EB_SEG_FLOATS * 4u)
+#define EB_BEGIN()                                                                                                   \
+  eb_prefetch<NW>(P.wstream, seg + EB_NBUF - 1, n_seg,                                                               \
+                  wbuf0_lds + (unsigned)((seg + EB_NBUF - 1) & (EB_NBUF - 1)) * EB_SEG_FLOATS * 4u, wave, lane)
+#define EB_END()        \
+  do {                  \
+    eb_wait_next(seg);  \
+    __syncthreads();    \
+    ++seg;              \
   } while (0)
 
   // ---------------------------------------------------------------- merge: 128 -> 128 on the attention output
@@ -130,7 +176,7 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
     const float mult = pow2i(em);
 #pragma unroll
     for (int m = 0; m < 4; ++m) m1[m] = (f32x16)(0.0f);
-    segment_wait();
+    eb_wait_next(-1);
     __syncthreads();  // weight segment 0 and the LayerNorm parameters are in LDS
 #pragma unroll
     for (int sgi = 0; sgi < 2; ++sgi) {
@@ -156,18 +202,40 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
   } else {
     // ---------------------------------------------------------------- FFN on cat[source, message]
     // one true gain for both operand sets of mlp.0 (they share the accumulator), from the larger of the two maxima
+    // the token's 128 source features in K16-step order, loaded ONCE: an ordinary global load inside the chunk loop
+    // would make hipcc drain every weight DMA in flight in front of its first use (it counts only its own loads),
+    // i.e. undo the three-segment prefetch
+    float s_in[64];
     float smax = 0.0f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const float4 lo4 = *reinterpret_cast<const float4*>(srow + 16 * t);
       const float4 hi4 = *reinterpret_cast<const float4*>(srow + 16 * t + 4);
-      smax = fmaxf(fmaxf(smax, fmaxf(fabsf(lo4.x), fabsf(lo4.y))), fmaxf(fabsf(lo4.z), fabsf(lo4.w)));
-      smax = fmaxf(fmaxf(smax, fmaxf(fabsf(hi4.x), fabsf(hi4.y))), fmaxf(fabsf(hi4.z), fabsf(hi4.w)));
+      s_in[8 * t + 0] = lo4.x; s_in[8 * t + 1] = lo4.y; s_in[8 * t + 2] = lo4.z; s_in[8 * t + 3] = lo4.w;
+      s_in[8 * t + 4] = hi4.x; s_in[8 * t + 5] = hi4.y; s_in[8 * t + 6] = hi4.z; s_in[8 * t + 7] = hi4.w;
     }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) smax = fmaxf(smax, fabsf(s_in[i]));
     const float cmax = fmaxf(fmaxf(smax, __shfl_xor(smax, 32, 64)), sample_absmax<4>(m1));
     const int eg1 = gain_exp(cmax);
     const float mult1 = pow2i(eg1);
     const float c1 = pow2i(-(P.ew_w1 + eg1));
+    // both operand sets of mlp.0, split once for all eight hidden chunks: steps 0..7 source, 8..15 message
+    PartsH xp[16];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = s_in[8 * t + j];
+      xp[t] = split8h(v8, mult1);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = m1[t >> 1][8 * (t & 1) + j];
+      xp[8 + t] = split8h(v8, mult1);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) y[m] = (f32x16)(0.0f);
     int eg2 = 127;  // running operand-gain exponent of mlp.2 (the accumulator y holds 2^(ew_w2 + eg2) * true)
@@ -175,27 +243,11 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
       f32x16 hd[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) hd[m] = (f32x16)(0.0f);
-      // mlp.0, hidden chunk c: K16-steps 0..7 take the source features straight from global memory (L1 / L2 hits
-      // after the first chunk), steps 8..15 the message in accumulator order
+      // mlp.0, hidden chunk c: four segments of four K16-steps over cat[source, message]
 #pragma unroll
-      for (int sgi = 0; sgi < 2; ++sgi) {
+      for (int sgi = 0; sgi < 4; ++sgi) {
         EB_BEGIN();
-        float v[32];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float4 lo4 = *reinterpret_cast<const float4*>(srow + 16 * (4 * sgi + t));
-          const float4 hi4 = *reinterpret_cast<const float4*>(srow + 16 * (4 * sgi + t) + 4);
-          v[8 * t + 0] = lo4.x; v[8 * t + 1] = lo4.y; v[8 * t + 2] = lo4.z; v[8 * t + 3] = lo4.w;
-          v[8 * t + 4] = hi4.x; v[8 * t + 5] = hi4.y; v[8 * t + 6] = hi4.z; v[8 * t + 7] = hi4.w;
-        }
-        ksteps_h<4, 4>(hd, EB_CUR, lane, v, mult1);
-        EB_END();
-      }
-#pragma unroll
-      for (int sgi = 0; sgi < 2; ++sgi) {
-        EB_BEGIN();
-        kblock_h<4>(hd, EB_CUR, lane, m1[2 * sgi], mult1);
-        kblock_h<4>(hd, EB_CUR + 8 * H16_UNIT_BYTES, lane, m1[2 * sgi + 1], mult1);
+        ksteps_presplit<4, 4>(hd, EB_CUR, lane, xp + 4 * sgi);
         EB_END();
       }
       // GELU; the chunk's largest activation sets (or lowers) the operand gain of mlp.2
@@ -284,7 +336,7 @@ extern "C" int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* 
   p.ew_w1 = blk->ew_w1;
   p.ew_w2 = blk->ew_w2;
   constexpr int NW = 4;
-  const size_t lds = (2 * EB_SEG_FLOATS + 4 * EB_C) * sizeof(float);
+  const size_t lds = ((size_t)EB_NBUF * EB_SEG_FLOATS + 4 * EB_C) * sizeof(float);
   static std::atomic<unsigned long long> attr_set{0};
   if (mnerf_once_per_device(attr_set))
     (void)hipFuncSetAttribute((const void*)encoder_block_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

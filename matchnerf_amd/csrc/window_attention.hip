@@ -26,9 +26,7 @@
 // is in flight while tile t feeds 128 MFMAs per wave; one barrier per tile.
 #include <stdlib.h>
 
-#include "common.hpp"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "split_f16.hpp"
 
 #define WA_C 128
 #define WA_KT 32            // keys per tile
@@ -401,6 +399,200 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_bf16_kernel(
   }
 }
 
+// ============================================================================ split-fp16 variant (default)
+// The same loop on v_mfma_f32_32x32x16_f16 with two range-managed fp16 terms per operand and three products per MAC
+// (split_f16.hpp; decoder.hip "split-fp16 matrix path"): half the matrix instructions of the split-bf16 variant and
+// less than half of its operand-split VALU work, which is what bounds that kernel.  Gains (exact powers of two):
+//   Q   one per query (lane), from the query's 128 channels;
+//   K,V one per 32-key TILE (the wave's 64 lanes hold the whole tile exactly once: in-lane max + wave butterfly);
+//   P   fixed 2^14 (probabilities are <= 1).
+// The score accumulator is un-scaled per lane (2^-(eq + ek) folded into the softmax scale); the output accumulator
+// carries the V gain of the tile it was last updated with, and the change of gain from tile to tile rides in the
+// multiplication by the softmax correction factor that happens anyway.
+template <int NQW>
+__global__ __launch_bounds__(NQW * 64, 2) void window_attention_f16_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    float* __restrict__ out, WinGeom G, int shifted, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float wa_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  const int win = blockIdx.y, b = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
+
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, 0, WA_KBUF(0), WA_VBUF(0), wave, lane);
+
+  // ---- this lane's query, split once: K-step t holds channels 16t + 8 hl + j
+  const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
+  const bool q_ok = qi_raw < G.Lw;
+  int q_region;
+  const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
+  PartsH qp[8];
+  int eq;
+  {
+    const float4* src = reinterpret_cast<const float4*>(q + seq_base + (size_t)q_tok * WA_C + hl * 8);
+    float qv[64];
+    float qmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 a = src[4 * t], c = src[4 * t + 1];
+      qv[8 * t + 0] = a.x; qv[8 * t + 1] = a.y; qv[8 * t + 2] = a.z; qv[8 * t + 3] = a.w;
+      qv[8 * t + 4] = c.x; qv[8 * t + 5] = c.y; qv[8 * t + 6] = c.z; qv[8 * t + 7] = c.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) qmax = fmaxf(qmax, fabsf(qv[i]));
+    qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
+    eq = gain_exp(qmax);
+    const float mq = pow2i(eq);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = qv[8 * t + j];
+      qp[t] = split8h(v8, mq);
+    }
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
+  float m_run = -3.0e38f, l_run = 0.0f;
+  int ev_run = 0;  // V gain exponent the output accumulator currently carries (irrelevant while o == 0)
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < n_tiles)
+      wa_stage_tile<NQW>(k, v, seq_base, G, wy, wx, kt + 1, WA_KBUF(cur ^ 1), WA_VBUF(cur ^ 1), wave, lane);
+    // ---- S^T = K Q^T: the wave's 64 lanes hold the 32 x 128 K tile exactly once (lane = key row, half = channel
+    // half of every K16-step): tile maximum -> one gain
+    f32x16 s0 = (f32x16)(0.0f), s1 = (f32x16)(0.0f);
+    int ek;
+    {
+      const float* krow = WA_KBUF(cur) + n * WA_C;
+      float kv[64];
+      float kmax = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int c4 = 4 * t + 2 * hl;  // 16-byte column groups of channels 16t + 8hl .. + 7 (swizzled by the key)
+        const float4 a = *reinterpret_cast<const float4*>(krow + ((c4 ^ n) << 2));
+        const float4 c = *reinterpret_cast<const float4*>(krow + (((c4 + 1) ^ n) << 2));
+        kv[8 * t + 0] = a.x; kv[8 * t + 1] = a.y; kv[8 * t + 2] = a.z; kv[8 * t + 3] = a.w;
+        kv[8 * t + 4] = c.x; kv[8 * t + 5] = c.y; kv[8 * t + 6] = c.z; kv[8 * t + 7] = c.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 64; ++i) kmax = fmaxf(kmax, fabsf(kv[i]));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, off, 64));
+      ek = gain_exp(kmax);
+      const float mk = pow2i(ek);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = kv[8 * t + j];
+        const PartsH kp = split8h(v8, mk);
+        if (t & 1) {
+          s1 = mfma16h(kp.hi, qp[t].lo, s1);
+          s1 = mfma16h(kp.lo, qp[t].hi, s1);
+          s1 = mfma16h(kp.hi, qp[t].hi, s1);
+        } else {
+          s0 = mfma16h(kp.hi, qp[t].lo, s0);
+          s0 = mfma16h(kp.lo, qp[t].hi, s0);
+          s0 = mfma16h(kp.hi, qp[t].hi, s0);
+        }
+      }
+    }
+    f32x16 s = s0 + s1;
+    const float sscale = scale * pow2i(-(ek + eq));
+    // ---- scale, masks, online softmax (as in the f32 kernel)
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+      const int li = kt * WA_KT + key;
+      float sv = s[r] * sscale;
+      if (shifted) {
+        int kreg;
+        (void)win_token(G, wy, wx, li < G.Lw ? li : (G.Lw - 1), kreg);
+        if (kreg != q_region) sv += -100.0f;
+      }
+      if (li >= G.Lw) sv = -3.0e38f;
+      s[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // ---- O^T += V^T P^T: the lanes' 2 x 4 x 8 V values are the whole tile once more -> tile maximum -> gain
+    float vv[2][4][8];
+    float vmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * t + j;
+          const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+          const float x = WA_VBUF(cur)[key * WA_C + 32 * m + n];
+          vv[t][m][j] = x;
+          vmax = fmaxf(vmax, fabsf(x));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    const int ev = gain_exp(vmax);
+    const float mv = pow2i(ev);
+    const float corr = alpha * pow2i(ev - ev_run);  // softmax correction and change of V gain in one multiplication
+    ev_run = ev;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[m][r] *= corr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+      const PartsH pp = split8h(pv, 16384.0f);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const PartsH vp = split8h(vv[t][m], mv);
+        o[m] = mfma16h(vp.hi, pp.lo, o[m]);
+        o[m] = mfma16h(vp.lo, pp.hi, o[m]);
+        o[m] = mfma16h(vp.hi, pp.hi, o[m]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (q_ok) {
+    const float inv_l = pow2i(-(ev_run + 14)) / l_run;
+    float* dst = out + seq_base + (size_t)q_tok * WA_C;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 t = make_float4(o[m][4 * g4] * inv_l, o[m][4 * g4 + 1] * inv_l,
+                                     o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
+        *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
+      }
+  }
+}
+
 extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                                       int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                                       int32_t shifted, int32_t math, void* stream) {
@@ -413,7 +605,7 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
                 "mnerf_window_attention: %dx%d not divisible into %d splits", h, w, num_splits);
   MNERF_REQUIRE(batch <= 65535 && num_splits * num_splits <= 65535, MNERF_E_RANGE,
                 "mnerf_window_attention: grid too large");
-  MNERF_REQUIRE(math == MNERF_WA_SPLIT_BF16 || math == MNERF_WA_EXACT_F32, MNERF_E_UNSUPPORTED,
+  MNERF_REQUIRE(math == MNERF_WA_SPLIT_BF16 || math == MNERF_WA_EXACT_F32 || math == MNERF_WA_SPLIT_F16, MNERF_E_UNSUPPORTED,
                 "mnerf_window_attention: math=%d", math);
   if (batch == 0) return MNERF_OK;
   WinGeom G;
@@ -430,9 +622,14 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   hipStream_t st = (hipStream_t)stream;
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * num_splits * num_splits * batch;
   const size_t lds = 4 * WA_KT * WA_C * sizeof(float);  // 64 KiB: K and V tiles, double buffered
-  const bool split = math == MNERF_WA_SPLIT_BF16;  // split-bf16 products (default) or the exact-f32 MFMA
-  static std::atomic<unsigned long long> attr_f32{0}, attr_split{0};
-  if (!split && mnerf_once_per_device(attr_f32)) {
+  const bool split = math == MNERF_WA_SPLIT_BF16;  // split-bf16 products, split-fp16 products (default) or the exact-f32 MFMA
+  const bool split_h = math == MNERF_WA_SPLIT_F16;
+  static std::atomic<unsigned long long> attr_f32{0}, attr_split{0}, attr_split_h{0};
+  if (split_h && mnerf_once_per_device(attr_split_h)) {
+    (void)hipFuncSetAttribute((const void*)window_attention_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (!split && !split_h && mnerf_once_per_device(attr_f32)) {
     (void)hipFuncSetAttribute((const void*)window_attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)window_attention_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
@@ -443,13 +640,17 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   const int min4 = mnerf_tune().wa_min4;
   if (wgs4 >= min4) {
     dim3 grid((G.Lw + 127) / 128, num_splits * num_splits, batch);
-    if (split)
+    if (split_h)
+      hipLaunchKernelGGL(window_attention_f16_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
+    else if (split)
       hipLaunchKernelGGL(window_attention_bf16_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
     else
       hipLaunchKernelGGL(window_attention_kernel<4>, grid, dim3(256), lds, st, q, k, v, out, G, do_shift, scale);
   } else {
     dim3 grid((G.Lw + 63) / 64, num_splits * num_splits, batch);
-    if (split)
+    if (split_h)
+      hipLaunchKernelGGL(window_attention_f16_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
+    else if (split)
       hipLaunchKernelGGL(window_attention_bf16_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);
     else
       hipLaunchKernelGGL(window_attention_kernel<2>, grid, dim3(128), lds, st, q, k, v, out, G, do_shift, scale);

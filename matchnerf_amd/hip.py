@@ -64,7 +64,7 @@ class EncoderLayer(C.Structure):
 
 
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
-WA_SPLIT_BF16, WA_EXACT_F32 = 0, 1
+WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
 
 
 def lib_path():
@@ -403,11 +403,11 @@ def render_workspace_bytes(n_rays, n_samples, cond_stride):
 
 
 def wa_math():
-    """Matrix arithmetic of the window-attention kernel: MNERF_WA_MATH = 'bf16x6' (default) or 'f32'."""
-    m = os.environ.get("MNERF_WA_MATH", "bf16x6")
-    if m not in ("bf16x6", "f32"):
-        raise ValueError(f"MNERF_WA_MATH={m!r}: expected 'bf16x6' or 'f32'")
-    return WA_EXACT_F32 if m == "f32" else WA_SPLIT_BF16
+    """Matrix arithmetic of the window-attention kernel: MNERF_WA_MATH = 'f16x3' (default), 'bf16x6' or 'f32'."""
+    m = os.environ.get("MNERF_WA_MATH", "f16x3")
+    if m not in ("f16x3", "bf16x6", "f32"):
+        raise ValueError(f"MNERF_WA_MATH={m!r}: expected 'f16x3', 'bf16x6' or 'f32'")
+    return {"f16x3": WA_SPLIT_F16, "bf16x6": WA_SPLIT_BF16, "f32": WA_EXACT_F32}[m]
 
 
 def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, stream=None):

@@ -124,10 +124,11 @@ def test_window_attention_matches_reference(hip, golden, tag):
     assert linf(hip.window_attention(q, k, v, h, w, 1, False), g[f"{tag}_full"]) < 2e-5
 
 
-@pytest.mark.parametrize("math", ["bf16x6", "f32"])
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
 def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
-    """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case, through both
-    matrix paths of the kernel (split-bf16 = default, exact-f32 MFMA)."""
+    """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case, through all three
+    matrix paths of the kernel (split-fp16 = default, split-bf16, exact-f32 MFMA); the second pass scales tokens by
+    wildly different factors (the split-fp16 path's per-query / per-tile gains)."""
     monkeypatch.setenv("MNERF_WA_MATH", math)
     gen = torch.Generator().manual_seed(3)
     for (b, h, w, splits) in ((2, 64, 80, 2), (1, 50, 50, 2)):
@@ -136,6 +137,12 @@ def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
             ref = O.window_attention(q, k, v, h, w, splits, shifted)
             out = hip.window_attention(q.cuda(), k.cuda(), v.cuda(), h, w, splits, shifted)
             assert linf(out, ref) < 2e-5, (h, w, shifted)
+        # magnitudes spread over 2^+-10 across tokens (values) and queries; softmax stays well-conditioned (k unscaled)
+        sv = 2.0 ** torch.randint(-10, 11, (b, h * w, 1), generator=gen).float()
+        sq = 2.0 ** torch.randint(-3, 2, (b, h * w, 1), generator=gen).float()
+        ref = O.window_attention(q * sq, k, v * sv, h, w, splits, True)
+        out = hip.window_attention((q * sq).cuda(), k.cuda(), (v * sv).cuda(), h, w, splits, True)
+        assert torch.isfinite(out).all() and linf(out, ref) < 2e-5 * float(ref.abs().max()), (h, w, "scaled")
 
 
 @pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])

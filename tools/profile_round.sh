@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; rm -rf /tmp/prof_$TAG /tmp/pmc_${TAG}_*
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o trace -- python $R/tools/prof_render.py 3 > $O/trace.log 2>&1
-python $R/tools/rocpd_stats.py $(find /tmp/prof_$TAG -name '*.db' | head -1) > $O/kernel_stats.md 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/prof_$TAG -name '*.db' | head -1) 40 --last-frame 5 > $O/kernel_stats.md 2>&1
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
 B="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT"
 for P in a b c d; do

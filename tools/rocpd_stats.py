@@ -2,17 +2,25 @@
 the same content `rocprofv3 --stats` prints as kernel_stats.csv in older releases.
 
     python tools/rocpd_stats.py gpurun_out/prof/x_results.db > profiles/r1_kernel_stats.md
+    python tools/rocpd_stats.py x_results.db 40 --last-frame 5   # only the dispatches after the 6th-from-last
+                                                                 # decoder_kernel launch: the steady-state frame
+                                                                 # (5 ray-chunk launches), without MIOpen's find pass
 """
 import sqlite3
 import sys
 
 
-def main(path, top=40):
+def main(path, top=40, last_frame=0):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+    if last_frame:
+        dec = sorted(e for n, s, e in rows if "decoder_kernel" in n)
+        if len(dec) > last_frame:
+            t0 = dec[-last_frame - 1]
+            rows = [r for r in rows if r[1] > t0]
     agg = {}
     for name, s, e in rows:
         d = (e - s) / 1e3  # ns -> us
@@ -31,4 +39,5 @@ def main(path, top=40):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    lf = int(sys.argv[sys.argv.index("--last-frame") + 1]) if "--last-frame" in sys.argv else 0
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 40, lf)
