@@ -224,9 +224,9 @@ int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays,
  * shift-mask tensor (models/gmflow/transformer.py:8-16, 19-43, 46-105).
  * q,k,v,out [batch, h*w, 128]; num_splits >= 1 (1 = full attention); `shifted` applies the
  * swin roll by half a window with wrap-region masking (-100 added across regions).
- * `math`: MNERF_WA_SPLIT_F16 (fp32-grade products from two range-managed fp16 terms per operand, three products
- * per MAC on the fp16 matrix cores: the fastest; gains per query and per 32-key K / V tile), MNERF_WA_SPLIT_BF16
- * (three bf16 terms per operand, six products) or MNERF_WA_EXACT_F32 (v_mfma_f32_32x32x2_f32). */
+ * `math`: MNERF_WA_SPLIT_BF16 (fp32-grade products from three bf16 terms per operand, six products per MAC on the
+ * bf16 matrix cores: the fastest measured, the host's default), MNERF_WA_SPLIT_F16 (two range-managed fp16 terms,
+ * three products; gains per query and per 32-key K / V tile) or MNERF_WA_EXACT_F32 (v_mfma_f32_32x32x2_f32). */
 #define MNERF_WA_SPLIT_BF16 0
 #define MNERF_WA_EXACT_F32 1
 #define MNERF_WA_SPLIT_F16 2

@@ -399,10 +399,13 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_bf16_kernel(
   }
 }
 
-// ============================================================================ split-fp16 variant (default)
+// ============================================================================ split-fp16 variant
 // The same loop on v_mfma_f32_32x32x16_f16 with two range-managed fp16 terms per operand and three products per MAC
 // (split_f16.hpp; decoder.hip "split-fp16 matrix path"): half the matrix instructions of the split-bf16 variant and
-// less than half of its operand-split VALU work, which is what bounds that kernel.  Gains (exact powers of two):
+// less than half of its operand-split VALU work.  NOT the default: the tile maxima have to be known before the first
+// product of a tile (read the whole tile, reduce across the wave, then split), which serialises a loop that is
+// latency-bound already — 229 us per call against 204 us for the split-bf16 variant at 64x80 tokens on MI355X.
+// Gains (exact powers of two):
 //   Q   one per query (lane), from the query's 128 channels;
 //   K,V one per 32-key TILE (the wave's 64 lanes hold the whole tile exactly once: in-lane max + wave butterfly);
 //   P   fixed 2^14 (probabilities are <= 1).
@@ -622,7 +625,7 @@ extern "C" int mnerf_window_attention(const float* q, const float* k, const floa
   hipStream_t st = (hipStream_t)stream;
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * num_splits * num_splits * batch;
   const size_t lds = 4 * WA_KT * WA_C * sizeof(float);  // 64 KiB: K and V tiles, double buffered
-  const bool split = math == MNERF_WA_SPLIT_BF16;  // split-bf16 products, split-fp16 products (default) or the exact-f32 MFMA
+  const bool split = math == MNERF_WA_SPLIT_BF16;  // split-bf16 products (the host's default), split-fp16 products or the exact-f32 MFMA
   const bool split_h = math == MNERF_WA_SPLIT_F16;
   static std::atomic<unsigned long long> attr_f32{0}, attr_split{0}, attr_split_h{0};
   if (split_h && mnerf_once_per_device(attr_split_h)) {
