@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
     if (!ray_live) ray_ll = R.n_rays - 1;
     const int ray = (int)ray_ll;
     const int jrow = j0 < S ? j0 : S - 1;
-    cv_walk_unit<CPL, CVW_SEG>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
+    cv_walk_unit<CPL, CVW_SEG, true>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
                                uv_lds, wrec_lds, cs_lds, sub);
   }
 }

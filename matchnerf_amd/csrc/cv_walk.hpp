@@ -243,7 +243,22 @@ __host__ __device__ inline int cv_slot_lds_floats(int seg, int n_views, int sum_
 // the stand-alone kernel, LDS in the fused ray-chunk kernel), rows are `cond_stride` floats apart; samples at or
 // beyond S are computed on the last real sample and not written.  uv / wrec / cs: this slot's LDS scratch.
 // Only wave-level synchronisation inside (the lanes of a slot belong to one wave).
-template <int CPL, int SEG>
+#ifndef MNERF_NT_COND
+#define MNERF_NT_COND 1
+#endif
+// row stores: written once and read once by another kernel (stand-alone form): streamed past the caches
+template <bool NT>
+__device__ __forceinline__ void cv_store(float* p, float v) {
+#if MNERF_NT_COND
+  if constexpr (NT) {
+    __builtin_nontemporal_store(v, p);
+    return;
+  }
+#endif
+  *p = v;
+}
+
+template <int CPL, int SEG, bool NT = false>
 __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
                                              float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds,
                                              float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub) {
@@ -281,16 +296,16 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
       if (live) {
-        out[sumG + 3 * v + 0] = t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11;
-        out[sumG + 3 * v + 1] = t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11;
-        out[sumG + 3 * v + 2] = t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11;
-        out[sumG + 3 * V + v] = m;
+        cv_store<NT>(out + sumG + 3 * v + 0, t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11);
+        cv_store<NT>(out + sumG + 3 * v + 1, t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11);
+        cv_store<NT>(out + sumG + 3 * v + 2, t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11);
+        cv_store<NT>(out + sumG + 3 * V + v, m);
       }
     }
     if (live) {
       const int dc = sumG + 4 * V;
-      out[dc] = 1.0f;  // constant input of the packed FiLM bias column
-      for (int c = dc + 1; c < cond_stride; ++c) out[c] = 0.0f;
+      cv_store<NT>(out + dc, 1.0f);  // constant input of the packed FiLM bias column
+      for (int c = dc + 1; c < cond_stride; ++c) cv_store<NT>(out + c, 0.0f);
     }
   }
   for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
@@ -355,7 +370,7 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
     const int js = sub + LPS * half;
     if (js < SEG && ray_live && (j0 + js < S)) {
       float* out = row0 + (size_t)js * cond_stride;
-      for (int c = 0; c < sumG; ++c) out[c] = cs_lds[js * cs_stride + c] * inv_pairs;
+      for (int c = 0; c < sumG; ++c) cv_store<NT>(out + c, cs_lds[js * cs_stride + c] * inv_pairs);
     }
   }
   __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds / wrec_lds are rewritten by the next unit

@@ -339,6 +339,23 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
 }
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
 
+// The conditioning rows are read exactly once (0.4 GB per launch streaming through L2): non-temporal loads keep
+// them from evicting the kernel's register-spill scratch lines, which would otherwise bounce to HBM and back
+// (rows in LDS - the fused form - are read normally).
+#ifndef MNERF_NT_COND
+#define MNERF_NT_COND 1
+#endif
+__device__ __forceinline__ float4 ld_stream4(const float* p, bool lds) {
+#if MNERF_NT_COND
+  if (!lds) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  }
+#endif
+  return *reinterpret_cast<const float4*>(p);
+}
+
 template <int NW, int SP>
 struct Smem {
   static constexpr int TILE = NW * 32;
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
-        cpre[i] = (o + 4 <= CS && (i >> 1) < sch.film_steps) ? *reinterpret_cast<const float4*>(crow_base + o)
+        cpre[i] = (o + 4 <= CS && (i >> 1) < sch.film_steps) ? ld_stream4(crow_base + o, CVF)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
