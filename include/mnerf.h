@@ -225,7 +225,7 @@ int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays,
  * q,k,v,out [batch, h*w, 128]; num_splits >= 1 (1 = full attention); `shifted` applies the
  * swin roll by half a window with wrap-region masking (-100 added across regions).
  * `math`: MNERF_WA_SPLIT_BF16 (fp32-grade products from three bf16 terms per operand, six products per MAC on the
- * bf16 matrix cores: the fastest measured, the host's default), MNERF_WA_SPLIT_F16 (two range-managed fp16 terms,
+ * bf16 matrix cores), MNERF_WA_SPLIT_F16 (two range-managed fp16 terms,
  * three products; gains per query and per 32-key K / V tile) or MNERF_WA_EXACT_F32 (v_mfma_f32_32x32x2_f32). */
 #define MNERF_WA_SPLIT_BF16 0
 #define MNERF_WA_EXACT_F32 1
@@ -233,6 +233,17 @@ int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays,
 int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                            int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                            int32_t shifted, int32_t math, void* stream);
+
+/* K6 with the K / V matrix operands prepared once per call (the host's default): a first small kernel turns every
+ * 32-key tile of every window into split-fp16 operand fragments + one power-of-two gain per tile and matrix in
+ * `workspace`, the attention kernel streams those images through LDS (arithmetic = MNERF_WA_SPLIT_F16; its waves
+ * no longer convert the window's K and V once per 32 queries).  Same arguments and semantics as above;
+ * `workspace`: device, 16-byte aligned, at least mnerf_window_attention_workspace_bytes(batch, h, w, num_splits)
+ * bytes (= the size of k and v together + 32 bytes per tile), scratch only - nothing is kept between calls. */
+size_t mnerf_window_attention_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t num_splits);
+int mnerf_window_attention_presplit(const float* q, const float* k, const float* v, float* out,
+                                    int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
  * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):

@@ -244,9 +244,9 @@ __host__ __device__ inline int cv_slot_lds_floats(int seg, int n_views, int sum_
 // beyond S are computed on the last real sample and not written.  uv / wrec / cs: this slot's LDS scratch.
 // Only wave-level synchronisation inside (the lanes of a slot belong to one wave).
 #ifndef MNERF_NT_COND
-#define MNERF_NT_COND 1
+#define MNERF_NT_COND 0  // see decoder.hip: non-temporal row traffic measured slower, kept as a build-time experiment
 #endif
-// row stores: written once and read once by another kernel (stand-alone form): streamed past the caches
+// row stores of the stand-alone form (NT only has an effect when MNERF_NT_COND is built in)
 template <bool NT>
 __device__ __forceinline__ void cv_store(float* p, float v) {
 #if MNERF_NT_COND

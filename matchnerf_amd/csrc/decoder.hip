@@ -339,11 +339,12 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
 }
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
 
-// The conditioning rows are read exactly once (0.4 GB per launch streaming through L2): non-temporal loads keep
-// them from evicting the kernel's register-spill scratch lines, which would otherwise bounce to HBM and back
-// (rows in LDS - the fused form - are read normally).
+// Experiment knob, OFF: streaming the conditioning rows with non-temporal stores (cost volume) and loads (here).
+// Measured on MI355X (profiles/r2_nt_*): the rows then really travel to HBM and back instead of being served from
+// L2 / Infinity Cache - 3.3 GB instead of 2.2 GB of HBM traffic per 65 536-ray launch, cost volume 9.8 -> 11.2 ms,
+// decoder unchanged.  The write-then-read pair of the staged form is served best by the default cache policy.
 #ifndef MNERF_NT_COND
-#define MNERF_NT_COND 1
+#define MNERF_NT_COND 0
 #endif
 __device__ __forceinline__ float4 ld_stream4(const float* p, bool lds) {
 #if MNERF_NT_COND

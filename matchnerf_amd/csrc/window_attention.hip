@@ -596,6 +596,339 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_f16_kernel(
   }
 }
 
+// ============================================================================ pre-split fp16 variant
+// The split-fp16 arithmetic above with the K / V operand fragments produced ONCE per call instead of once per wave
+// and tile: in the kernels above every one of the Lw/32 query waves of a window converts the window's whole K and V
+// (Lw x 128 values each) to matrix operands again - 70 % of their VALU instructions.  wa_presplit_kernel (one wave per
+// 32-key tile) writes, per (batch, window, tile), a 32 KiB image that IS the LDS image the main loop wants:
+//   K part  [t = 0..7 ][term hi|lo][lane 0..63] x 16 B   A operand of K16-step t of S^T (lane = key n, half hl)
+//   V part  [t = 0..1 ][m = 0..3][term hi|lo][lane]  x 16 B   A operand of step t, output block m of O^T
+// plus a 32-byte side record: the two power-of-two gain exponents of the tile (ek, ev) and the wrap region of each of
+// its keys (shift mask, one nibble per key - the kernels above recompute them with an integer division per score).  The main kernel copies an image with
+// 32 x 1 KiB LDS-DMA pieces and reads every fragment with one conflict-free ds_read_b128; the tile gains come from a
+// scalar load issued one tile ahead, so nothing in the loop waits for a reduction any more (what made the in-loop
+// split-fp16 variant slower than split-bf16).  Same products, same accumulation order as window_attention_f16_kernel.
+#define WA_IMG_BYTES 32768
+#define WA_IMG_VOFF 1024  // u32x4 index of the V part inside an image
+#define WA_REC_INTS 8     // side record of a tile: ek, ev, 4 words of key wrap regions (one nibble per key), 2 pad
+
+__global__ __launch_bounds__(64) void wa_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                         u32x4* __restrict__ img, int* __restrict__ gains, WinGeom G) {
+  const int lane = threadIdx.x, n = lane & 31, hl = lane >> 5;
+  const int kt = blockIdx.x, win = blockIdx.y, b = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
+  const size_t tile = ((size_t)b * gridDim.y + win) * gridDim.x + kt;
+  u32x4* dst = img + tile * (WA_IMG_BYTES / 16) + lane;
+  int reg_unused;
+  int ek, ev;
+  {  // ---- K: lane (key n, half hl) holds channels 16t + 8hl .. + 7 of every K16-step t
+    int li = kt * WA_KT + n;
+    if (li >= G.Lw) li = G.Lw - 1;
+    const int tok = win_token(G, wy, wx, li, reg_unused);
+    const float4* src = reinterpret_cast<const float4*>(k + seq_base + (size_t)tok * WA_C + hl * 8);
+    float kv[64];
+    float kmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 a = src[4 * t], c = src[4 * t + 1];
+      kv[8 * t + 0] = a.x; kv[8 * t + 1] = a.y; kv[8 * t + 2] = a.z; kv[8 * t + 3] = a.w;
+      kv[8 * t + 4] = c.x; kv[8 * t + 5] = c.y; kv[8 * t + 6] = c.z; kv[8 * t + 7] = c.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) kmax = fmaxf(kmax, fabsf(kv[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) kmax = fmaxf(kmax, __shfl_xor(kmax, off, 64));
+    ek = gain_exp(kmax);
+    const float mk = pow2i(ek);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = kv[8 * t + j];
+      const PartsH kp = split8h(v8, mk);
+      dst[(2 * t) * 64] = __builtin_bit_cast(u32x4, kp.hi);
+      dst[(2 * t + 1) * 64] = __builtin_bit_cast(u32x4, kp.lo);
+    }
+  }
+  {  // ---- V: lane (n, hl) holds V[key(t, hl, j)][32m + n], key(t, hl, j) = ((8t+j)&3) + 8((8t+j)>>2) + 4hl
+    float vv[2][4][8];
+    float vmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = 8 * t + j;
+        int li = kt * WA_KT + (r & 3) + 8 * (r >> 2) + 4 * hl;
+        if (li >= G.Lw) li = G.Lw - 1;
+        const int tok = win_token(G, wy, wx, li, reg_unused);
+        const float* row = v + seq_base + (size_t)tok * WA_C + n;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float x = row[32 * m];
+          vv[t][m][j] = x;
+          vmax = fmaxf(vmax, fabsf(x));
+        }
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    ev = gain_exp(vmax);
+    const float mv = pow2i(ev);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const PartsH vp = split8h(vv[t][m], mv);
+        dst[(WA_IMG_VOFF / 64 + 2 * (4 * t + m)) * 64] = __builtin_bit_cast(u32x4, vp.hi);
+        dst[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64] = __builtin_bit_cast(u32x4, vp.lo);
+      }
+  }
+  // ---- wrap region (0..8) of every key of the tile, one nibble per key (lane n < 32 owns key n)
+  unsigned nib;
+  {
+    int li = kt * WA_KT + n, region;
+    if (li >= G.Lw) li = G.Lw - 1;
+    (void)win_token(G, wy, wx, li, region);
+    nib = (unsigned)region << (4 * (n & 7));
+  }
+  nib |= __shfl_xor(nib, 1, 64);
+  nib |= __shfl_xor(nib, 2, 64);
+  nib |= __shfl_xor(nib, 4, 64);  // lanes 8g .. 8g+7 now hold word g
+  int* rec = gains + WA_REC_INTS * tile;
+  if (lane < 32 && (lane & 7) == 0) rec[2 + (lane >> 3)] = (int)nib;
+  if (lane == 0) {
+    rec[0] = ek;
+    rec[1] = ev;
+  }
+}
+
+template <int NQW>
+__device__ __forceinline__ void wa_stage_image(const u32x4* __restrict__ img_tile, unsigned lds_base, int wave, int lane) {
+  for (int piece = wave; piece < WA_IMG_BYTES / 1024; piece += NQW)
+    wa_glds16(reinterpret_cast<const float*>(img_tile + piece * 64 + lane),
+              __builtin_amdgcn_readfirstlane(lds_base + (unsigned)piece * 1024u));
+}
+
+template <int NQW>
+__global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
+    const float* __restrict__ q, const u32x4* __restrict__ img, const int* __restrict__ gains,
+    float* __restrict__ out, WinGeom G, int shifted, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float wa_smem[];  // two images: 64 KiB
+  const unsigned smem0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wa_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  const int win = blockIdx.y, b = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
+
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  const size_t tile0 = ((size_t)b * gridDim.y + win) * n_tiles;
+  const u32x4* img_win = img + tile0 * (WA_IMG_BYTES / 16);
+  const int4* rec_win = reinterpret_cast<const int4*>(gains + WA_REC_INTS * tile0);
+  wa_stage_image<NQW>(img_win, smem0, wave, lane);
+  int4 ra = rec_win[0], rb = rec_win[1];  // (ek, ev, regions 0-7, 8-15), (regions 16-23, 24-31, -, -)
+
+  // ---- this lane's query, split once: K-step t holds channels 16t + 8 hl + j
+  const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
+  const bool q_ok = qi_raw < G.Lw;
+  int q_region;
+  const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
+  PartsH qp[8];
+  int eq;
+  {
+    const float4* src = reinterpret_cast<const float4*>(q + seq_base + (size_t)q_tok * WA_C + hl * 8);
+    float qv[64];
+    float qmax = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 a = src[4 * t], c = src[4 * t + 1];
+      qv[8 * t + 0] = a.x; qv[8 * t + 1] = a.y; qv[8 * t + 2] = a.z; qv[8 * t + 3] = a.w;
+      qv[8 * t + 4] = c.x; qv[8 * t + 5] = c.y; qv[8 * t + 6] = c.z; qv[8 * t + 7] = c.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) qmax = fmaxf(qmax, fabsf(qv[i]));
+    qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
+    eq = gain_exp(qmax);
+    const float mq = pow2i(eq);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = qv[8 * t + j];
+      qp[t] = split8h(v8, mq);
+    }
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
+  float m_run = -3.0e38f, l_run = 0.0f;
+  int ev_run = 0;  // V gain exponent the output accumulator currently carries (irrelevant while o == 0)
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int cur = kt & 1;
+    int4 ra_next = ra, rb_next = rb;
+    if (kt + 1 < n_tiles) {
+      wa_stage_image<NQW>(img_win + (size_t)(kt + 1) * (WA_IMG_BYTES / 16), smem0 + (unsigned)(cur ^ 1) * WA_IMG_BYTES, wave, lane);
+      ra_next = rec_win[2 * (kt + 1)];
+      rb_next = rec_win[2 * (kt + 1) + 1];
+    }
+    const int ek = ra.x, ev = ra.y;
+    const unsigned regw[4] = {(unsigned)ra.z, (unsigned)ra.w, (unsigned)rb.x, (unsigned)rb.y};
+    lds_u32x4_cptr frag = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)cur * WA_IMG_BYTES) + lane;
+    // ---- S^T = K Q^T: 8 K16-steps, two accumulators so that consecutive MFMA groups are independent
+    f32x16 s0 = (f32x16)(0.0f), s1 = (f32x16)(0.0f);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f16x8 khi = __builtin_bit_cast(f16x8, frag[(2 * t) * 64]);
+      const f16x8 klo = __builtin_bit_cast(f16x8, frag[(2 * t + 1) * 64]);
+      if (t & 1) {
+        s1 = mfma16h(khi, qp[t].lo, s1);
+        s1 = mfma16h(klo, qp[t].hi, s1);
+        s1 = mfma16h(khi, qp[t].hi, s1);
+      } else {
+        s0 = mfma16h(khi, qp[t].lo, s0);
+        s0 = mfma16h(klo, qp[t].hi, s0);
+        s0 = mfma16h(khi, qp[t].hi, s0);
+      }
+    }
+    f32x16 s = s0 + s1;
+    const float sscale = scale * pow2i(-(ek + eq));
+    // ---- scale, masks, online softmax (as in the f32 kernel)
+    float tmax = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
+      const int li = kt * WA_KT + key;
+      float sv = s[r] * sscale;
+      if (shifted) {  // key (r, hl) = nibble (r & 3) + 4 hl of word r >> 2
+        const int kreg = (int)((regw[r >> 2] >> (4 * (r & 3) + 16 * hl)) & 15u);
+        if (kreg != q_region) sv += -100.0f;
+      }
+      if (li >= G.Lw) sv = -3.0e38f;
+      s[r] = sv;
+      tmax = fmaxf(tmax, sv);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      s[r] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // ---- O^T += V^T P^T; the softmax correction and the change of V gain ride in one multiplication
+    const float corr = alpha * pow2i(ev - ev_run);
+    ev_run = ev;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[m][r] *= corr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+      const PartsH pp = split8h(pv, 16384.0f);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f16x8 vhi = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m)) * 64]);
+        const f16x8 vlo = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64]);
+        o[m] = mfma16h(vhi, pp.lo, o[m]);
+        o[m] = mfma16h(vlo, pp.hi, o[m]);
+        o[m] = mfma16h(vhi, pp.hi, o[m]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ra = ra_next;
+    rb = rb_next;
+  }
+  if (q_ok) {
+    const float inv_l = pow2i(-(ev_run + 14)) / l_run;
+    float* dst = out + seq_base + (size_t)q_tok * WA_C;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 t = make_float4(o[m][4 * g4] * inv_l, o[m][4 * g4 + 1] * inv_l,
+                                     o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
+        *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
+      }
+  }
+}
+
+static int wa_geometry(const char* who, int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                       WinGeom& G, int& do_shift) {
+  MNERF_REQUIRE(batch >= 0 && h >= 1 && w >= 1 && num_splits >= 1, MNERF_E_RANGE, "%s: batch=%d h=%d w=%d splits=%d",
+                who, batch, h, w, num_splits);
+  MNERF_REQUIRE(h % num_splits == 0 && w % num_splits == 0, MNERF_E_RANGE, "%s: %dx%d not divisible into %d splits",
+                who, h, w, num_splits);
+  MNERF_REQUIRE(batch <= 65535 && num_splits * num_splits <= 65535, MNERF_E_RANGE, "%s: grid too large", who);
+  G.h = h;
+  G.w = w;
+  G.splits = num_splits;
+  G.wh = h / num_splits;
+  G.ww = w / num_splits;
+  do_shift = (shifted && num_splits > 1) ? 1 : 0;
+  G.sh = do_shift ? G.wh / 2 : 0;
+  G.sw = do_shift ? G.ww / 2 : 0;
+  G.Lw = G.wh * G.ww;
+  return MNERF_OK;
+}
+
+extern "C" size_t mnerf_window_attention_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t num_splits) {
+  if (batch <= 0 || h < 1 || w < 1 || num_splits < 1 || h % num_splits || w % num_splits) return 0;
+  const size_t lw = (size_t)(h / num_splits) * (w / num_splits);
+  const size_t tiles = (size_t)batch * num_splits * num_splits * ((lw + WA_KT - 1) / WA_KT);
+  return tiles * (WA_IMG_BYTES + WA_REC_INTS * sizeof(int32_t));
+}
+
+extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, const float* v, float* out,
+                                               int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  const char* who = "mnerf_window_attention_presplit";
+  MNERF_REQUIRE(q && k && v && out, MNERF_E_NULL, "%s: NULL buffer", who);
+  MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(k) && mnerf_aligned16(v) && mnerf_aligned16(out), MNERF_E_ALIGN,
+                "%s: buffers must be 16-byte aligned", who);
+  WinGeom G;
+  int do_shift;
+  if (const int rc = wa_geometry(who, batch, h, w, num_splits, shifted, G, do_shift)) return rc;
+  if (batch == 0) return MNERF_OK;
+  const size_t need = mnerf_window_attention_workspace_bytes(batch, h, w, num_splits);
+  MNERF_REQUIRE(workspace && mnerf_aligned16(workspace), MNERF_E_ALIGN, "%s: workspace NULL or not 16-byte aligned", who);
+  MNERF_REQUIRE(workspace_bytes >= need, MNERF_E_RANGE, "%s: workspace %zu bytes < %zu", who, workspace_bytes, need);
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  const int n_win = num_splits * num_splits;
+  u32x4* img = reinterpret_cast<u32x4*>(workspace);
+  int* gains = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)batch * n_win * n_tiles * WA_IMG_BYTES);
+  const float scale = 1.0f / sqrtf((float)WA_C);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = 2 * WA_IMG_BYTES;
+  static std::atomic<unsigned long long> attr{0};
+  if (mnerf_once_per_device(attr)) {
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
+  const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
+  if (wgs4 >= mnerf_tune().wa_min4)
+    hipLaunchKernelGGL(window_attention_pre_kernel<4>, dim3((G.Lw + 127) / 128, n_win, batch), dim3(256), lds, st, q, img,
+                       gains, out, G, do_shift, scale);
+  else
+    hipLaunchKernelGGL(window_attention_pre_kernel<2>, dim3((G.Lw + 63) / 64, n_win, batch), dim3(128), lds, st, q, img,
+                       gains, out, G, do_shift, scale);
+  return mnerf_check_launch(who);
+}
+
 extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,
                                       int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                                       int32_t shifted, int32_t math, void* stream) {

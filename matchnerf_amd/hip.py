@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -65,6 +65,7 @@ class EncoderLayer(C.Structure):
 
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
 WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
+WA_PRESPLIT_F16 = 3  # host-side selector only: routed to mnerf_window_attention_presplit
 
 
 def lib_path():
@@ -121,6 +122,10 @@ def load():
     lib.mnerf_render_chunk.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), vp, fp, fp, fp, vp]
     lib.mnerf_window_attention.restype = C.c_int
     lib.mnerf_window_attention.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_window_attention_workspace_bytes.restype = C.c_size_t
+    lib.mnerf_window_attention_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.mnerf_window_attention_presplit.restype = C.c_int
+    lib.mnerf_window_attention_presplit.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_encoder_block_wstream_floats.restype = i64
     lib.mnerf_encoder_block_wstream_floats.argtypes = [i32]
     lib.mnerf_encoder_block.restype = C.c_int
@@ -403,13 +408,16 @@ def render_workspace_bytes(n_rays, n_samples, cond_stride):
 
 
 def wa_math():
-    """Matrix arithmetic of the window-attention kernel: MNERF_WA_MATH = 'bf16x6' (default), 'f16x3' or 'f32'.
-    (f16x3 halves the matrix instructions but needs the K / V tile maxima before the first product of a tile, which
-    serialises a latency-bound loop: measured 229 us per call against 204 us for bf16x6 at 64x80 tokens.)"""
-    m = os.environ.get("MNERF_WA_MATH", "bf16x6")
-    if m not in ("f16x3", "bf16x6", "f32"):
-        raise ValueError(f"MNERF_WA_MATH={m!r}: expected 'f16x3', 'bf16x6' or 'f32'")
-    return {"f16x3": WA_SPLIT_F16, "bf16x6": WA_SPLIT_BF16, "f32": WA_EXACT_F32}[m]
+    """Matrix arithmetic of the window-attention kernel, MNERF_WA_MATH =
+      'f16pre' (default)  split-fp16 products, K / V operand fragments + tile gains prepared once per call
+      'f16x3'             the same arithmetic, every wave splits the K / V tiles itself (slower: 229 us per call)
+      'bf16x6'            split-bf16, six products per MAC (204 us per call at 64x80 tokens)
+      'f32'               exact-f32 MFMA"""
+    m = os.environ.get("MNERF_WA_MATH", "f16pre")
+    table = {"f16pre": WA_PRESPLIT_F16, "f16x3": WA_SPLIT_F16, "bf16x6": WA_SPLIT_BF16, "f32": WA_EXACT_F32}
+    if m not in table:
+        raise ValueError(f"MNERF_WA_MATH={m!r}: expected one of {sorted(table)}")
+    return table[m]
 
 
 def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, stream=None):
@@ -422,10 +430,19 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
         raise MnerfError(f"window_attention: expected [B,{h * w},128], got {tuple(q.shape)}")
     if out is None:
         out = torch.empty_like(q)
+    math = wa_math() if math is None else int(math)
     with _on(q.device, stream) as st:
-        check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
-                                         int(bool(shifted)), wa_math() if math is None else int(math), st),
-              "mnerf_window_attention")
+        if math == WA_PRESPLIT_F16:
+            nbytes = int(lib.mnerf_window_attention_workspace_bytes(b, h, w, int(num_splits)))
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)  # caching allocator: no hipMalloc
+            if stream is not None:
+                ws.record_stream(stream)
+            check(lib.mnerf_window_attention_presplit(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
+                                                      int(bool(shifted)), C.c_void_p(ws.data_ptr()), nbytes, st),
+                  "mnerf_window_attention_presplit")
+        else:
+            check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
+                                             int(bool(shifted)), math, st), "mnerf_window_attention")
     return out
 
 

@@ -124,10 +124,11 @@ def test_window_attention_matches_reference(hip, golden, tag):
     assert linf(hip.window_attention(q, k, v, h, w, 1, False), g[f"{tag}_full"]) < 2e-5
 
 
-@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
+@pytest.mark.parametrize("math", ["f16pre", "f16x3", "bf16x6", "f32"])
 def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
     """one 64x80 map (1280-token windows, BASELINE config[1]) + a 25x25-window tail case, through all three
-    matrix paths of the kernel (split-bf16 = default, split-fp16, exact-f32 MFMA); the second pass scales tokens by
+    matrix paths of the kernel (split-fp16 with K / V operands prepared once per call = default, split-fp16 in the
+    loop, split-bf16, exact-f32 MFMA); the second pass scales tokens by
     wildly different factors (the split-fp16 path's per-query / per-tile gains)."""
     monkeypatch.setenv("MNERF_WA_MATH", math)
     gen = torch.Generator().manual_seed(3)
