@@ -712,25 +712,33 @@ __device__ __forceinline__ void wa_stage_image(const u32x4* __restrict__ img_til
 template <int NQW>
 __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const float* __restrict__ q, const u32x4* __restrict__ img, const int* __restrict__ gains,
-    float* __restrict__ out, WinGeom G, int shifted, float scale) {
+    float* __restrict__ out, WinGeom G, int shifted, float scale, int n_batch, int xcd_map) {
   extern __shared__ __attribute__((aligned(16))) float wa_smem[];  // two images: 64 KiB
   const unsigned smem0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wa_smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hl = lane >> 5;
-  const int win = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round-robin by their linear id, so id = 8 * slot + xcd; all query
+  // blocks of one window get the same xcd - the window's K / V images (1.3 MB at 1280 tokens) are then fetched into
+  // ONE L2 and hit there by its other query blocks, instead of missing in all eight
+  const int n_win = G.splits * G.splits;
+  const int n_qb = (G.Lw + NQW * 32 - 1) / (NQW * 32);
+  const int slot = xcd_map ? blockIdx.x >> 3 : blockIdx.x, wl = slot / n_qb;
+  const int qblock = slot - wl * n_qb, gwin = xcd_map ? wl * 8 + (blockIdx.x & 7) : wl;
+  if (gwin >= n_win * n_batch) return;
+  const int b = gwin / n_win, win = gwin - b * n_win;
   const int wy = win / G.splits, wx = win - wy * G.splits;
   const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
 
   const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
-  const size_t tile0 = ((size_t)b * gridDim.y + win) * n_tiles;
+  const size_t tile0 = (size_t)gwin * n_tiles;
   const u32x4* img_win = img + tile0 * (WA_IMG_BYTES / 16);
   const int4* rec_win = reinterpret_cast<const int4*>(gains + WA_REC_INTS * tile0);
   wa_stage_image<NQW>(img_win, smem0, wave, lane);
   int4 ra = rec_win[0], rb = rec_win[1];  // (ek, ev, regions 0-7, 8-15), (regions 16-23, 24-31, -, -)
 
   // ---- this lane's query, split once: K-step t holds channels 16t + 8 hl + j
-  const int qi_raw = (blockIdx.x * NQW + wave) * 32 + n;
+  const int qi_raw = (qblock * NQW + wave) * 32 + n;
   const bool q_ok = qi_raw < G.Lw;
   int q_region;
   const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
@@ -920,12 +928,13 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
   }
   hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
+  const long long win_groups = ((long long)n_win * batch + 7) / 8;  // windows per XCD
   if (wgs4 >= mnerf_tune().wa_min4)
-    hipLaunchKernelGGL(window_attention_pre_kernel<4>, dim3((G.Lw + 127) / 128, n_win, batch), dim3(256), lds, st, q, img,
-                       gains, out, G, do_shift, scale);
+    hipLaunchKernelGGL(window_attention_pre_kernel<4>, dim3((unsigned)(8 * win_groups * ((G.Lw + 127) / 128))), dim3(256), lds,
+                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd);
   else
-    hipLaunchKernelGGL(window_attention_pre_kernel<2>, dim3((G.Lw + 63) / 64, n_win, batch), dim3(128), lds, st, q, img,
-                       gains, out, G, do_shift, scale);
+    hipLaunchKernelGGL(window_attention_pre_kernel<2>, dim3((unsigned)(8 * win_groups * ((G.Lw + 63) / 64))), dim3(128), lds,
+                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd);
   return mnerf_check_launch(who);
 }
 
