@@ -787,23 +787,28 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const int ek = ra.x, ev = ra.y;
     const unsigned regw[4] = {(unsigned)ra.z, (unsigned)ra.w, (unsigned)rb.x, (unsigned)rb.y};
     lds_u32x4_cptr frag = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)cur * WA_IMG_BYTES) + lane;
-    // ---- S^T = K Q^T: 8 K16-steps, two accumulators so that consecutive MFMA groups are independent
-    f32x16 s0 = (f32x16)(0.0f), s1 = (f32x16)(0.0f);
+    // ---- S^T = K Q^T: 8 K16-steps x 3 products on FOUR accumulators, term-major inside a group of four steps, so
+    // that no matrix instruction waits for the result of one of the three before it (a product on the accumulator of
+    // its predecessor costs the full result latency with one wave per SIMD)
+    f32x16 sa[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const f16x8 khi = __builtin_bit_cast(f16x8, frag[(2 * t) * 64]);
-      const f16x8 klo = __builtin_bit_cast(f16x8, frag[(2 * t + 1) * 64]);
-      if (t & 1) {
-        s1 = mfma16h(khi, qp[t].lo, s1);
-        s1 = mfma16h(klo, qp[t].hi, s1);
-        s1 = mfma16h(khi, qp[t].hi, s1);
-      } else {
-        s0 = mfma16h(khi, qp[t].lo, s0);
-        s0 = mfma16h(klo, qp[t].hi, s0);
-        s0 = mfma16h(khi, qp[t].hi, s0);
+    for (int a = 0; a < 4; ++a) sa[a] = (f32x16)(0.0f);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f16x8 khi[4], klo[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        khi[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 * g + a)) * 64]);
+        klo[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 * g + a) + 1) * 64]);
       }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[4 * g + a].lo, sa[a]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(klo[a], qp[4 * g + a].hi, sa[a]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[4 * g + a].hi, sa[a]);
     }
-    f32x16 s = s0 + s1;
+    f32x16 s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     const float sscale = scale * pow2i(-(ek + eq));
     // ---- scale, masks, online softmax (as in the f32 kernel)
     float tmax = -3.0e38f;
@@ -846,14 +851,19 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
       const PartsH pp = split8h(pv, 16384.0f);
+      f16x8 vhi[4], vlo[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const f16x8 vhi = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m)) * 64]);
-        const f16x8 vlo = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64]);
-        o[m] = mfma16h(vhi, pp.lo, o[m]);
-        o[m] = mfma16h(vlo, pp.hi, o[m]);
-        o[m] = mfma16h(vhi, pp.hi, o[m]);
+        vhi[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m)) * 64]);
+        vlo[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64]);
       }
+      // term-major over the four output blocks: consecutive matrix instructions are independent
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.lo, o[m]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo[m], pp.hi, o[m]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.hi, o[m]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
