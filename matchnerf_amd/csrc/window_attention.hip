@@ -712,7 +712,7 @@ __device__ __forceinline__ void wa_stage_image(const u32x4* __restrict__ img_til
 template <int NQW>
 __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const float* __restrict__ q, const u32x4* __restrict__ img, const int* __restrict__ gains,
-    float* __restrict__ out, WinGeom G, int shifted, float scale, int n_batch, int xcd_map) {
+    float* __restrict__ out, WinGeom G, int shifted, float scale, int n_batch, int xcd_map, unsigned long long* tl) {
   extern __shared__ __attribute__((aligned(16))) float wa_smem[];  // two images: 64 KiB
   const unsigned smem0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wa_smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -776,6 +776,17 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+#ifdef MNERF_TIMELINE  // debug build (tools/exp/build_timeline.sh): cycles per loop phase, summed over the tiles
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tmark = __builtin_amdgcn_s_memtime();
+#define WA_STAMP(i)                                          \
+  do {                                                       \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    tph[i] += now - tmark;                                   \
+    tmark = now;                                             \
+  } while (0)
+#else
+#define WA_STAMP(i)
+#endif
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int cur = kt & 1;
     int4 ra_next = ra, rb_next = rb;
@@ -784,6 +795,7 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
       ra_next = rec_win[2 * (kt + 1)];
       rb_next = rec_win[2 * (kt + 1) + 1];
     }
+    WA_STAMP(0);  // DMA + record load issued
     const int ek = ra.x, ev = ra.y;
     const unsigned regw[4] = {(unsigned)ra.z, (unsigned)ra.w, (unsigned)rb.x, (unsigned)rb.y};
     lds_u32x4_cptr frag = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)cur * WA_IMG_BYTES) + lane;
@@ -809,6 +821,10 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
       for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[4 * g + a].hi, sa[a]);
     }
     f32x16 s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+#ifdef MNERF_TIMELINE
+    asm volatile("" ::"v"(s[0]));
+#endif
+    WA_STAMP(1);  // scores
     const float sscale = scale * pow2i(-(ek + eq));
     // ---- scale, masks, online softmax (as in the f32 kernel)
     float tmax = -3.0e38f;
@@ -838,6 +854,10 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
+#ifdef MNERF_TIMELINE
+    asm volatile("" ::"v"(l_run));
+#endif
+    WA_STAMP(2);  // softmax
     // ---- O^T += V^T P^T; the softmax correction and the change of V gain ride in one multiplication
     const float corr = alpha * pow2i(ev - ev_run);
     ev_run = ev;
@@ -865,11 +885,21 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
 #pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.hi, o[m]);
     }
+#ifdef MNERF_TIMELINE
+    asm volatile("" ::"v"(o[3][0]));
+#endif
+    WA_STAMP(3);  // output update
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WA_STAMP(4);  // own DMA pieces
     __syncthreads();
+    WA_STAMP(5);  // barrier
     ra = ra_next;
     rb = rb_next;
   }
+#ifdef MNERF_TIMELINE
+  if (tl && lane == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 6; ++i) tl[(blockIdx.x * NQW + wave) * 6 + i] = tph[i];
+#endif
   if (q_ok) {
     const float inv_l = pow2i(-(ev_run + 14)) / l_run;
     float* dst = out + seq_base + (size_t)q_tok * WA_C;
@@ -936,15 +966,19 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
     (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  unsigned long long* tl = nullptr;
+#ifdef MNERF_TIMELINE
+  if (const char* e = getenv("MNERF_WA_TIMELINE_PTR")) tl = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
   hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
   const long long win_groups = ((long long)n_win * batch + 7) / 8;  // windows per XCD
   if (wgs4 >= mnerf_tune().wa_min4)
     hipLaunchKernelGGL(window_attention_pre_kernel<4>, dim3((unsigned)(8 * win_groups * ((G.Lw + 127) / 128))), dim3(256), lds,
-                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd);
+                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd, tl);
   else
     hipLaunchKernelGGL(window_attention_pre_kernel<2>, dim3((unsigned)(8 * win_groups * ((G.Lw + 63) / 64))), dim3(128), lds,
-                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd);
+                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd, tl);
   return mnerf_check_launch(who);
 }
 
