@@ -702,6 +702,16 @@ __global__ __launch_bounds__(64) void wa_presplit_kernel(const float* __restrict
   }
 }
 
+// x of lane (n, 0) and of lane (n, 1) in every lane of the pair: v_permlane32_swap (gfx950) exchanges the upper half of
+// its first operand with the lower half of its second - one VALU instruction instead of a ds_bpermute round trip.
+// (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane32_swap into one)
+__device__ __forceinline__ void wa_halves(float x, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+
 template <int NQW>
 __device__ __forceinline__ void wa_stage_image(const u32x4* __restrict__ img_tile, unsigned lds_base, int wave, int lane) {
   for (int piece = wave; piece < WA_IMG_BYTES / 1024; piece += NQW)
@@ -787,71 +797,110 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
 #else
 #define WA_STAMP(i)
 #endif
+  // DMA pieces of the next image are issued BETWEEN the rows of matrix instructions (8 slots per tile): issued in one
+  // block at the top of the tile they cost 880 cycles of pure issue (110 each) with the matrix pipe idle
+  constexpr int PPS = (WA_IMG_BYTES / 1024) / NQW / 8;  // pieces per slot and wave
+  const float l2e = 1.44269504088896f;
+  const float mask_l2 = -100.0f * l2e;  // the reference's -100 across wrap regions, in the log2 domain
+  const bool ragged = (G.Lw & (WA_KT - 1)) != 0;
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int cur = kt & 1;
-    int4 ra_next = ra, rb_next = rb;
-    if (kt + 1 < n_tiles) {
-      wa_stage_image<NQW>(img_win + (size_t)(kt + 1) * (WA_IMG_BYTES / 16), smem0 + (unsigned)(cur ^ 1) * WA_IMG_BYTES, wave, lane);
-      ra_next = rec_win[2 * (kt + 1)];
-      rb_next = rec_win[2 * (kt + 1) + 1];
-    }
-    WA_STAMP(0);  // DMA + record load issued
+    // the last tile prefetches itself into the idle buffer (no branch around the pieces)
+    const int ktn = kt + 1 < n_tiles ? kt + 1 : kt;
+    const u32x4* img_next = img_win + (size_t)ktn * (WA_IMG_BYTES / 16) + lane;
+    const unsigned lds_next = smem0 + (unsigned)(cur ^ 1) * WA_IMG_BYTES;
+    const int4 ra_next = rec_win[2 * ktn], rb_next = rec_win[2 * ktn + 1];
+#define WA_SLOT(slot)                                                                        \
+  do {                                                                                       \
+    _Pragma("unroll") for (int pp_ = 0; pp_ < PPS; ++pp_) {                                  \
+      const int piece = wave + NQW * ((slot)*PPS + pp_);                                     \
+      wa_glds16(reinterpret_cast<const float*>(img_next + piece * 64),                       \
+                __builtin_amdgcn_readfirstlane(lds_next + (unsigned)piece * 1024u));         \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  } while (0)
+    WA_STAMP(0);
     const int ek = ra.x, ev = ra.y;
     const unsigned regw[4] = {(unsigned)ra.z, (unsigned)ra.w, (unsigned)rb.x, (unsigned)rb.y};
     lds_u32x4_cptr frag = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)cur * WA_IMG_BYTES) + lane;
-    // ---- S^T = K Q^T: 8 K16-steps x 3 products on FOUR accumulators, term-major inside a group of four steps, so
-    // that no matrix instruction waits for the result of one of the three before it (a product on the accumulator of
-    // its predecessor costs the full result latency with one wave per SIMD)
+    // ---- S^T = K Q^T: 8 K16-steps x 3 products on FOUR accumulators, term-major inside a group of four steps:
+    // consecutive matrix instructions never wait for each other's result
     f32x16 sa[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) sa[a] = (f32x16)(0.0f);
+    // fragment reads staged so that at most eight are live (lo of a group dies after its first row):
+    //   lo.hi g0 | hi.lo g0 | hi.hi g0 | lo.hi g1 | hi.lo g1 | hi.hi g1, reads of group 1 two rows ahead of their use
+    f16x8 khi[4], klo[4], khi1[4], klo1[4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      f16x8 khi[4], klo[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        khi[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 * g + a)) * 64]);
-        klo[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 * g + a) + 1) * 64]);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[4 * g + a].lo, sa[a]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(klo[a], qp[4 * g + a].hi, sa[a]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[4 * g + a].hi, sa[a]);
+    for (int a = 0; a < 4; ++a) {
+      klo[a] = __builtin_bit_cast(f16x8, frag[(2 * a + 1) * 64]);
+      khi[a] = __builtin_bit_cast(f16x8, frag[(2 * a) * 64]);
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(klo[a], qp[a].hi, sa[a]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) klo1[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 + a) + 1) * 64]);
+    WA_SLOT(0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[a].lo, sa[a]);
+    WA_SLOT(1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi[a], qp[a].hi, sa[a]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) khi1[a] = __builtin_bit_cast(f16x8, frag[(2 * (4 + a)) * 64]);
+    WA_SLOT(2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(klo1[a], qp[4 + a].hi, sa[a]);
+    WA_SLOT(3);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi1[a], qp[4 + a].lo, sa[a]);
+    WA_SLOT(4);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sa[a] = mfma16h(khi1[a], qp[4 + a].hi, sa[a]);
+    WA_SLOT(5);
     f32x16 s = (sa[0] + sa[1]) + (sa[2] + sa[3]);
 #ifdef MNERF_TIMELINE
     asm volatile("" ::"v"(s[0]));
 #endif
     WA_STAMP(1);  // scores
-    const float sscale = scale * pow2i(-(ek + eq));
-    // ---- scale, masks, online softmax (as in the f32 kernel)
+    // ---- scale, masks, online softmax in the log2 domain (log2 e folded into the score scale: one v_exp_f32 per key)
+    const float sscale = scale * l2e * pow2i(-(ek + eq));
     float tmax = -3.0e38f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = (r & 3) + 8 * (r >> 2) + 4 * hl;
-      const int li = kt * WA_KT + key;
       float sv = s[r] * sscale;
       if (shifted) {  // key (r, hl) = nibble (r & 3) + 4 hl of word r >> 2
         const int kreg = (int)((regw[r >> 2] >> (4 * (r & 3) + 16 * hl)) & 15u);
-        if (kreg != q_region) sv += -100.0f;
+        if (kreg != q_region) sv += mask_l2;
       }
-      if (li >= G.Lw) sv = -3.0e38f;
       s[r] = sv;
-      tmax = fmaxf(tmax, sv);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (ragged && kt == n_tiles - 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * WA_KT + (r & 3) + 8 * (r >> 2) + 4 * hl >= G.Lw) s[r] = -3.0e38f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+    {
+      float lo, hi;
+      wa_halves(tmax, lo, hi);
+      tmax = fmaxf(lo, hi);
+    }
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __expf(s[r] - m_new);
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
       s[r] = p;
       psum += p;
     }
-    psum += __shfl_xor(psum, 32, 64);
+    {
+      float lo, hi;
+      wa_halves(psum, lo, hi);
+      psum = lo + hi;
+    }
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #ifdef MNERF_TIMELINE
@@ -880,8 +929,10 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
       // term-major over the four output blocks: consecutive matrix instructions are independent
 #pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.lo, o[m]);
+      if (t == 0) WA_SLOT(6);
 #pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo[m], pp.hi, o[m]);
+      if (t == 0) WA_SLOT(7);
 #pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.hi, o[m]);
     }
@@ -896,6 +947,7 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     ra = ra_next;
     rb = rb_next;
   }
+#undef WA_SLOT
 #ifdef MNERF_TIMELINE
   if (tl && lane == 0 && blockIdx.x < 64)
     for (int i = 0; i < 6; ++i) tl[(blockIdx.x * NQW + wave) * 6 + i] = tph[i];
@@ -973,12 +1025,14 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
   hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
   const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
   const long long win_groups = ((long long)n_win * batch + 7) / 8;  // windows per XCD
-  if (wgs4 >= mnerf_tune().wa_min4)
-    hipLaunchKernelGGL(window_attention_pre_kernel<4>, dim3((unsigned)(8 * win_groups * ((G.Lw + 127) / 128))), dim3(256), lds,
-                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd, tl);
+  const int xcd = mnerf_tune().wa_xcd;
+  const bool four = wgs4 >= mnerf_tune().wa_min4;
+  const int n_qb = four ? (G.Lw + 127) / 128 : (G.Lw + 63) / 64;
+  const dim3 grid((unsigned)(8 * win_groups * n_qb));
+  if (four)
+    hipLaunchKernelGGL(window_attention_pre_kernel<4>, grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
   else
-    hipLaunchKernelGGL(window_attention_pre_kernel<2>, dim3((unsigned)(8 * win_groups * ((G.Lw + 63) / 64))), dim3(128), lds,
-                       st, q, img, gains, out, G, do_shift, scale, batch, mnerf_tune().wa_xcd, tl);
+    hipLaunchKernelGGL(window_attention_pre_kernel<2>, grid, dim3(128), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
   return mnerf_check_launch(who);
 }
 
