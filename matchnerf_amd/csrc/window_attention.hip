@@ -809,7 +809,6 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const int ktn = kt + 1 < n_tiles ? kt + 1 : kt;
     const u32x4* img_next = img_win + (size_t)ktn * (WA_IMG_BYTES / 16) + lane;
     const unsigned lds_next = smem0 + (unsigned)(cur ^ 1) * WA_IMG_BYTES;
-    const int4 ra_next = rec_win[2 * ktn], rb_next = rec_win[2 * ktn + 1];
 #define WA_SLOT(slot)                                                                        \
   do {                                                                                       \
     _Pragma("unroll") for (int pp_ = 0; pp_ < PPS; ++pp_) {                                  \
@@ -863,6 +862,17 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     asm volatile("" ::"v"(s[0]));
 #endif
     WA_STAMP(1);  // scores
+    // V fragments of the first key half and the next tile's record are requested here: the softmax below has no LDS
+    // or scalar-memory traffic of its own, so both latencies disappear under it (the record load at the top of the
+    // tile was waited for by the first fragment read: ~400 exposed cycles per tile)
+    f16x8 vhi[4], vlo[4], vhi1[4], vlo1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      vlo[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * m + 1) * 64]);
+      vhi[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * m) * 64]);
+    }
+    const int4 ra_next = rec_win[2 * ktn], rb_next = rec_win[2 * ktn + 1];
+    __builtin_amdgcn_sched_barrier(0);
     // ---- scale, masks, online softmax in the log2 domain (log2 e folded into the score scale: one v_exp_f32 per key)
     const float sscale = scale * l2e * pow2i(-(ek + eq));
     float tmax = -3.0e38f;
@@ -914,27 +924,36 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[m][r] *= corr;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    {
       float pv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = s[8 * t + j];
+      for (int j = 0; j < 8; ++j) pv[j] = s[j];
       const PartsH pp = split8h(pv, 16384.0f);
-      f16x8 vhi[4], vlo[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        vhi[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m)) * 64]);
-        vlo[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64]);
-      }
       // term-major over the four output blocks: consecutive matrix instructions are independent
 #pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.lo, o[m]);
-      if (t == 0) WA_SLOT(6);
-#pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo[m], pp.hi, o[m]);
-      if (t == 0) WA_SLOT(7);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) vlo1[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 + m) + 1) * 64]);
+      WA_SLOT(6);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.lo, o[m]);
+      WA_SLOT(7);
 #pragma unroll
       for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.hi, o[m]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) vhi1[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 + m)) * 64]);
+    }
+    {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = s[8 + j];
+      const PartsH pp = split8h(pv, 16384.0f);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo1[m], pp.hi, o[m]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi1[m], pp.lo, o[m]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi1[m], pp.hi, o[m]);
     }
 #ifdef MNERF_TIMELINE
     asm volatile("" ::"v"(o[3][0]));
