@@ -48,9 +48,6 @@ __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define H16_UNIT_BYTES 2048  // one (step, block): hi | lo fragments
-#ifndef MNERF_PAIR_UNITS
-#define MNERF_PAIR_UNITS 0
-#endif
 #define H16_TARGET_EXP 15    // largest operand of a sample is scaled into [2^14, 2^15)
 
 struct PartsH {
@@ -130,41 +127,6 @@ template <int NMB, int NS>
 __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const float (&v)[8 * NS],
                                          float mult) {
   lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
-#if MNERF_PAIR_UNITS
-  // experiment: two output blocks per group of six matrix instructions, interleaved, so that no instruction has the
-  // accumulator of its predecessor (same products, same order per accumulator: bit-identical results)
-  if constexpr (NMB % 2 == 0) {
-    u32x4 c0h = a[0], c0l = a[64], c1h = a[128], c1l = a[192];
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      float vv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vv[j] = v[8 * u + j];
-      const PartsH b = split8h(vv, mult);
-#pragma unroll
-      for (int m = 0; m < NMB; m += 2) {
-        const int i = u * NMB + m;
-        const int nx = (i + 2 < NS * NMB) ? (i + 2) * 128 : i * 128;
-        const u32x4 n0h = a[nx], n0l = a[nx + 64], n1h = a[nx + 128], n1l = a[nx + 192];
-        __builtin_amdgcn_sched_barrier(0);
-        const f16x8 a0h = __builtin_bit_cast(f16x8, c0h), a0l = __builtin_bit_cast(f16x8, c0l);
-        const f16x8 a1h = __builtin_bit_cast(f16x8, c1h), a1l = __builtin_bit_cast(f16x8, c1l);
-        acc[m] = mfma16h(a0h, b.lo, acc[m]);
-        acc[m + 1] = mfma16h(a1h, b.lo, acc[m + 1]);
-        acc[m] = mfma16h(a0l, b.hi, acc[m]);
-        acc[m + 1] = mfma16h(a1l, b.hi, acc[m + 1]);
-        acc[m] = mfma16h(a0h, b.hi, acc[m]);
-        acc[m + 1] = mfma16h(a1h, b.hi, acc[m + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        c0h = n0h;
-        c0l = n0l;
-        c1h = n1h;
-        c1l = n1l;
-      }
-    }
-    return;
-  }
-#endif
   u32x4 ch = a[0], cl = a[64];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
