@@ -1,7 +1,7 @@
 #!/bin/bash
 # One command that regenerates every profile-derived number of a round ON THE GPU BOX:
 #   tools/profile_round.sh r2_01
-# -> gpurun_out/<tag>/{kernel_stats.md, pmc_summary.txt, decoder_counters.json, bench.json}; copy the ones to be
+# -> gpurun_out/<tag>/{kernel_stats.md, bench_kernel_stats.md, pmc_summary.txt, decoder_counters.json}; copy the ones to be
 # judged into profiles/ (profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc_summary.txt, profiles/decoder_counters.json).
 # Kernel trace and PMC counters are collected in SEPARATE rocprofv3 runs (no sys / hip tracing with --pmc).
 TAG=${1:-r2}
@@ -10,6 +10,9 @@ O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; rm -rf /tmp/prof_$TAG /tmp/pmc_${TAG}_*
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o trace -- python $R/tools/prof_render.py 3 > $O/trace.log 2>&1
 python $R/tools/rocpd_stats.py $(find /tmp/prof_$TAG -name '*.db' | head -1) 40 --last-frame 5 > $O/kernel_stats.md 2>&1
+# the bench command itself under the kernel trace (whole run: warm-up, timed steps, the other-math and secondary legs)
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_${TAG}_bench -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_traced.log 2>&1
+python $R/tools/rocpd_stats.py $(find /tmp/prof_${TAG}_bench -name '*.db' | head -1) 25 > $O/bench_kernel_stats.md 2>&1
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
 B="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT"
 for P in a b c d; do
