@@ -340,9 +340,9 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
 #define K16_UNIT_BYTES 3072  // one (step, block): hi | mid | lo fragments
 
 // Experiment knob, OFF: streaming the conditioning rows with non-temporal stores (cost volume) and loads (here).
-// Measured on MI355X (profiles/r2_nt_*): the rows then really travel to HBM and back instead of being served from
-// L2 / Infinity Cache - 3.3 GB instead of 2.2 GB of HBM traffic per 65 536-ray launch, cost volume 9.8 -> 11.2 ms,
-// decoder unchanged.  The write-then-read pair of the staged form is served best by the default cache policy.
+// Measured on MI355X (profiles/r2_nt_*): HBM-side counters unchanged (the scratch lines it was meant to protect are
+// written back either way), cost volume 9.8 -> 11.2 ms, decoder unchanged.  The write-then-read pair of the staged
+// form is served best by the default cache policy.
 #ifndef MNERF_NT_COND
 #define MNERF_NT_COND 0
 #endif
