@@ -245,6 +245,14 @@ int mnerf_window_attention_presplit(const float* q, const float* k, const float*
                                     int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* InstanceNorm2d (no affine, biased variance, as torch.nn.functional.instance_norm) of an NCHW tensor fused with what
+ * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):
+ *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);
+ *   if residual: v += residual;                     if relu_outer: v = max(v, 0)
+ * x, residual (or NULL), out: [planes = N*C][plane_size = H*W] fp32; out may alias x.  One workgroup per plane. */
+int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes, int64_t plane_size,
+                        float eps, int32_t relu_inner, int32_t relu_outer, void* stream);
+
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
  * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):
  *   message = norm1(merge(attn));  [ffn:] message = norm2(mlp.2(GELU(mlp.0(cat[source, message]))));  out = source + message

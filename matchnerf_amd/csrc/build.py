@@ -10,17 +10,20 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "backward.hip", "composite.hip", "cost_volume.hip", "decoder.hip", "encoder_block.hip", "geometry.hip", "render_chunk.hip",
-           "window_attention.hip"]
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "cost_volume.hip", "decoder.hip", "encoder_block.hip", "geometry.hip",
+           "instance_norm.hip", "render_chunk.hip", "window_attention.hip"]
+DECODER_SOURCES = ["decoder.hip", "split_f16.hpp", "cv_walk.hpp", "common.hpp"]  # what decoder_kernel is compiled from
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def source_hash():
-    """sha256 over the kernel sources and the ABI header: identifies the build that profile-derived numbers
-    (profiles/decoder_counters.json) belong to, so that bench.py can tell when they have gone stale."""
+    """sha256 over everything the decoder kernel is compiled from (its sources, the ABI header, the compiler flags):
+    identifies the build that profile-derived numbers (profiles/decoder_counters.json) belong to, so that bench.py can
+    tell when they have gone stale.  (Other kernels' sources are left out: a change in the encoder does not change the
+    decoder's counters.)"""
     import hashlib
-    h = hashlib.sha256()
-    for name in sorted(SOURCES + ["common.hpp", "cv_walk.hpp", "split_f16.hpp"]):
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in sorted(DECODER_SOURCES):
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     with open(os.path.join(PKG, "..", "include", "mnerf.h"), "rb") as f:

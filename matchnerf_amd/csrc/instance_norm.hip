@@ -1,0 +1,130 @@
+// InstanceNorm2d (no affine, biased variance) + the activations / residual add that follow it in the GMFlow CNN
+// backbone, one kernel per use (gfx950).
+//
+// Replaces (paths relative to /root/reference/models/gmflow/backbone.py):
+//   backbone.py:27-35   ResidualBlock.forward: relu(norm1(conv1 x)), relu(norm2(conv2 y)), norm3(downsample x),
+//                       relu(x + y)
+//   backbone.py:101-103 CNNEncoder.forward: relu(norm1(conv1 x))
+// torch runs each InstanceNorm as three kernels (batch-norm statistics, inverse std, transform) followed by a clamp
+// and, at the end of a block, an add and another clamp: five to seven passes over the activation.  Here a workgroup
+// owns one (image, channel) plane of the NCHW tensor, keeps it in REGISTERS (up to 80 floats per lane at 1 024 lanes:
+// the 256x320 plane of the first stage), takes mean and centred variance from the registers (two workgroup
+// reductions) and writes the finished value once: one read, one write - the kernel is HBM/L2-bound by construction.
+// Planes that do not fit (or whose size is not a multiple of four) take a three-pass streaming kernel.
+#include "common.hpp"
+
+template <int THREADS>
+__device__ __forceinline__ float in_block_sum(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // red may still be read by the previous reduction
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+#pragma unroll
+  for (int i = 0; i < THREADS / 64; ++i) t += red[i];
+  return t;
+}
+
+__device__ __forceinline__ float in_finish(float x, float mean, float rstd, float res, bool has_res, int relu_inner,
+                                           int relu_outer) {
+  float v = (x - mean) * rstd;
+  if (relu_inner) v = fmaxf(v, 0.0f);
+  if (has_res) v += res;
+  if (relu_outer) v = fmaxf(v, 0.0f);
+  return v;
+}
+
+template <int THREADS, int VPT>
+__global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ residual,
+                                                                       float* __restrict__ out, int plane_size, float eps,
+                                                                       int relu_inner, int relu_outer) {
+  __shared__ float red[THREADS / 64];
+  const size_t base = (size_t)blockIdx.x * plane_size;
+  const float4* src = reinterpret_cast<const float4*>(x + base);
+  const int n4 = plane_size >> 2;
+  float4 v[VPT];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int j = i * THREADS + threadIdx.x;
+    v[i] = j < n4 ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float inv_n = 1.0f / (float)plane_size;
+  const float mean = in_block_sum<THREADS>(s, red) * inv_n;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int j = i * THREADS + threadIdx.x;
+    if (j < n4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float var = in_block_sum<THREADS>(q, red) * inv_n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float4* res = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
+  float4* dst = reinterpret_cast<float4*>(out + base);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int j = i * THREADS + threadIdx.x;
+    if (j < n4) {
+      const float4 r = res ? res[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 o;
+      o.x = in_finish(v[i].x, mean, rstd, r.x, res != nullptr, relu_inner, relu_outer);
+      o.y = in_finish(v[i].y, mean, rstd, r.y, res != nullptr, relu_inner, relu_outer);
+      o.z = in_finish(v[i].z, mean, rstd, r.z, res != nullptr, relu_inner, relu_outer);
+      o.w = in_finish(v[i].w, mean, rstd, r.w, res != nullptr, relu_inner, relu_outer);
+      dst[j] = o;
+    }
+  }
+}
+
+// any plane size: three passes (the plane of a running workgroup stays in L2 / Infinity Cache between them)
+__global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ residual,
+                                                                   float* __restrict__ out, int plane_size, float eps,
+                                                                   int relu_inner, int relu_outer) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * plane_size;
+  const float* src = x + base;
+  float s = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 256) s += src[j];
+  const float inv_n = 1.0f / (float)plane_size;
+  const float mean = in_block_sum<256>(s, red) * inv_n;
+  float q = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 256) {
+    const float a = src[j] - mean;
+    q += a * a;
+  }
+  const float rstd = 1.0f / sqrtf(in_block_sum<256>(q, red) * inv_n + eps);
+  for (int j = threadIdx.x; j < plane_size; j += 256)
+    out[base + j] = in_finish(src[j], mean, rstd, residual ? residual[base + j] : 0.0f, residual != nullptr, relu_inner,
+                              relu_outer);
+}
+
+extern "C" int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes,
+                                   int64_t plane_size, float eps, int32_t relu_inner, int32_t relu_outer, void* stream) {
+  MNERF_REQUIRE(x && out, MNERF_E_NULL, "mnerf_instance_norm: NULL buffer");
+  MNERF_REQUIRE(planes >= 0 && planes <= 0x7fffffffLL && plane_size >= 1 && plane_size <= 0x7fffffffLL, MNERF_E_RANGE,
+                "mnerf_instance_norm: planes=%lld plane_size=%lld", (long long)planes, (long long)plane_size);
+  MNERF_REQUIRE(eps >= 0.0f, MNERF_E_RANGE, "mnerf_instance_norm: eps=%g", (double)eps);
+  if (planes == 0) return MNERF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = (int)plane_size;
+  const bool vec = (n & 3) == 0 && mnerf_aligned16(x) && mnerf_aligned16(out) && (!residual || mnerf_aligned16(residual));
+  const dim3 grid((unsigned)planes);
+#define IN_LAUNCH(T, V)                                                                                              \
+  hipLaunchKernelGGL((instance_norm_cached_kernel<T, V>), grid, dim3(T), 0, st, x, residual, out, n, eps, relu_inner, \
+                     relu_outer)
+  if (vec && n <= 256 * 8 * 4) IN_LAUNCH(256, 8);
+  else if (vec && n <= 256 * 20 * 4) IN_LAUNCH(256, 20);
+  else if (vec && n <= 1024 * 20 * 4) IN_LAUNCH(1024, 20);
+  else
+    hipLaunchKernelGGL(instance_norm_stream_kernel, grid, dim3(256), 0, st, x, residual, out, n, eps, relu_inner, relu_outer);
+#undef IN_LAUNCH
+  return mnerf_check_launch("mnerf_instance_norm");
+}

@@ -30,6 +30,16 @@ from .autograd import window_attention
 from .camera import pair_list
 
 
+def _fused_norm(x):
+    """the fused InstanceNorm kernel serves inference on the GPU; under autograd the torch op chain is kept"""
+    return x.is_cuda and not torch.is_grad_enabled()
+
+
+def _conv_out(conv, x):
+    """convolution result as a plain NCHW-contiguous fp32 tensor (what ``mnerf_instance_norm`` reads plane by plane)"""
+    return conv(x).contiguous()
+
+
 class ResidualBlock(nn.Module):
     """backbone.py:6-36 (InstanceNorm2d without affine => no parameters for the norms)."""
 
@@ -46,6 +56,14 @@ class ResidualBlock(nn.Module):
             self.downsample = None
 
     def forward(self, x):
+        if _fused_norm(x):  # inference: every norm + activation (+ residual add) is one HIP kernel, in place
+            y = _conv_out(self.conv1, x)
+            hip.instance_norm(y, relu_inner=True, out=y)
+            y = _conv_out(self.conv2, y)
+            if self.downsample is not None:
+                x = _conv_out(self.downsample[0], x)
+                hip.instance_norm(x, out=x)
+            return hip.instance_norm(y, residual=x.contiguous(), relu_inner=True, relu_outer=True, out=y)
         y = F.relu(F.instance_norm(self.conv1(x)))
         y = F.relu(F.instance_norm(self.conv2(y)))
         if self.downsample is not None:
@@ -68,7 +86,11 @@ class CNNEncoder(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = F.relu(F.instance_norm(self.conv1(x)))
+        if _fused_norm(x):
+            x = _conv_out(self.conv1, x)
+            hip.instance_norm(x, relu_inner=True, out=x)
+        else:
+            x = F.relu(F.instance_norm(self.conv1(x)))
         x = self.layer3(self.layer2(self.layer1(x)))
         return self.conv2(x)
 

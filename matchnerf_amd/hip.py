@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_instance_norm", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -126,6 +126,8 @@ def load():
     lib.mnerf_window_attention_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.mnerf_window_attention_presplit.restype = C.c_int
     lib.mnerf_window_attention_presplit.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
+    lib.mnerf_instance_norm.restype = C.c_int
+    lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, vp]
     lib.mnerf_encoder_block_wstream_floats.restype = i64
     lib.mnerf_encoder_block_wstream_floats.argtypes = [i32]
     lib.mnerf_encoder_block.restype = C.c_int
@@ -443,6 +445,27 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
         else:
             check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                              int(bool(shifted)), math, st), "mnerf_window_attention")
+    return out
+
+
+def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, stream=None):
+    """F.instance_norm(x) of an NCHW tensor fused with the ReLU / residual add / ReLU that follow it in the GMFlow
+    backbone (backbone.py:27-35): out = [relu](residual + [relu](IN(x)))."""
+    import torch
+    lib = load()
+    _f32c(x, "x")
+    if x.dim() != 4:
+        raise MnerfError(f"instance_norm: expected [N,C,H,W], got {tuple(x.shape)}")
+    if residual is not None:
+        _f32c(residual, "residual")
+        if residual.shape != x.shape:
+            raise MnerfError(f"instance_norm: residual {tuple(residual.shape)} vs x {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty_like(x)
+    n, c, h, w = x.shape
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_instance_norm(_ptr(x), _ptr(residual), _ptr(out), n * c, h * w, float(eps), int(bool(relu_inner)),
+                                      int(bool(relu_outer)), st), "mnerf_instance_norm")
     return out
 
 
