@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* 
 
 extern "C" int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes,
                                    int64_t plane_size, float eps, int32_t relu_inner, int32_t relu_outer, void* stream) {
-  MNERF_REQUIRE(x && out, MNERF_E_NULL, "mnerf_instance_norm: NULL buffer");
   MNERF_REQUIRE(planes >= 0 && planes <= 0x7fffffffLL && plane_size >= 1 && plane_size <= 0x7fffffffLL, MNERF_E_RANGE,
                 "mnerf_instance_norm: planes=%lld plane_size=%lld", (long long)planes, (long long)plane_size);
   MNERF_REQUIRE(eps >= 0.0f, MNERF_E_RANGE, "mnerf_instance_norm: eps=%g", (double)eps);
   if (planes == 0) return MNERF_OK;
+  MNERF_REQUIRE(x && out, MNERF_E_NULL, "mnerf_instance_norm: NULL buffer");
   hipStream_t st = (hipStream_t)stream;
   const int n = (int)plane_size;
   const bool vec = (n & 3) == 0 && mnerf_aligned16(x) && mnerf_aligned16(out) && (!residual || mnerf_aligned16(residual));
