@@ -130,7 +130,7 @@ typedef struct mnerf_decoder {
 
 int mnerf_abi_version(void);
 const char* mnerf_last_error(void);
-/* sizeof() of the argument structs as compiled (0 view, 1 rays, 2 scene, 3 decoder; -1 else):
+/* sizeof() of the argument structs as compiled (0 view, 1 rays, 2 scene, 3 decoder, 4 encoder_layer, 5 conv; -1 else):
  * lets a foreign-language binding verify its struct mirrors before the first call. */
 int64_t mnerf_struct_size(int32_t which);
 
@@ -249,9 +249,38 @@ int mnerf_window_attention_presplit(const float* q, const float* k, const float*
  * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):
  *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);
  *   if residual: v += residual;                     if relu_outer: v = max(v, 0)
- * x, residual (or NULL), out: [planes = N*C][plane_size = H*W] fp32; out may alias x.  One workgroup per plane. */
+ * x, residual (or NULL), out: [planes = N*C][plane_size = H*W] fp32; out may alias x.  One workgroup per plane.
+ * out_absmax: device scalar or NULL; max |out| is merged into it with an atomic maximum (the operand scale of the
+ * convolution that reads `out`, see mnerf_conv2d). */
 int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes, int64_t plane_size,
-                        float eps, int32_t relu_inner, int32_t relu_outer, void* stream);
+                        float eps, int32_t relu_inner, int32_t relu_outer, float* out_absmax, void* stream);
+
+/* Convolutions of the GMFlow backbone / up-sampler (models/gmflow/backbone.py:6-122, superres.py:5-38) as implicit
+ * GEMMs with fp32-grade split-fp16 products (matchnerf_amd/csrc/conv.hip).  Built: c_in a multiple of 32, c_out 64 /
+ * 96 / 128, 1x1 and 3x3 filters with padding ksize/2, stride 1 / 2.
+ *   wstream     : A-operand fragments of 2^ew * W, K16-step s = (tap, 16 input channels), unit (s, 32-row block) =
+ *                 [hi | lo] x 64 lanes x 8 fp16 (matchnerf_amd/gmflow.py: pack_conv); mnerf_conv_wstream_floats() words
+ *   bias        : [c_out] or NULL;  leaky_slope: LeakyReLU slope applied to the result (1 = none)
+ * mnerf_conv2d: in [n_img, c_in, h_in, w_in] (or [n_img, h_in, w_in, c_in] with in_channels_last), optionally read
+ * through a nearest 2x up-sampling (upsample2x); out [n_img, c_out, h_out, w_out] NCHW.
+ *   in_absmax   : device scalar >= max |in| (operands are scaled by ONE power of two taken from it; a value that is
+ *                 too small overflows fp16) - written by the producer of `in`: mnerf_instance_norm, mnerf_conv2d
+ *                 (out_absmax) or mnerf_absmax
+ *   out_absmax  : device scalar or NULL; max |out| is merged into it with an atomic maximum (zero it first). */
+typedef struct mnerf_conv {
+  const float* wstream;
+  int64_t wstream_floats;
+  const float* bias;
+  int32_t c_in, c_out, ksize, stride;
+  int32_t ew;
+  float leaky_slope;
+} mnerf_conv;
+int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize);
+int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
+                 const float* in_absmax, float* out, float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in,
+                 void* stream);
+/* max |x| of n floats merged into the device scalar `out` (atomic maximum; zero it first) */
+int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
  * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):

@@ -25,6 +25,8 @@ extern "C" int64_t mnerf_struct_size(int32_t which) {
     case 1: return (int64_t)sizeof(mnerf_rays);
     case 2: return (int64_t)sizeof(mnerf_scene);
     case 3: return (int64_t)sizeof(mnerf_decoder);
+    case 4: return (int64_t)sizeof(mnerf_encoder_layer);
+    case 5: return (int64_t)sizeof(mnerf_conv);
     default: return -1;
   }
 }

@@ -1,0 +1,291 @@
+// Convolutions of the GMFlow CNN backbone and feature up-sampler as implicit GEMMs on the matrix cores (gfx950).
+//
+// Replaces the library convolutions behind (paths relative to /root/reference/models/gmflow):
+//   backbone.py:6-36, 39-122   ResidualBlock / CNNEncoder: 3x3 (stride 1 / 2) and 1x1 (stride 1 / 2) convolutions,
+//                              64 / 96 / 128 channels (the 7x7 stem on 3 channels stays a library call)
+//   superres.py:5-38           the up-sampler's 3x3 convolutions, incl. the one that follows a nearest 2x up-sampling
+//                              (read through the up-sampling here: the 4x larger tensor is never written) and its
+//                              LeakyReLU(0.2)
+// MIOpen runs these in fp32 on v_mfma_f32_32x32x2_f32 at ~100 TFLOP/s (65 % of that instruction's peak).  Here the
+// products are fp32-grade split-fp16 (split_f16.hpp: two fp16 terms per operand, three products per MAC on
+// v_mfma_f32_32x32x16_f16 - the arithmetic of the decoder and of the encoder block kernel).
+//
+// Formulation: Y^T[out channel, pixel] = W[out, (tap, in channel)] . X^T[(tap, in channel), pixel] - the transposed
+// chain again: a wave owns 2 x 32 output pixels (lane & 31 = pixel, consecutive along the row: coalesced NCHW
+// accesses), accumulators hold all output channels of its pixels.  One K16-step = 16 input channels of one filter tap;
+// lane (pixel, half) loads its 8 channels of that tap straight from global memory (predicated: zero padding),
+// one step ahead of their use, and splits them with ONE power-of-two gain per input TENSOR - its largest magnitude,
+// left in a device scalar by the kernel that produced it (mnerf_instance_norm, this kernel, mnerf_absmax); the IN
+// output of a plane is bounded by sqrt(plane size), so the typical value keeps >= 21 significant bits.
+// Weights: packed by the host as A-operand fragments (matchnerf_amd/gmflow.py, pack_conv), streamed in segments of
+// whole K16-step pairs (<= 36 KiB) through a 2 x 36 KiB LDS double buffer by LDS-DMA, one barrier per segment, two
+// workgroups of four waves per CU.
+#include "split_f16.hpp"
+
+#define CONV_NW 4
+#define CONV_TPW 2             // 32-pixel tiles per wave
+#define CONV_BUF_BYTES 36864u  // one LDS weight buffer (36 KiB: six K16-steps x three 32-row blocks)
+
+struct ConvParams {
+  const float* in;
+  const float* wstream;
+  const float* bias;
+  float* out;
+  const float* in_absmax;
+  float* out_absmax;
+  int n_img, c_in, h_in, w_in, h_out, w_out;
+  int ksize, stride, up;      // up = 1: the input is read through a nearest 2x up-sampling
+  long long sc, sy, sx, si;   // element strides of the stored input: channel, row, column, image
+  int ew, seg_steps, n_seg;
+  float leaky;                // LeakyReLU slope applied to the result (1 = none)
+};
+
+template <int NMB>
+__global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
+  extern __shared__ __attribute__((aligned(16))) float conv_smem[];
+  const unsigned buf0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)conv_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  const int seg_units = P.seg_steps * NMB;
+  const int pieces = seg_units * 2;  // 1 KiB each
+
+  auto stage = [&](int seg) {
+    const float* src = P.wstream + (size_t)seg * (size_t)seg_units * 512 + lane * 4;
+    const unsigned dst = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
+    for (int p = wave; p < pieces; p += CONV_NW)
+      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+  };
+  stage(0);
+
+  // ---- this lane's output pixels
+  const int hw_out = P.h_out * P.w_out;
+  const long long n_pix = (long long)P.n_img * hw_out;
+  int oy[CONV_TPW], ox[CONV_TPW];
+  long long ibase[CONV_TPW], obase[CONV_TPW];
+  bool live[CONV_TPW];
+#pragma unroll
+  for (int t = 0; t < CONV_TPW; ++t) {
+    const long long p = ((long long)blockIdx.x * CONV_NW + wave) * (32 * CONV_TPW) + t * 32 + n;
+    live[t] = p < n_pix;
+    const long long pc = live[t] ? p : n_pix - 1;
+    const int img = (int)(pc / hw_out), rem = (int)(pc - (long long)img * hw_out);
+    oy[t] = rem / P.w_out;
+    ox[t] = rem - oy[t] * P.w_out;
+    ibase[t] = (long long)img * P.si + (long long)(8 * hl) * P.sc;
+    obase[t] = (long long)img * (32 * NMB) * hw_out + rem;
+  }
+  const int pad = P.ksize >> 1;
+  const int h_eff = P.h_in << P.up, w_eff = P.w_in << P.up;
+  const int csteps = P.c_in >> 4, n_steps = P.ksize * P.ksize * csteps;
+
+  const float amax = P.in_absmax ? *P.in_absmax : 1.0f;
+  const int eg = gain_exp(amax);
+  const float mult = pow2i(eg);
+
+  // ---- operand pipeline: an iteration covers TWO K16-steps (32 input channels of one tap); the values of iteration
+  // i+1 are requested before the 12..24 x 2 matrix instructions of iteration i, so an L2 round trip fits under them.
+  // Loads are unconditional from a clamped address and zeroed by a select (padding): no branches in the loop.
+  int tap = 0, cpair = 0;
+  long long toff[CONV_TPW];
+  bool tok[CONV_TPW];
+  auto tap_geometry = [&]() {
+    const int dy = tap / P.ksize - pad, dx = tap % P.ksize - pad;
+#pragma unroll
+    for (int t = 0; t < CONV_TPW; ++t) {
+      const int yy = oy[t] * P.stride + dy, xx = ox[t] * P.stride + dx;
+      tok[t] = live[t] && yy >= 0 && yy < h_eff && xx >= 0 && xx < w_eff;
+      const int yc = min(max(yy, 0), h_eff - 1), xc = min(max(xx, 0), w_eff - 1);
+      toff[t] = ibase[t] + (long long)(yc >> P.up) * P.sy + (long long)(xc >> P.up) * P.sx;
+    }
+  };
+  const int cpairs = P.c_in >> 5, n_iter = n_steps >> 1;
+  float vn[CONV_TPW][16];  // [tile][K16-step of the pair * 8 + j], as loaded: the padding mask is applied at the USE
+  bool vok[CONV_TPW];      // (a select next to the load would make the wave wait for the data one iteration early)
+  auto load_pair = [&]() {
+#pragma unroll
+    for (int t = 0; t < CONV_TPW; ++t) {
+      const float* src = P.in + toff[t] + (long long)(32 * cpair) * P.sc;
+      vok[t] = tok[t];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vn[t][8 * u + j] = src[(long long)(16 * u + j) * P.sc];
+    }
+    if (++cpair == cpairs) {
+      cpair = 0;
+      if (++tap < P.ksize * P.ksize) tap_geometry();
+    }
+  };
+  tap_geometry();
+  load_pair();
+
+  f32x16 acc[CONV_TPW][NMB];
+#pragma unroll
+  for (int t = 0; t < CONV_TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) acc[t][m] = (f32x16)(0.0f);
+
+  segment_wait();
+  __syncthreads();
+
+  int iter = 0;
+  const int seg_iters = P.seg_steps >> 1;
+  for (int seg = 0; seg < P.n_seg; ++seg) {
+    if (seg + 1 < P.n_seg) stage(seg + 1);
+    const unsigned cur = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
+    for (int it = 0; it < seg_iters; ++it, ++iter) {
+      PartsH b[2][CONV_TPW];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < CONV_TPW; ++t) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = vok[t] ? vn[t][8 * u + j] : 0.0f;
+          b[u][t] = split8h(v8, mult);
+        }
+      if (iter + 1 < n_iter) load_pair();
+      lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)(cur + (unsigned)(2 * it * NMB) * H16_UNIT_BYTES) + lane;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int m = 0; m < NMB; ++m) {
+          const int unit = u * NMB + m;
+          const f16x8 ah = __builtin_bit_cast(f16x8, a[unit * 128]), al = __builtin_bit_cast(f16x8, a[unit * 128 + 64]);
+          // the two pixel tiles alternate: no matrix instruction has the accumulator of its predecessor
+#pragma unroll
+          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].lo, acc[t][m]);
+#pragma unroll
+          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(al, b[u][t].hi, acc[t][m]);
+#pragma unroll
+          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].hi, acc[t][m]);
+        }
+    }
+    segment_wait();   // this wave's pieces of the next segment (and its operand prefetch) have landed
+    __syncthreads();  // ... everybody's; the current buffer is free
+  }
+
+  // ---- epilogue: scale back, bias, LeakyReLU, largest magnitude, NCHW store (32 consecutive pixels per register)
+  const float cm = pow2i(-(P.ew + eg));
+  float* bias_lds = conv_smem;  // the weight buffers are free now
+  for (int i = tid; i < 32 * NMB; i += CONV_NW * 64) bias_lds[i] = P.bias ? P.bias[i] : 0.0f;
+  __syncthreads();
+  float omax = 0.0f;
+#pragma unroll
+  for (int t = 0; t < CONV_TPW; ++t) {
+    if (!live[t]) continue;
+#pragma unroll
+    for (int m = 0; m < NMB; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + 32 * m + 8 * g + 4 * hl);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[t][m][4 * g + q] * cm + bb[q];
+          v = v < 0.0f ? v * P.leaky : v;
+          omax = fmaxf(omax, fabsf(v));
+          P.out[obase[t] + (long long)(32 * m + 8 * g + 4 * hl + q) * hw_out] = v;
+        }
+      }
+  }
+  if (P.out_absmax) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+    if (lane == 0) atomicMax(reinterpret_cast<int*>(P.out_absmax), __float_as_int(omax));  // non-negative floats order as ints
+  }
+}
+
+// largest |x| of a tensor into a device scalar (atomic maximum: the caller zeroes it)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  float m = 0.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+}
+
+extern "C" int mnerf_absmax(const float* x, int64_t n, float* out, void* stream) {
+  MNERF_REQUIRE(n >= 0, MNERF_E_RANGE, "mnerf_absmax: n=%lld", (long long)n);
+  MNERF_REQUIRE(out, MNERF_E_NULL, "mnerf_absmax: out is NULL");
+  if (n == 0) return MNERF_OK;
+  MNERF_REQUIRE(x, MNERF_E_NULL, "mnerf_absmax: x is NULL");
+  const long long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)n, out);
+  return mnerf_check_launch("mnerf_absmax");
+}
+
+static int conv_seg_steps(int n_steps, int nmb) {  // largest even divisor of n_steps whose units fit one LDS buffer
+  int best = 2;
+  for (int s = 2; s <= n_steps; s += 2)
+    if (n_steps % s == 0 && s * nmb * H16_UNIT_BYTES <= (int)CONV_BUF_BYTES) best = s;
+  return best;
+}
+
+extern "C" int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize) {
+  if (c_in < 32 || c_in % 32 || c_out < 32 || c_out % 32 || ksize < 1) return 0;
+  return (int64_t)ksize * ksize * (c_in / 16) * (c_out / 32) * (H16_UNIT_BYTES / 4);
+}
+
+extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
+                            const float* in_absmax, float* out, float* out_absmax, int32_t n_img, int32_t h_in,
+                            int32_t w_in, void* stream) {
+  const char* who = "mnerf_conv2d";
+  MNERF_REQUIRE(cv, MNERF_E_NULL, "%s: cv is NULL", who);
+  MNERF_REQUIRE(cv->c_in >= 32 && cv->c_in % 32 == 0 && (cv->c_out == 64 || cv->c_out == 96 || cv->c_out == 128) &&
+                    (cv->ksize == 1 || cv->ksize == 3) && (cv->stride == 1 || cv->stride == 2),
+                MNERF_E_UNSUPPORTED, "%s: c_in=%d c_out=%d ksize=%d stride=%d (built: c_in %% 32 == 0, c_out 64/96/128, 1x1 / 3x3, stride 1 / 2)",
+                who, cv->c_in, cv->c_out, cv->ksize, cv->stride);
+  MNERF_REQUIRE(n_img >= 0 && h_in >= 1 && w_in >= 1, MNERF_E_RANGE, "%s: n_img=%d h_in=%d w_in=%d", who, n_img, h_in, w_in);
+  MNERF_REQUIRE(cv->leaky_slope >= 0.0f, MNERF_E_RANGE, "%s: leaky_slope=%g", who, (double)cv->leaky_slope);
+  if (n_img == 0) return MNERF_OK;
+  MNERF_REQUIRE(cv->wstream && in && out && in_absmax, MNERF_E_NULL, "%s: NULL buffer", who);
+  MNERF_REQUIRE(mnerf_aligned16(cv->wstream), MNERF_E_ALIGN, "%s: wstream must be 16-byte aligned", who);
+  MNERF_REQUIRE(cv->wstream_floats == mnerf_conv_wstream_floats(cv->c_in, cv->c_out, cv->ksize), MNERF_E_RANGE,
+                "%s: wstream has %lld floats, expected %lld", who, (long long)cv->wstream_floats,
+                (long long)mnerf_conv_wstream_floats(cv->c_in, cv->c_out, cv->ksize));
+  const int up = upsample2x ? 1 : 0, pad = cv->ksize / 2;
+  ConvParams p;
+  p.in = in;
+  p.wstream = cv->wstream;
+  p.bias = cv->bias;
+  p.out = out;
+  p.in_absmax = in_absmax;
+  p.out_absmax = out_absmax;
+  p.n_img = n_img;
+  p.c_in = cv->c_in;
+  p.h_in = h_in;
+  p.w_in = w_in;
+  p.h_out = ((h_in << up) + 2 * pad - cv->ksize) / cv->stride + 1;
+  p.w_out = ((w_in << up) + 2 * pad - cv->ksize) / cv->stride + 1;
+  p.ksize = cv->ksize;
+  p.stride = cv->stride;
+  p.up = up;
+  if (in_channels_last) {
+    p.sc = 1; p.sx = cv->c_in; p.sy = (long long)w_in * cv->c_in; p.si = (long long)h_in * w_in * cv->c_in;
+  } else {
+    p.sx = 1; p.sy = w_in; p.sc = (long long)h_in * w_in; p.si = (long long)h_in * w_in * cv->c_in;
+  }
+  p.ew = cv->ew;
+  const int nmb = cv->c_out / 32, n_steps = cv->ksize * cv->ksize * (cv->c_in / 16);
+  p.seg_steps = conv_seg_steps(n_steps, nmb);
+  p.n_seg = n_steps / p.seg_steps;
+  p.leaky = cv->leaky_slope;
+  const long long n_pix = (long long)n_img * p.h_out * p.w_out;
+  const long long per_wg = 32 * CONV_TPW * CONV_NW;
+  const dim3 grid((unsigned)((n_pix + per_wg - 1) / per_wg));
+  const size_t lds = 2 * CONV_BUF_BYTES;
+  hipStream_t st = (hipStream_t)stream;
+  static std::atomic<unsigned long long> attr{0};
+  if (mnerf_once_per_device(attr)) {
+    (void)hipFuncSetAttribute((const void*)conv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (nmb == 2) hipLaunchKernelGGL(conv_kernel<2>, grid, dim3(CONV_NW * 64), lds, st, p);
+  else if (nmb == 3) hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(CONV_NW * 64), lds, st, p);
+  else hipLaunchKernelGGL(conv_kernel<4>, grid, dim3(CONV_NW * 64), lds, st, p);
+  return mnerf_check_launch(who);
+}

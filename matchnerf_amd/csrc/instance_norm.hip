@@ -36,11 +36,21 @@ __device__ __forceinline__ float in_finish(float x, float mean, float rstd, floa
   return v;
 }
 
+// largest |out| of the tensor, merged into a device scalar (non-negative floats order as integers): the operand scale of
+// the split-fp16 convolution that reads the result (conv.hip)
+__device__ __forceinline__ void in_merge_absmax(float m, float* out_absmax) {
+  if (!out_absmax) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out_absmax), __float_as_int(m));
+}
+
 template <int THREADS, int VPT>
 __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ residual,
                                                                        float* __restrict__ out, int plane_size, float eps,
-                                                                       int relu_inner, int relu_outer) {
+                                                                       int relu_inner, int relu_outer,
+                                                                       float* __restrict__ out_absmax) {
   __shared__ float red[THREADS / 64];
   const size_t base = (size_t)blockIdx.x * plane_size;
   const float4* src = reinterpret_cast<const float4*>(x + base);
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
   const float rstd = 1.0f / sqrtf(var + eps);
   const float4* res = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
   float4* dst = reinterpret_cast<float4*>(out + base);
+  float omax = 0.0f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int j = i * THREADS + threadIdx.x;
@@ -79,15 +90,18 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
       o.z = in_finish(v[i].z, mean, rstd, r.z, res != nullptr, relu_inner, relu_outer);
       o.w = in_finish(v[i].w, mean, rstd, r.w, res != nullptr, relu_inner, relu_outer);
       dst[j] = o;
+      omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
+  in_merge_absmax(omax, out_absmax);
 }
 
 // any plane size: three passes (the plane of a running workgroup stays in L2 / Infinity Cache between them)
 __global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ residual,
                                                                    float* __restrict__ out, int plane_size, float eps,
-                                                                   int relu_inner, int relu_outer) {
+                                                                   int relu_inner, int relu_outer,
+                                                                   float* __restrict__ out_absmax) {
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.x * plane_size;
   const float* src = x + base;
@@ -101,13 +115,19 @@ __global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* 
     q += a * a;
   }
   const float rstd = 1.0f / sqrtf(in_block_sum<256>(q, red) * inv_n + eps);
-  for (int j = threadIdx.x; j < plane_size; j += 256)
-    out[base + j] = in_finish(src[j], mean, rstd, residual ? residual[base + j] : 0.0f, residual != nullptr, relu_inner,
+  float omax = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 256) {
+    const float o = in_finish(src[j], mean, rstd, residual ? residual[base + j] : 0.0f, residual != nullptr, relu_inner,
                               relu_outer);
+    out[base + j] = o;
+    omax = fmaxf(omax, fabsf(o));
+  }
+  in_merge_absmax(omax, out_absmax);
 }
 
 extern "C" int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes,
-                                   int64_t plane_size, float eps, int32_t relu_inner, int32_t relu_outer, void* stream) {
+                                   int64_t plane_size, float eps, int32_t relu_inner, int32_t relu_outer,
+                                   float* out_absmax, void* stream) {
   MNERF_REQUIRE(planes >= 0 && planes <= 0x7fffffffLL && plane_size >= 1 && plane_size <= 0x7fffffffLL, MNERF_E_RANGE,
                 "mnerf_instance_norm: planes=%lld plane_size=%lld", (long long)planes, (long long)plane_size);
   MNERF_REQUIRE(eps >= 0.0f, MNERF_E_RANGE, "mnerf_instance_norm: eps=%g", (double)eps);
@@ -119,12 +139,13 @@ extern "C" int mnerf_instance_norm(const float* x, const float* residual, float*
   const dim3 grid((unsigned)planes);
 #define IN_LAUNCH(T, V)                                                                                              \
   hipLaunchKernelGGL((instance_norm_cached_kernel<T, V>), grid, dim3(T), 0, st, x, residual, out, n, eps, relu_inner, \
-                     relu_outer)
+                     relu_outer, out_absmax)
   if (vec && n <= 256 * 8 * 4) IN_LAUNCH(256, 8);
   else if (vec && n <= 256 * 20 * 4) IN_LAUNCH(256, 20);
   else if (vec && n <= 1024 * 20 * 4) IN_LAUNCH(1024, 20);
   else
-    hipLaunchKernelGGL(instance_norm_stream_kernel, grid, dim3(256), 0, st, x, residual, out, n, eps, relu_inner, relu_outer);
+    hipLaunchKernelGGL(instance_norm_stream_kernel, grid, dim3(256), 0, st, x, residual, out, n, eps, relu_inner, relu_outer,
+                       out_absmax);
 #undef IN_LAUNCH
   return mnerf_check_launch("mnerf_instance_norm");
 }

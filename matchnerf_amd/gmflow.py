@@ -36,8 +36,38 @@ def _fused_norm(x):
 
 
 def _conv_out(conv, x):
-    """convolution result as a plain NCHW-contiguous fp32 tensor (what ``mnerf_instance_norm`` reads plane by plane)"""
+    """library convolution result as a plain NCHW-contiguous fp32 tensor (what ``mnerf_instance_norm`` reads plane by plane)"""
     return conv(x).contiguous()
+
+
+def pack_conv(weight):
+    """Conv2d weight [c_out, c_in, k, k] -> (wstream float32 words, ew) for ``mnerf_conv2d`` (csrc/conv.hip): the
+    implicit-GEMM matrix W[out, tap * c_in + c] (tap = ky * k + kx) as split-fp16 A-operand fragments, K16-step s =
+    16 consecutive columns, unit (s, 32-row block) = [hi | lo] x 64 lanes x 8 (the decoder's unit layout,
+    cond_nerf._fragments_h)."""
+    import numpy as np
+    from . import cond_nerf as CN
+    w = (weight.detach().cpu().numpy() if torch.is_tensor(weight) else np.asarray(weight)).astype(np.float32)
+    c_out, c_in, kh, kw = w.shape
+    assert kh == kw and c_in % 32 == 0 and c_out % 32 == 0, w.shape
+    mat = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(c_out, kh * kw * c_in))
+    ew = CN.f16_weight_exponent(mat)
+    cols = np.arange(mat.shape[1]).reshape(-1, 2, 8)
+    halfs = CN._fragments_h(mat, cols, c_out // 32, ew)            # [steps, blocks, 2, 64, 8] fp16
+    return halfs.reshape(-1).view(np.float32).copy(), int(ew)
+
+
+def _hip_conv(conv, x, in_absmax, **kw):
+    """``conv`` (nn.Conv2d with a shape conv.hip builds) through ``mnerf_conv2d``; the packed weights are cached on the
+    module and re-packed when the parameter changed."""
+    ps = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+    key = (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(x.device))
+    if getattr(conv, "_mnerf_pack", None) is None or conv._mnerf_pack[0] != key:
+        ws, ew = pack_conv(conv.weight)
+        bias = conv.bias.detach().float().contiguous().to(x.device) if conv.bias is not None else None
+        conv._mnerf_pack = (key, torch.from_numpy(ws).to(x.device), bias, ew)
+    _, ws, bias, ew = conv._mnerf_pack
+    return hip.conv2d(x, ws, bias, conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], ew, in_absmax, **kw)
 
 
 class ResidualBlock(nn.Module):
@@ -55,15 +85,20 @@ class ResidualBlock(nn.Module):
         else:
             self.downsample = None
 
+    def forward_fused(self, x, x_absmax, scal):
+        """Inference: split-fp16 MFMA convolutions (conv.hip) and one norm + activation (+ residual) kernel each
+        (instance_norm.hip).  ``x_absmax``: device scalar max|x| left by x's producer; ``scal``: two zeroed device
+        scalars for this block's own intermediate / output maxima.  Returns (out, scalar holding max|out|)."""
+        y = _hip_conv(self.conv1, x, x_absmax)
+        hip.instance_norm(y, relu_inner=True, out=y, out_absmax=scal[0:1])
+        y = _hip_conv(self.conv2, y, scal[0:1])
+        if self.downsample is not None:
+            x = _hip_conv(self.downsample[0], x, x_absmax)
+            hip.instance_norm(x, out=x)
+        hip.instance_norm(y, residual=x, relu_inner=True, relu_outer=True, out=y, out_absmax=scal[1:2])
+        return y, scal[1:2]
+
     def forward(self, x):
-        if _fused_norm(x):  # inference: every norm + activation (+ residual add) is one HIP kernel, in place
-            y = _conv_out(self.conv1, x)
-            hip.instance_norm(y, relu_inner=True, out=y)
-            y = _conv_out(self.conv2, y)
-            if self.downsample is not None:
-                x = _conv_out(self.downsample[0], x)
-                hip.instance_norm(x, out=x)
-            return hip.instance_norm(y, residual=x.contiguous(), relu_inner=True, relu_outer=True, out=y)
         y = F.relu(F.instance_norm(self.conv1(x)))
         y = F.relu(F.instance_norm(self.conv2(y)))
         if self.downsample is not None:
@@ -87,10 +122,17 @@ class CNNEncoder(nn.Module):
 
     def forward(self, x):
         if _fused_norm(x):
+            # the 7x7 stem (3 input channels) stays a library call; everything after it is HIP: 14 convolutions, 15 norms
+            scal = torch.zeros(16, device=x.device, dtype=torch.float32)  # max|.| of every convolution input
             x = _conv_out(self.conv1, x)
-            hip.instance_norm(x, relu_inner=True, out=x)
-        else:
-            x = F.relu(F.instance_norm(self.conv1(x)))
+            hip.instance_norm(x, relu_inner=True, out=x, out_absmax=scal[0:1])
+            amax, k = scal[0:1], 1
+            for layer in (self.layer1, self.layer2, self.layer3):
+                for blk in layer:
+                    x, amax = blk.forward_fused(x, amax, scal[k:k + 2])
+                    k += 2
+            return _hip_conv(self.conv2, x, amax)
+        x = F.relu(F.instance_norm(self.conv1(x)))
         x = self.layer3(self.layer2(self.layer1(x)))
         return self.conv2(x)
 
@@ -220,6 +262,22 @@ class UpSampler(nn.Module):
         self.conv_ls = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks)])
         self.conv_l2rs = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks + 1)])
 
+    def forward_tokens(self, x_cl):
+        """Inference on channel-last tokens [N,h,w,C] (what the transformer leaves): the convolutions read them as they
+        are, the nearest up-sampling in front of ``conv_ls`` is index arithmetic inside the convolution, LeakyReLU its
+        epilogue (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like ``forward``."""
+        scal = torch.zeros(self.n_blocks + 1, device=x_cl.device, dtype=torch.float32)
+        hip.absmax(x_cl, scal[0:1])
+        right = _hip_conv(self.conv_l2rs[0], x_cl, scal[0:1], channels_last=True)
+        left, left_cl = x_cl, True
+        for i in range(self.n_blocks):
+            left = _hip_conv(self.conv_ls[i], left, scal[i:i + 1], channels_last=left_cl, upsample2x=True, leaky=0.2,
+                             out_absmax=scal[i + 1:i + 2])
+            left_cl = False
+            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) \
+                + _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1:i + 2])
+        return right
+
     def forward(self, x):
         right = self.conv_l2rs[0](x)
         left = x
@@ -296,7 +354,10 @@ class GMFlow(nn.Module):
             src = torch.cat([tok[bi, ia], tok[bi, ib]], 0).contiguous()       # [2P, hw, C]
             src = self.transformer(src, p_n, h, w, splits, wo_self_attn)
             outs0.append(torch.stack([src[:p_n], src[p_n:]], 1).reshape(p_n, 2, h, w, ch))
-            up = self.featup_net(src.reshape(2 * p_n, h, w, ch).permute(0, 3, 1, 2))  # [2P,C,2h,2w]
+            if _fused_norm(src):
+                up = self.featup_net.forward_tokens(src.reshape(2 * p_n, h, w, ch))
+            else:
+                up = self.featup_net(src.reshape(2 * p_n, h, w, ch).permute(0, 3, 1, 2))  # [2P,C,2h,2w]
             up = up.permute(0, 2, 3, 1)
             outs1.append(torch.stack([up[:p_n], up[p_n:]], 1).contiguous())
         return [torch.stack(outs0, 0).contiguous(), torch.stack(outs1, 0).contiguous()]

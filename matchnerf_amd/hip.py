@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_instance_norm", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -66,6 +66,13 @@ class EncoderLayer(C.Structure):
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
 WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
 WA_PRESPLIT_F16 = 3  # host-side selector only: routed to mnerf_window_attention_presplit
+
+
+class ConvLayer(C.Structure):
+    """struct mnerf_conv (include/mnerf.h)"""
+    _fields_ = [("wstream", C.c_void_p), ("wstream_floats", C.c_int64), ("bias", C.c_void_p), ("c_in", C.c_int32),
+                ("c_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("ew", C.c_int32),
+                ("leaky_slope", C.c_float)]
 
 
 def lib_path():
@@ -127,7 +134,13 @@ def load():
     lib.mnerf_window_attention_presplit.restype = C.c_int
     lib.mnerf_window_attention_presplit.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_instance_norm.restype = C.c_int
-    lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, vp]
+    lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, fp, vp]
+    lib.mnerf_conv_wstream_floats.restype = i64
+    lib.mnerf_conv_wstream_floats.argtypes = [i32, i32, i32]
+    lib.mnerf_conv2d.restype = C.c_int
+    lib.mnerf_conv2d.argtypes = [C.POINTER(ConvLayer), fp, i32, i32, fp, fp, fp, i32, i32, i32, vp]
+    lib.mnerf_absmax.restype = C.c_int
+    lib.mnerf_absmax.argtypes = [fp, i64, fp, vp]
     lib.mnerf_encoder_block_wstream_floats.restype = i64
     lib.mnerf_encoder_block_wstream_floats.argtypes = [i32]
     lib.mnerf_encoder_block.restype = C.c_int
@@ -135,7 +148,7 @@ def load():
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
-    for which, st in enumerate((View, Rays, Scene, Decoder)):
+    for which, st in enumerate((View, Rays, Scene, Decoder, EncoderLayer, ConvLayer)):
         if lib.mnerf_struct_size(which) != C.sizeof(st):
             raise MnerfError(f"struct {st.__name__}: library says {lib.mnerf_struct_size(which)} bytes, "
                              f"ctypes mirror has {C.sizeof(st)}")
@@ -448,9 +461,10 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
     return out
 
 
-def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, stream=None):
+def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):
     """F.instance_norm(x) of an NCHW tensor fused with the ReLU / residual add / ReLU that follow it in the GMFlow
-    backbone (backbone.py:27-35): out = [relu](residual + [relu](IN(x)))."""
+    backbone (backbone.py:27-35): out = [relu](residual + [relu](IN(x))).  ``out_absmax``: 1-element float tensor that
+    max|out| is merged into (the operand scale of the convolution that reads ``out``)."""
     import torch
     lib = load()
     _f32c(x, "x")
@@ -465,7 +479,45 @@ def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5
     n, c, h, w = x.shape
     with _on(x.device, stream) as st:
         check(lib.mnerf_instance_norm(_ptr(x), _ptr(residual), _ptr(out), n * c, h * w, float(eps), int(bool(relu_inner)),
-                                      int(bool(relu_outer)), st), "mnerf_instance_norm")
+                                      int(bool(relu_outer)), _ptr(out_absmax), st), "mnerf_instance_norm")
+    return out
+
+
+def absmax(x, out, stream=None):
+    """max|x| merged into the 1-element float tensor ``out`` (atomic maximum: zero it first)."""
+    lib = load()
+    _f32c(x, "x")
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_absmax(_ptr(x), x.numel(), _ptr(out), st), "mnerf_absmax")
+    return out
+
+
+def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.0, channels_last=False, upsample2x=False,
+           out_absmax=None, out=None, stream=None):
+    """Split-fp16 implicit-GEMM convolution (csrc/conv.hip; gmflow/backbone.py, superres.py).  x [N,c_in,H,W], or
+    [N,H,W,c_in] with ``channels_last``; ``wstream`` from gmflow.pack_conv; ``in_absmax`` 1-element tensor >= max|x|
+    left by the producer of x.  Returns [N,c_out,H_out,W_out]."""
+    import torch
+    lib = load()
+    _f32c(x, "x"), _f32c(wstream, "wstream")
+    if x.dim() != 4:
+        raise MnerfError(f"conv2d: expected a 4-D tensor, got {tuple(x.shape)}")
+    n, h, w = (x.shape[0], x.shape[1], x.shape[2]) if channels_last else (x.shape[0], x.shape[2], x.shape[3])
+    if (x.shape[3] if channels_last else x.shape[1]) != c_in:
+        raise MnerfError(f"conv2d: input {tuple(x.shape)} does not have {c_in} channels")
+    up = 1 if upsample2x else 0
+    pad = ksize // 2
+    h_out = ((h << up) + 2 * pad - ksize) // stride + 1
+    w_out = ((w << up) + 2 * pad - ksize) // stride + 1
+    if out is None:
+        out = torch.empty(n, c_out, h_out, w_out, device=x.device, dtype=torch.float32)
+    cv = ConvLayer()
+    cv.wstream, cv.wstream_floats = wstream.data_ptr(), wstream.numel()
+    cv.bias = bias.data_ptr() if bias is not None else None
+    cv.c_in, cv.c_out, cv.ksize, cv.stride, cv.ew, cv.leaky_slope = c_in, c_out, ksize, stride, int(ew), float(leaky)
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_conv2d(C.byref(cv), _ptr(x), int(bool(channels_last)), up, _ptr(in_absmax), _ptr(out),
+                               _ptr(out_absmax), n, h, w, st), "mnerf_conv2d")
     return out
 
 

@@ -1,0 +1,103 @@
+"""Split-fp16 implicit-GEMM convolution (mnerf_conv2d): packer on the CPU, kernel parity on the GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from matchnerf_amd import gmflow as G
+
+
+def _unpack(ws, c_out, k_total, ew):
+    """inverse of pack_conv: the implicit-GEMM matrix the fragments encode"""
+    halfs = ws.view(np.float16).reshape(k_total // 16, c_out // 32, 2, 64, 8).astype(np.float64)
+    w = halfs[:, :, 0] + halfs[:, :, 1]                      # [steps, blocks, 64, 8]
+    mat = np.zeros((c_out, k_total))
+    lane = np.arange(64)
+    for s in range(k_total // 16):
+        for m in range(c_out // 32):
+            rows = 32 * m + (lane & 31)
+            for j in range(8):
+                mat[rows, 16 * s + 8 * (lane >> 5) + j] = w[s, m, lane, j]
+    return np.ldexp(mat, -ew)
+
+
+@pytest.mark.parametrize("c_in,c_out,k", [(64, 64, 3), (64, 96, 1), (96, 128, 3), (128, 128, 3)])
+def test_pack_conv_encodes_the_tap_major_matrix(c_in, c_out, k):
+    rng = np.random.default_rng(c_in + c_out + k)
+    w = (rng.standard_normal((c_out, c_in, k, k)) * 0.1).astype(np.float32)
+    ws, ew = G.pack_conv(w)
+    from matchnerf_amd import hip
+    assert ws.size == c_out // 32 * (k * k * c_in // 16) * 512
+    mat = _unpack(ws, c_out, k * k * c_in, ew)
+    assert np.abs(mat - w.transpose(0, 2, 3, 1).reshape(c_out, -1)).max() < 2.0 ** -20 * np.abs(w).max()
+    # the matrix applied to an im2col of the input (tap = ky * k + kx, then channel) is the convolution
+    x = rng.standard_normal((1, c_in, 6, 7)).astype(np.float32)
+    xp = np.pad(x, ((0, 0), (0, 0), (k // 2, k // 2), (k // 2, k // 2)))
+    cols = np.stack([xp[0, :, ky:ky + 6, kx:kx + 7] for ky in range(k) for kx in range(k)], 0)  # [taps, c, 6, 7]
+    y = (mat @ cols.reshape(k * k * c_in, -1)).reshape(c_out, 6, 7)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), padding=k // 2)[0].numpy()
+    assert np.abs(y - ref).max() < 1e-5
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from matchnerf_amd import hip as H
+    H.load()
+    return H
+
+
+CASES = [  # n, c_in, c_out, k, stride, h, w, channels_last, upsample2x, leaky, bias
+    (3, 64, 64, 3, 1, 64, 80, False, False, 1.0, False),
+    (2, 64, 96, 3, 2, 64, 80, False, False, 1.0, False),
+    (2, 64, 96, 1, 2, 64, 80, False, False, 1.0, True),
+    (2, 96, 96, 3, 1, 32, 40, False, False, 1.0, False),
+    (2, 96, 128, 3, 2, 33, 41, False, False, 1.0, False),   # odd sizes: ragged last tile, odd stride-2 geometry
+    (1, 128, 128, 1, 1, 8, 10, False, False, 1.0, True),
+    (2, 128, 128, 3, 1, 16, 20, True, False, 1.0, True),     # channel-last tokens in
+    (2, 128, 128, 3, 1, 16, 20, True, True, 0.2, True),      # ... through a nearest 2x up-sampling, LeakyReLU epilogue
+    (1, 128, 128, 3, 1, 9, 7, False, True, 0.2, True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d_matches_float64(hip, case):
+    n, ci, co, k, s, h, w, cl, up, leaky, use_bias = case
+    gen = torch.Generator().manual_seed(ci * 7 + co + k + h)
+    x = torch.randn(n, ci, h, w, generator=gen) * (0.5 + 4 * torch.rand(1, ci, 1, 1, generator=gen))
+    x[0, 0, 0, 0] = 37.0                                            # one spike: sets the tensor's operand scale
+    wt = torch.randn(co, ci, k, k, generator=gen) * (1.0 / np.sqrt(ci * k * k))
+    bias = torch.randn(co, generator=gen) if use_bias else None
+    ws, ew = G.pack_conv(wt)
+    xin = x.permute(0, 2, 3, 1).contiguous() if cl else x
+    scal = torch.zeros(2, device="cuda")
+    hip.absmax(xin.cuda(), scal[0:1])
+    assert float(scal[0]) == float(x.abs().max())
+    got = hip.conv2d(xin.cuda(), torch.from_numpy(ws).cuda(), bias.cuda() if use_bias else None, ci, co, k, s, ew,
+                     scal[0:1], leaky=leaky, channels_last=cl, upsample2x=up, out_absmax=scal[1:2])
+    xr = x.double()
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xr, wt.double(), bias.double() if use_bias else None, stride=s, padding=k // 2)
+    if leaky != 1.0:
+        want = F.leaky_relu(want, leaky)
+    assert got.shape == want.shape
+    err = float((got.cpu().double() - want).abs().max())
+    ref32 = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x, wt, bias, stride=s, padding=k // 2)
+    if leaky != 1.0:
+        ref32 = F.leaky_relu(ref32, leaky)
+    err32 = float((ref32.double() - want).abs().max())              # what an fp32 evaluation (CPU) achieves
+    assert err < 4 * err32 + 1e-6 * float(want.abs().max()), (case, err, err32)
+    assert abs(float(scal[1]) - float(got.abs().max())) == 0.0
+
+
+@pytest.mark.gpu
+def test_conv2d_argument_checks(hip):
+    ws = torch.zeros(512 * 4, device="cuda")
+    s = torch.ones(1, device="cuda")
+    with pytest.raises(hip.MnerfError):  # 3 input channels are not built
+        hip.conv2d(torch.zeros(1, 3, 8, 8, device="cuda"), ws, None, 3, 64, 3, 1, 0, s)
+    with pytest.raises(hip.MnerfError):  # stream size
+        hip.conv2d(torch.zeros(1, 64, 8, 8, device="cuda"), ws, None, 64, 64, 3, 1, 0, s)
+    with pytest.raises(hip.MnerfError):  # missing operand scale
+        hip.conv2d(torch.zeros(1, 32, 8, 8, device="cuda"), torch.zeros(512 * 4, device="cuda"), None, 32, 64, 1, 1, 0, None)
