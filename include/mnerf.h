@@ -250,8 +250,8 @@ int mnerf_window_attention_presplit(const float* q, const float* k, const float*
  *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);
  *   if residual: v += residual;                     if relu_outer: v = max(v, 0)
  * x, residual (or NULL), out: [planes = N*C][plane_size = H*W] fp32; out may alias x.  One workgroup per plane.
- * out_absmax: device scalar or NULL; max |out| is merged into it with an atomic maximum (the operand scale of the
- * convolution that reads `out`, see mnerf_conv2d). */
+ * out_absmax: absmax region (MNERF_ABSMAX_FLOATS floats, see mnerf_conv2d) or NULL; max |out| is merged into it (the
+ * operand scale of the convolution that reads `out`). */
 int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes, int64_t plane_size,
                         float eps, int32_t relu_inner, int32_t relu_outer, float* out_absmax, void* stream);
 
@@ -263,10 +263,13 @@ int mnerf_instance_norm(const float* x, const float* residual, float* out, int64
  *   bias        : [c_out] or NULL;  leaky_slope: LeakyReLU slope applied to the result (1 = none)
  * mnerf_conv2d: in [n_img, c_in, h_in, w_in] (or [n_img, h_in, w_in, c_in] with in_channels_last), optionally read
  * through a nearest 2x up-sampling (upsample2x); out [n_img, c_out, h_out, w_out] NCHW.
- *   in_absmax   : device scalar >= max |in| (operands are scaled by ONE power of two taken from it; a value that is
- *                 too small overflows fp16) - written by the producer of `in`: mnerf_instance_norm, mnerf_conv2d
- *                 (out_absmax) or mnerf_absmax
- *   out_absmax  : device scalar or NULL; max |out| is merged into it with an atomic maximum (zero it first). */
+ *   in_absmax   : absmax region (MNERF_ABSMAX_FLOATS floats) whose maximum is >= max |in| (operands are scaled by ONE
+ *                 power of two taken from it; a value that is too small overflows fp16) - filled by the producer of
+ *                 `in`: mnerf_instance_norm, mnerf_conv2d (out_absmax) or mnerf_absmax
+ *   out_absmax  : absmax region or NULL; max |out| is merged into it with atomic maxima (zero it first). */
+#define MNERF_ABSMAX_SLOTS 64   /* an "absmax region" = SLOTS partial maxima, STRIDE floats apart: 2048 floats, zeroed */
+#define MNERF_ABSMAX_STRIDE 32  /* by the caller; producers merge with atomic maxima, the convolution reduces the slots */
+#define MNERF_ABSMAX_FLOATS (MNERF_ABSMAX_SLOTS * MNERF_ABSMAX_STRIDE)
 typedef struct mnerf_conv {
   const float* wstream;
   int64_t wstream_floats;
@@ -279,7 +282,7 @@ int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize);
 int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
                  const float* in_absmax, float* out, float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in,
                  void* stream);
-/* max |x| of n floats merged into the device scalar `out` (atomic maximum; zero it first) */
+/* max |x| of n floats merged into the absmax region `out` (atomic maxima; zero it first) */
 int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel

@@ -171,3 +171,21 @@ __device__ __forceinline__ float sin_quarter(float arg, int quarter) {
   return sin_quarter_turns(th, tl, quarter);
 }
 #pragma clang fp contract(fast)
+
+// ---- "largest magnitude of a tensor" hand-over between a producer kernel and the split-fp16 convolution that reads
+// the tensor (conv.hip): a region of MNERF_ABSMAX_SLOTS partial maxima, one 128-byte line apart, zeroed by the caller.
+// Workgroup b of the producer merges its maximum into slot b % SLOTS with an atomic maximum (non-negative floats order
+// as integers; one address would serialise thousands of atomics: 15-40 us per kernel measured), the consumer takes the
+// maximum of the slots.
+#ifdef __HIPCC__
+__device__ __forceinline__ void mnerf_absmax_merge(float wave_or_block_max, float* region) {
+  atomicMax(reinterpret_cast<int*>(region + (blockIdx.x % MNERF_ABSMAX_SLOTS) * MNERF_ABSMAX_STRIDE),
+            __float_as_int(wave_or_block_max));
+}
+__device__ __forceinline__ float mnerf_absmax_read(const float* region) {  // whole wave; every lane gets the maximum
+  float m = region[(threadIdx.x & (MNERF_ABSMAX_SLOTS - 1)) * MNERF_ABSMAX_STRIDE];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  return m;
+}
+#endif

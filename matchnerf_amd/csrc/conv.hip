@@ -15,7 +15,7 @@
 // accesses), accumulators hold all output channels of its pixels.  One K16-step = 16 input channels of one filter tap;
 // lane (pixel, half) loads its 8 channels of that tap straight from global memory (predicated: zero padding),
 // one step ahead of their use, and splits them with ONE power-of-two gain per input TENSOR - its largest magnitude,
-// left in a device scalar by the kernel that produced it (mnerf_instance_norm, this kernel, mnerf_absmax); the IN
+// left in an absmax region (common.hpp) by the kernel that produced it (mnerf_instance_norm, this kernel, mnerf_absmax); the IN
 // output of a plane is bounded by sqrt(plane size), so the typical value keeps >= 21 significant bits.
 // Weights: packed by the host as A-operand fragments (matchnerf_amd/gmflow.py, pack_conv), streamed in segments of
 // whole K16-step pairs (<= 36 KiB) through a 2 x 36 KiB LDS double buffer by LDS-DMA, one barrier per segment, two
@@ -23,7 +23,6 @@
 #include "split_f16.hpp"
 
 #define CONV_NW 4
-#define CONV_TPW 2             // 32-pixel tiles per wave
 #define CONV_BUF_BYTES 36864u  // one LDS weight buffer (36 KiB: six K16-steps x three 32-row blocks)
 
 struct ConvParams {
@@ -40,7 +39,9 @@ struct ConvParams {
   float leaky;                // LeakyReLU slope applied to the result (1 = none)
 };
 
-template <int NMB>
+// NMB: 32-row blocks of output channels; CONV_TPW: 32-pixel tiles per wave (2, or 1 when that is what it takes to give
+// every CU a workgroup); CL: the input is stored channel-last (a lane's 8 channels are two float4)
+template <int NMB, int CONV_TPW, bool CL>
 __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float conv_smem[];
   const unsigned buf0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)conv_smem;
@@ -79,8 +80,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   const int h_eff = P.h_in << P.up, w_eff = P.w_in << P.up;
   const int csteps = P.c_in >> 4, n_steps = P.ksize * P.ksize * csteps;
 
-  const float amax = P.in_absmax ? *P.in_absmax : 1.0f;
-  const int eg = gain_exp(amax);
+  const int eg = gain_exp(mnerf_absmax_read(P.in_absmax));
   const float mult = pow2i(eg);
 
   // ---- operand pipeline: an iteration covers TWO K16-steps (32 input channels of one tap); the values of iteration
@@ -108,9 +108,16 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
       const float* src = P.in + toff[t] + (long long)(32 * cpair) * P.sc;
       vok[t] = tok[t];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u) {
+        if constexpr (CL) {
+          const float4 a4 = *reinterpret_cast<const float4*>(src + 16 * u), b4 = *reinterpret_cast<const float4*>(src + 16 * u + 4);
+          vn[t][8 * u + 0] = a4.x; vn[t][8 * u + 1] = a4.y; vn[t][8 * u + 2] = a4.z; vn[t][8 * u + 3] = a4.w;
+          vn[t][8 * u + 4] = b4.x; vn[t][8 * u + 5] = b4.y; vn[t][8 * u + 6] = b4.z; vn[t][8 * u + 7] = b4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vn[t][8 * u + j] = src[(long long)(16 * u + j) * P.sc];
+          for (int j = 0; j < 8; ++j) vn[t][8 * u + j] = src[(long long)(16 * u + j) * P.sc];
+        }
+      }
     }
     if (++cpair == cpairs) {
       cpair = 0;
@@ -190,20 +197,35 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
         }
       }
   }
-  if (P.out_absmax) {
+  if (P.out_absmax) {  // one atomic per workgroup into the tensor's absmax region
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
-    if (lane == 0) atomicMax(reinterpret_cast<int*>(P.out_absmax), __float_as_int(omax));  // non-negative floats order as ints
+    __syncthreads();
+    if (lane == 0) bias_lds[wave] = omax;
+    __syncthreads();
+    if (tid == 0) mnerf_absmax_merge(fmaxf(fmaxf(bias_lds[0], bias_lds[1]), fmaxf(bias_lds[2], bias_lds[3])), P.out_absmax);
   }
 }
 
-// largest |x| of a tensor into a device scalar (atomic maximum: the caller zeroes it)
+// largest |x| of a tensor into an absmax region (the caller zeroes it)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
   float m = 0.0f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+  const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+  const bool vec = (reinterpret_cast<size_t>(x) & 15) == 0;
+  if (vec) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const float4 v = x4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
+  for (long long i = (vec ? n4 * 4 : 0) + (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) mnerf_absmax_merge(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), out);
 }
 
 extern "C" int mnerf_absmax(const float* x, int64_t n, float* out, void* stream) {
@@ -212,7 +234,7 @@ extern "C" int mnerf_absmax(const float* x, int64_t n, float* out, void* stream)
   if (n == 0) return MNERF_OK;
   MNERF_REQUIRE(x, MNERF_E_NULL, "mnerf_absmax: x is NULL");
   const long long blocks = (n + 256 * 16 - 1) / (256 * 16);
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, (hipStream_t)stream, x,
                      (long long)n, out);
   return mnerf_check_launch("mnerf_absmax");
 }
@@ -274,18 +296,24 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.n_seg = n_steps / p.seg_steps;
   p.leaky = cv->leaky_slope;
   const long long n_pix = (long long)n_img * p.h_out * p.w_out;
-  const long long per_wg = 32 * CONV_TPW * CONV_NW;
+  // two pixel tiles per wave share every weight fragment read; one tile per wave when that grid would leave CUs idle
+  const int tpw = (n_pix + 255) / 256 >= 256 ? 2 : 1;
+  const long long per_wg = 32 * tpw * CONV_NW;
   const dim3 grid((unsigned)((n_pix + per_wg - 1) / per_wg));
   const size_t lds = 2 * CONV_BUF_BYTES;
   hipStream_t st = (hipStream_t)stream;
-  static std::atomic<unsigned long long> attr{0};
-  if (mnerf_once_per_device(attr)) {
-    (void)hipFuncSetAttribute((const void*)conv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)conv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool cl = in_channels_last != 0;
+  MNERF_REQUIRE(!cl || nmb == 4, MNERF_E_UNSUPPORTED, "%s: channel-last input is built for c_out = 128 only", who);
+#define CONV_CASE(NMB, TPW, CLV)                                                                                      \
+  if (nmb == NMB && tpw == TPW && cl == CLV) {                                                                        \
+    static std::atomic<unsigned long long> attr{0};                                                                   \
+    if (mnerf_once_per_device(attr))                                                                                  \
+      (void)hipFuncSetAttribute((const void*)conv_kernel<NMB, TPW, CLV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                (int)lds);                                                                            \
+    hipLaunchKernelGGL((conv_kernel<NMB, TPW, CLV>), grid, dim3(CONV_NW * 64), lds, st, p);                           \
   }
-  if (nmb == 2) hipLaunchKernelGGL(conv_kernel<2>, grid, dim3(CONV_NW * 64), lds, st, p);
-  else if (nmb == 3) hipLaunchKernelGGL(conv_kernel<3>, grid, dim3(CONV_NW * 64), lds, st, p);
-  else hipLaunchKernelGGL(conv_kernel<4>, grid, dim3(CONV_NW * 64), lds, st, p);
+  CONV_CASE(2, 2, false) CONV_CASE(2, 1, false) CONV_CASE(3, 2, false) CONV_CASE(3, 1, false)
+  CONV_CASE(4, 2, false) CONV_CASE(4, 1, false) CONV_CASE(4, 2, true) CONV_CASE(4, 1, true)
+#undef CONV_CASE
   return mnerf_check_launch(who);
 }

@@ -7,7 +7,7 @@
 //   backbone.py:101-103 CNNEncoder.forward: relu(norm1(conv1 x))
 // torch runs each InstanceNorm as three kernels (batch-norm statistics, inverse std, transform) followed by a clamp
 // and, at the end of a block, an add and another clamp: five to seven passes over the activation.  Here a workgroup
-// owns one (image, channel) plane of the NCHW tensor, keeps it in REGISTERS (up to 80 floats per lane at 1 024 lanes:
+// owns one (image, channel) plane of the NCHW tensor, keeps it in REGISTERS (up to 160 floats per lane at 512 lanes:
 // the 256x320 plane of the first stage), takes mean and centred variance from the registers (two workgroup
 // reductions) and writes the finished value once: one read, one write - the kernel is HBM/L2-bound by construction.
 // Planes that do not fit (or whose size is not a multiple of four) take a three-pass streaming kernel.
@@ -36,13 +36,21 @@ __device__ __forceinline__ float in_finish(float x, float mean, float rstd, floa
   return v;
 }
 
-// largest |out| of the tensor, merged into a device scalar (non-negative floats order as integers): the operand scale of
-// the split-fp16 convolution that reads the result (conv.hip)
-__device__ __forceinline__ void in_merge_absmax(float m, float* out_absmax) {
+// largest |out| of the plane -> the tensor's absmax region (common.hpp): the operand scale of the split-fp16
+// convolution that reads the result (conv.hip).  One atomic per workgroup.
+template <int THREADS>
+__device__ __forceinline__ void in_merge_absmax(float m, float* red, float* out_absmax) {
   if (!out_absmax) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(out_absmax), __float_as_int(m));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < THREADS / 64; ++i) m = fmaxf(m, red[i]);
+    mnerf_absmax_merge(m, out_absmax);
+  }
 }
 
 template <int THREADS, int VPT>
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
       omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
   }
-  in_merge_absmax(omax, out_absmax);
+  in_merge_absmax<THREADS>(omax, red, out_absmax);
 }
 
 // any plane size: three passes (the plane of a running workgroup stays in L2 / Infinity Cache between them)
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* 
     out[base + j] = o;
     omax = fmaxf(omax, fabsf(o));
   }
-  in_merge_absmax(omax, out_absmax);
+  in_merge_absmax<256>(omax, red, out_absmax);
 }
 
 extern "C" int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes,
@@ -142,7 +150,7 @@ extern "C" int mnerf_instance_norm(const float* x, const float* residual, float*
                      relu_outer, out_absmax)
   if (vec && n <= 256 * 8 * 4) IN_LAUNCH(256, 8);
   else if (vec && n <= 256 * 20 * 4) IN_LAUNCH(256, 20);
-  else if (vec && n <= 1024 * 20 * 4) IN_LAUNCH(1024, 20);
+  else if (vec && n <= 512 * 40 * 4) IN_LAUNCH(512, 40);  // two workgroups per CU: one plane loads while another stores
   else
     hipLaunchKernelGGL(instance_norm_stream_kernel, grid, dim3(256), 0, st, x, residual, out, n, eps, relu_inner, relu_outer,
                        out_absmax);

@@ -87,16 +87,16 @@ class ResidualBlock(nn.Module):
 
     def forward_fused(self, x, x_absmax, scal):
         """Inference: split-fp16 MFMA convolutions (conv.hip) and one norm + activation (+ residual) kernel each
-        (instance_norm.hip).  ``x_absmax``: device scalar max|x| left by x's producer; ``scal``: two zeroed device
-        scalars for this block's own intermediate / output maxima.  Returns (out, scalar holding max|out|)."""
+        (instance_norm.hip).  ``x_absmax``: absmax region filled by x's producer; ``scal``: two zeroed regions for this
+        block's own intermediate / output maxima.  Returns (out, region holding max|out|)."""
         y = _hip_conv(self.conv1, x, x_absmax)
-        hip.instance_norm(y, relu_inner=True, out=y, out_absmax=scal[0:1])
-        y = _hip_conv(self.conv2, y, scal[0:1])
+        hip.instance_norm(y, relu_inner=True, out=y, out_absmax=scal[0])
+        y = _hip_conv(self.conv2, y, scal[0])
         if self.downsample is not None:
             x = _hip_conv(self.downsample[0], x, x_absmax)
             hip.instance_norm(x, out=x)
-        hip.instance_norm(y, residual=x, relu_inner=True, relu_outer=True, out=y, out_absmax=scal[1:2])
-        return y, scal[1:2]
+        hip.instance_norm(y, residual=x, relu_inner=True, relu_outer=True, out=y, out_absmax=scal[1])
+        return y, scal[1]
 
     def forward(self, x):
         y = F.relu(F.instance_norm(self.conv1(x)))
@@ -123,10 +123,10 @@ class CNNEncoder(nn.Module):
     def forward(self, x):
         if _fused_norm(x):
             # the 7x7 stem (3 input channels) stays a library call; everything after it is HIP: 14 convolutions, 15 norms
-            scal = torch.zeros(16, device=x.device, dtype=torch.float32)  # max|.| of every convolution input
+            scal = hip.absmax_regions(13, x.device)  # max|.| of every convolution input (one fill kernel)
             x = _conv_out(self.conv1, x)
-            hip.instance_norm(x, relu_inner=True, out=x, out_absmax=scal[0:1])
-            amax, k = scal[0:1], 1
+            hip.instance_norm(x, relu_inner=True, out=x, out_absmax=scal[0])
+            amax, k = scal[0], 1
             for layer in (self.layer1, self.layer2, self.layer3):
                 for blk in layer:
                     x, amax = blk.forward_fused(x, amax, scal[k:k + 2])
@@ -266,16 +266,16 @@ class UpSampler(nn.Module):
         """Inference on channel-last tokens [N,h,w,C] (what the transformer leaves): the convolutions read them as they
         are, the nearest up-sampling in front of ``conv_ls`` is index arithmetic inside the convolution, LeakyReLU its
         epilogue (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like ``forward``."""
-        scal = torch.zeros(self.n_blocks + 1, device=x_cl.device, dtype=torch.float32)
-        hip.absmax(x_cl, scal[0:1])
-        right = _hip_conv(self.conv_l2rs[0], x_cl, scal[0:1], channels_last=True)
+        scal = hip.absmax_regions(self.n_blocks + 1, x_cl.device)
+        hip.absmax(x_cl, scal[0])
+        right = _hip_conv(self.conv_l2rs[0], x_cl, scal[0], channels_last=True)
         left, left_cl = x_cl, True
         for i in range(self.n_blocks):
-            left = _hip_conv(self.conv_ls[i], left, scal[i:i + 1], channels_last=left_cl, upsample2x=True, leaky=0.2,
-                             out_absmax=scal[i + 1:i + 2])
+            left = _hip_conv(self.conv_ls[i], left, scal[i], channels_last=left_cl, upsample2x=True, leaky=0.2,
+                             out_absmax=scal[i + 1])
             left_cl = False
             right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) \
-                + _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1:i + 2])
+                + _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1])
         return right
 
     def forward(self, x):

@@ -66,6 +66,7 @@ class EncoderLayer(C.Structure):
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
 WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
 WA_PRESPLIT_F16 = 3  # host-side selector only: routed to mnerf_window_attention_presplit
+ABSMAX_FLOATS = 64 * 32  # floats of one absmax region (MNERF_ABSMAX_FLOATS)
 
 
 class ConvLayer(C.Structure):
@@ -463,8 +464,8 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
 
 def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):
     """F.instance_norm(x) of an NCHW tensor fused with the ReLU / residual add / ReLU that follow it in the GMFlow
-    backbone (backbone.py:27-35): out = [relu](residual + [relu](IN(x))).  ``out_absmax``: 1-element float tensor that
-    max|out| is merged into (the operand scale of the convolution that reads ``out``)."""
+    backbone (backbone.py:27-35): out = [relu](residual + [relu](IN(x))).  ``out_absmax``: absmax region that max|out|
+    is merged into (the operand scale of the convolution that reads ``out``)."""
     import torch
     lib = load()
     _f32c(x, "x")
@@ -483,8 +484,20 @@ def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5
     return out
 
 
+def absmax_regions(n, device):
+    """n zeroed absmax regions [n, ABSMAX_FLOATS] (include/mnerf.h): the hand-over of a tensor's largest magnitude from
+    the kernel that writes it to the split-fp16 convolution that reads it."""
+    import torch
+    return torch.zeros(n, ABSMAX_FLOATS, device=device, dtype=torch.float32)
+
+
+def absmax_value(region):
+    """the maximum an absmax region holds (device tensor, no sync)"""
+    return region.max()
+
+
 def absmax(x, out, stream=None):
-    """max|x| merged into the 1-element float tensor ``out`` (atomic maximum: zero it first)."""
+    """max|x| merged into the absmax region ``out`` (atomic maxima: zero it first)."""
     lib = load()
     _f32c(x, "x")
     with _on(x.device, stream) as st:
@@ -495,8 +508,8 @@ def absmax(x, out, stream=None):
 def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.0, channels_last=False, upsample2x=False,
            out_absmax=None, out=None, stream=None):
     """Split-fp16 implicit-GEMM convolution (csrc/conv.hip; gmflow/backbone.py, superres.py).  x [N,c_in,H,W], or
-    [N,H,W,c_in] with ``channels_last``; ``wstream`` from gmflow.pack_conv; ``in_absmax`` 1-element tensor >= max|x|
-    left by the producer of x.  Returns [N,c_out,H_out,W_out]."""
+    [N,H,W,c_in] with ``channels_last``; ``wstream`` from gmflow.pack_conv; ``in_absmax``: absmax region filled by the
+    producer of x.  Returns [N,c_out,H_out,W_out]."""
     import torch
     lib = load()
     _f32c(x, "x"), _f32c(wstream, "wstream")

@@ -70,11 +70,11 @@ def test_conv2d_matches_float64(hip, case):
     bias = torch.randn(co, generator=gen) if use_bias else None
     ws, ew = G.pack_conv(wt)
     xin = x.permute(0, 2, 3, 1).contiguous() if cl else x
-    scal = torch.zeros(2, device="cuda")
-    hip.absmax(xin.cuda(), scal[0:1])
-    assert float(scal[0]) == float(x.abs().max())
+    scal = hip.absmax_regions(2, "cuda")
+    hip.absmax(xin.cuda(), scal[0])
+    assert float(hip.absmax_value(scal[0])) == float(x.abs().max())
     got = hip.conv2d(xin.cuda(), torch.from_numpy(ws).cuda(), bias.cuda() if use_bias else None, ci, co, k, s, ew,
-                     scal[0:1], leaky=leaky, channels_last=cl, upsample2x=up, out_absmax=scal[1:2])
+                     scal[0], leaky=leaky, channels_last=cl, upsample2x=up, out_absmax=scal[1])
     xr = x.double()
     if up:
         xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
@@ -88,13 +88,13 @@ def test_conv2d_matches_float64(hip, case):
         ref32 = F.leaky_relu(ref32, leaky)
     err32 = float((ref32.double() - want).abs().max())              # what an fp32 evaluation (CPU) achieves
     assert err < 4 * err32 + 1e-6 * float(want.abs().max()), (case, err, err32)
-    assert abs(float(scal[1]) - float(got.abs().max())) == 0.0
+    assert float(hip.absmax_value(scal[1])) == float(got.abs().max())
 
 
 @pytest.mark.gpu
 def test_conv2d_argument_checks(hip):
     ws = torch.zeros(512 * 4, device="cuda")
-    s = torch.ones(1, device="cuda")
+    s = torch.ones(hip.ABSMAX_FLOATS, device="cuda")
     with pytest.raises(hip.MnerfError):  # 3 input channels are not built
         hip.conv2d(torch.zeros(1, 3, 8, 8, device="cuda"), ws, None, 3, 64, 3, 1, 0, s)
     with pytest.raises(hip.MnerfError):  # stream size

@@ -39,10 +39,12 @@ def test_instance_norm_matches_torch_and_float64(hip, shape):
         err = float((got.cpu().double() - want64).abs().max())
         err_torch = float((torch_gpu.cpu().double() - want64).abs().max())
         assert err < 2e-5 and err <= 4 * err_torch + 2e-6, (shape, inner, outer, use_res, err, err_torch)
-    # in place
+    # in place; the largest magnitude is handed over exactly
     y = xg.clone()
-    hip.instance_norm(y, relu_inner=True, out=y)
+    reg = hip.absmax_regions(1, "cuda")
+    hip.instance_norm(y, relu_inner=True, out=y, out_absmax=reg[0])
     assert torch.equal(y, hip.instance_norm(xg, relu_inner=True))
+    assert float(hip.absmax_value(reg[0])) == float(y.max())
 
 
 def test_instance_norm_argument_checks(hip):
