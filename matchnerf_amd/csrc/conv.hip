@@ -32,6 +32,7 @@ struct ConvParams {
   float* out;
   const float* in_absmax;
   float* out_absmax;
+  const float* add_up;  // [n_img, c_out, h_out / 2, w_out / 2] or NULL: its bilinear 2x up-sampling is added to the result
   int n_img, c_in, h_in, w_in, h_out, w_out;
   int ksize, stride, up;      // up = 1: the input is read through a nearest 2x up-sampling
   long long sc, sy, sx, si;   // element strides of the stored input: channel, row, column, image
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   // ---- this lane's output pixels
   const int hw_out = P.h_out * P.w_out;
   const long long n_pix = (long long)P.n_img * hw_out;
-  int oy[CONV_TPW], ox[CONV_TPW];
+  int oy[CONV_TPW], ox[CONV_TPW], oimg[CONV_TPW];
   long long ibase[CONV_TPW], obase[CONV_TPW];
   bool live[CONV_TPW];
 #pragma unroll
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
     live[t] = p < n_pix;
     const long long pc = live[t] ? p : n_pix - 1;
     const int img = (int)(pc / hw_out), rem = (int)(pc - (long long)img * hw_out);
+    oimg[t] = img;
     oy[t] = rem / P.w_out;
     ox[t] = rem - oy[t] * P.w_out;
     ibase[t] = (long long)img * P.si + (long long)(8 * hl) * P.sc;
@@ -182,6 +184,14 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
 #pragma unroll
   for (int t = 0; t < CONV_TPW; ++t) {
     if (!live[t]) continue;
+    // F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) of `add_up` at this pixel (superres.py:37):
+    // source index max(0.5 (dst + 0.5) - 0.5, 0), second tap clamped at the border - torch's formula and order
+    const int hs = P.h_out >> 1, ws = P.w_out >> 1;
+    const float sy = fmaxf(0.5f * ((float)oy[t] + 0.5f) - 0.5f, 0.0f), sx = fmaxf(0.5f * ((float)ox[t] + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+    const float* up0 = P.add_up ? P.add_up + (long long)oimg[t] * (32 * NMB) * hs * ws : nullptr;
 #pragma unroll
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
@@ -190,10 +200,15 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const int ch = 32 * m + 8 * g + 4 * hl + q;
           float v = acc[t][m][4 * g + q] * cm + bb[q];
           v = v < 0.0f ? v * P.leaky : v;
+          if (up0) {
+            const float* pl = up0 + (long long)ch * hs * ws;
+            v = (ly0 * (lx0 * pl[y0 * ws + x0] + lx1 * pl[y0 * ws + x1]) + ly1 * (lx0 * pl[y1 * ws + x0] + lx1 * pl[y1 * ws + x1])) + v;
+          }
           omax = fmaxf(omax, fabsf(v));
-          P.out[obase[t] + (long long)(32 * m + 8 * g + 4 * hl + q) * hw_out] = v;
+          P.out[obase[t] + (long long)ch * hw_out] = v;
         }
       }
   }
@@ -252,8 +267,8 @@ extern "C" int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_
 }
 
 extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
-                            const float* in_absmax, float* out, float* out_absmax, int32_t n_img, int32_t h_in,
-                            int32_t w_in, void* stream) {
+                            const float* in_absmax, const float* add_bilinear2x, float* out, float* out_absmax,
+                            int32_t n_img, int32_t h_in, int32_t w_in, void* stream) {
   const char* who = "mnerf_conv2d";
   MNERF_REQUIRE(cv, MNERF_E_NULL, "%s: cv is NULL", who);
   MNERF_REQUIRE(cv->c_in >= 32 && cv->c_in % 32 == 0 && (cv->c_out == 64 || cv->c_out == 96 || cv->c_out == 128) &&
@@ -276,12 +291,15 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.out = out;
   p.in_absmax = in_absmax;
   p.out_absmax = out_absmax;
+  p.add_up = add_bilinear2x;
   p.n_img = n_img;
   p.c_in = cv->c_in;
   p.h_in = h_in;
   p.w_in = w_in;
   p.h_out = ((h_in << up) + 2 * pad - cv->ksize) / cv->stride + 1;
   p.w_out = ((w_in << up) + 2 * pad - cv->ksize) / cv->stride + 1;
+  MNERF_REQUIRE(!add_bilinear2x || (p.h_out % 2 == 0 && p.w_out % 2 == 0), MNERF_E_RANGE,
+                "%s: add_bilinear2x needs an even output size, got %dx%d", who, p.h_out, p.w_out);
   p.ksize = cv->ksize;
   p.stride = cv->stride;
   p.up = up;

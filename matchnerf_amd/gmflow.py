@@ -264,8 +264,8 @@ class UpSampler(nn.Module):
 
     def forward_tokens(self, x_cl):
         """Inference on channel-last tokens [N,h,w,C] (what the transformer leaves): the convolutions read them as they
-        are, the nearest up-sampling in front of ``conv_ls`` is index arithmetic inside the convolution, LeakyReLU its
-        epilogue (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like ``forward``."""
+        are, the nearest up-sampling in front of ``conv_ls`` is index arithmetic inside the convolution, LeakyReLU and the
+        bilinear up-sampling + add of the other branch are epilogues (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like ``forward``."""
         scal = hip.absmax_regions(self.n_blocks + 1, x_cl.device)
         hip.absmax(x_cl, scal[0])
         right = _hip_conv(self.conv_l2rs[0], x_cl, scal[0], channels_last=True)
@@ -274,8 +274,8 @@ class UpSampler(nn.Module):
             left = _hip_conv(self.conv_ls[i], left, scal[i], channels_last=left_cl, upsample2x=True, leaky=0.2,
                              out_absmax=scal[i + 1])
             left_cl = False
-            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) \
-                + _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1])
+            # right = up_bilinear(right) + conv(left): the up-sampling and the add are the convolution's epilogue
+            right = _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1], add_bilinear2x=right)
         return right
 
     def forward(self, x):

@@ -92,6 +92,35 @@ def test_conv2d_matches_float64(hip, case):
 
 
 @pytest.mark.gpu
+def test_conv2d_adds_bilinear_upsampling(hip):
+    """superres.py:37: right = F.interpolate(right, 2x bilinear) + conv(left), the up-sampling and add as the epilogue"""
+    gen = torch.Generator().manual_seed(5)
+    left = torch.randn(2, 128, 12, 20, generator=gen)
+    right = torch.randn(2, 128, 6, 10, generator=gen) * 3
+    wt = torch.randn(128, 128, 3, 3, generator=gen) * 0.03
+    bias = torch.randn(128, generator=gen)
+    ws, ew = G.pack_conv(wt)
+    scal = hip.absmax_regions(1, "cuda")
+    hip.absmax(left.cuda(), scal[0])
+    got = hip.conv2d(left.cuda(), torch.from_numpy(ws).cuda(), bias.cuda(), 128, 128, 3, 1, ew, scal[0], add_bilinear2x=right.cuda())
+    want = F.interpolate(right.double(), scale_factor=2, mode="bilinear", align_corners=False) \
+        + F.conv2d(left.double(), wt.double(), bias.double(), padding=1)
+    assert float((got.cpu().double() - want).abs().max()) < 3e-6 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_upsampler_fused_path_matches_op_chain(hip):
+    from matchnerf_amd.gmflow import UpSampler
+    torch.manual_seed(1)
+    net = UpSampler().cuda()
+    tok = torch.randn(2, 16, 24, 128, device="cuda")
+    with torch.no_grad():
+        fused = net.forward_tokens(tok)
+        chain = net(tok.permute(0, 3, 1, 2))
+    assert float((fused - chain).abs().max()) < 1e-5 * float(chain.abs().max())
+
+
+@pytest.mark.gpu
 def test_conv2d_argument_checks(hip):
     ws = torch.zeros(512 * 4, device="cuda")
     s = torch.ones(hip.ABSMAX_FLOATS, device="cuda")
