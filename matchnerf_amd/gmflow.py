@@ -10,12 +10,14 @@ forward pass designed around what the render kernels consume:
   ``torch.cat`` regrouping (reference: matchnerf.py:192-205);
 * the window sine position tile depends only on the token position, so it is added once per
   VIEW before pairs are formed (reference adds it per pair member, gmflow/utils.py:68-88);
-* the six swin self/cross attention layers call the flash-style f32-MFMA HIP kernel
+* the six swin self/cross attention layers call the flash-style HIP kernel
   ``mnerf_window_attention`` (K6): roll, window split/merge and the shift mask are index
   arithmetic in the kernel, the [24,1280,1280] score tensor is never materialised
   (reference: transformer.py:46-105);
-* convolutions / InstanceNorm / Linear / LayerNorm / GELU are PyTorch-ROCm library ops
-  (MIOpen, rocBLAS) — SURVEY.md §2 marks them "supporting, not a hand-kernel target".
+* the backbone and up-sampler convolutions after the 7x7 stem are split-fp16 implicit GEMMs (``mnerf_conv2d``), every
+  InstanceNorm + activation (+ residual add) one kernel (``mnerf_instance_norm``), everything after the attention
+  inside a transformer layer one kernel (``mnerf_encoder_block``); the stem and the q|k|v projections are library ops
+  (MIOpen, rocBLAS).  Under autograd the reference's op chain is used throughout.
 
 There is no CPU path: ``forward`` needs the HIP library and a GPU tensor.
 """
