@@ -245,6 +245,16 @@ int mnerf_window_attention_presplit(const float* q, const float* k, const float*
                                     int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* q | k | v projections of a GMFlow transformer layer in one launch (models/gmflow/transformer.py:147-151):
+ *   q = Wq x_q,  k = Wk x_kv',  v = Wv x_kv'      x_q, x_kv, q, k, v: [n_seq, seq_len, 128] fp32 tokens
+ * kv_swap: x_kv' is x_kv with its two batch halves exchanged (sequence b reads sequence (b + n_seq/2) mod n_seq): the
+ * "target" of the batched pair members (transformer.py:317-335) without building the concatenated tensor.
+ * wstream: split-fp16 A-operand fragments of [Wq | Wk | Wv] (matchnerf_amd/gmflow.py: pack_qkv;
+ * mnerf_qkv_wstream_floats() words, device), ew: the three weight-scale exponents (HOST array of 3). */
+int64_t mnerf_qkv_wstream_floats(void);
+int mnerf_qkv_projection(const float* wstream, const int32_t* ew, const float* x_q, const float* x_kv, int32_t kv_swap,
+                         float* q, float* k, float* v, int32_t n_seq, int32_t seq_len, void* stream);
+
 /* InstanceNorm2d (no affine, biased variance, as torch.nn.functional.instance_norm) of an NCHW tensor fused with what
  * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):
  *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
 SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "decoder.hip", "encoder_block.hip", "geometry.hip",
-           "instance_norm.hip", "render_chunk.hip", "window_attention.hip"]
+           "instance_norm.hip", "qkv.hip", "render_chunk.hip", "window_attention.hip"]
 DECODER_SOURCES = ["decoder.hip", "split_f16.hpp", "cv_walk.hpp", "common.hpp"]  # what decoder_kernel is compiled from
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

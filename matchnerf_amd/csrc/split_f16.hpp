@@ -151,6 +151,31 @@ __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, 
   }
 }
 
+// NS K16-steps against NMB output blocks with operands that are ALREADY split (mlp.0's operands are the same for
+// all eight hidden chunks: split once, 128 registers that the matrix instructions can read from the AGPR half)
+template <int NMB, int NS>
+__device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const PartsH* b) {
+  lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
+  u32x4 ch = a[0], cl = a[64];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+#pragma unroll
+    for (int m = 0; m < NMB; ++m) {
+      const int i = u * NMB + m;
+      const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;
+      const u32x4 nh = a[nx], nl = a[nx + 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
+      acc[m] = mfma16h(ah, b[u].lo, acc[m]);
+      acc[m] = mfma16h(al, b[u].hi, acc[m]);
+      acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+      __builtin_amdgcn_sched_barrier(0);
+      ch = nh;
+      cl = nl;
+    }
+  }
+}
+
 template <int NMB>
 __device__ __forceinline__ void kblock_h(f32x16 (&acc)[NMB], unsigned base_lds, int lane, const f32x16& h, float mult) {
   float v[16];

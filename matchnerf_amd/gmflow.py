@@ -176,9 +176,25 @@ def pack_encoder_block(merge_w, mlp0_w=None, mlp2_w=None):
     return ws, tuple(int(e) for e in ews)
 
 
+def pack_qkv(wq, wk, wv):
+    """q/k/v projection weights [128,128] -> (wstream float32 words, (ew_q, ew_k, ew_v)) for ``mnerf_qkv_projection``
+    (csrc/qkv.hip): three matrices of 8 K16-steps x 4 row blocks, input features in natural order, each with its own
+    power-of-two scale."""
+    import numpy as np
+    from . import cond_nerf as CN
+    natural = np.arange(128).reshape(8, 2, 8)
+    parts, ews = [], []
+    for w in (wq, wk, wv):
+        w = (w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)).astype(np.float32)
+        assert w.shape == (128, 128), w.shape
+        ews.append(CN.f16_weight_exponent(w))
+        parts.append(CN._fragments_h(w, natural, 4, ews[-1]).reshape(-1))
+    return np.concatenate(parts).view(np.float32).copy(), tuple(int(e) for e in ews)
+
+
 class TransformerLayer(nn.Module):
-    """transformer.py:108-185 (single head, swin windows).  Inference runs q/k/v projections (library GEMMs), the
-    window-attention kernel (K6) and ONE kernel for everything after it (K7, ``mnerf_encoder_block``: merge, LayerNorm,
+    """transformer.py:108-185 (single head, swin windows).  Inference runs the q|k|v projections as one kernel
+    (``mnerf_qkv_projection``), the window-attention kernel (K6) and ONE kernel for everything after it (K7, ``mnerf_encoder_block``: merge, LayerNorm,
     concatenation, FFN with exact GELU, LayerNorm, residual); under autograd the reference's op chain is used."""
 
     def __init__(self, d_model=128, no_ffn=False, ffn_dim_expansion=4):
@@ -208,10 +224,28 @@ class TransformerLayer(nn.Module):
             self._blk = (key, torch.from_numpy(ws).to(device), ln.to(device), ews)
         return self._blk[1:]
 
-    def forward(self, source, target, h, w, splits, shifted):
-        q = self.q_proj(source)
-        k = self.k_proj(target)
-        v = self.v_proj(target)
+    def _packed_qkv(self, device):
+        ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
+        key = (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(device))
+        if getattr(self, "_qkv", None) is None or self._qkv[0] != key:
+            ws, ews = pack_qkv(*ps)
+            self._qkv = (key, torch.from_numpy(ws).to(device), ews)
+        return self._qkv[1:]
+
+    def forward(self, source, target, h, w, splits, shifted, kv_swap=False):
+        """``kv_swap`` (inference only): ``target`` is given un-swapped and read with its batch halves exchanged"""
+        params = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
+        if source.is_cuda and not (torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or
+                                                                any(p.requires_grad for p in params))):
+            ws, ews = self._packed_qkv(source.device)
+            q, k, v = hip.qkv_projection(ws, ews, source.contiguous(), target.contiguous(), kv_swap)  # one launch
+        else:
+            if kv_swap:
+                half = target.shape[0] // 2
+                target = torch.cat([target[half:], target[:half]], 0)
+            q = self.q_proj(source)
+            k = self.k_proj(target)
+            v = self.v_proj(target)
         msg = window_attention(q, k, v, h, w, splits, shifted)  # HIP forward; torch re-evaluation backward
         if not torch.is_grad_enabled() or not (msg.requires_grad or source.requires_grad or self.merge.weight.requires_grad):
             ws, ln, ews = self._packed_block(source.device)
@@ -245,13 +279,13 @@ class FeatureTransformer(nn.Module):
 
     def forward(self, src, n_pairs, h, w, splits, wo_self_attn=False):
         """src [2P, h*w, C] (first P = pair member a, last P = member b) -> same shape."""
-        tgt = torch.cat([src[n_pairs:], src[:n_pairs]], 0)
+        assert src.shape[0] == 2 * n_pairs
         for i, blk in enumerate(self.layers):
             shifted = (i % 2 == 1) and splits > 1
-            if not wo_self_attn:
+            blk_in = src  # the cross attention's keys / values come from the block INPUT of the other pair member:
+            if not wo_self_attn:  # its batch halves exchanged (transformer.py:317-335) - an index, not a torch.cat
                 src = blk.self_attn(src, src, h, w, splits, shifted)
-            src = blk.cross_attn_ffn(src, tgt, h, w, splits, shifted)
-            tgt = torch.cat([src[n_pairs:], src[:n_pairs]], 0)
+            src = blk.cross_attn_ffn(src, blk_in, h, w, splits, shifted, kv_swap=True)
         return src
 
 

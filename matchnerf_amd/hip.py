@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -134,6 +134,10 @@ def load():
     lib.mnerf_window_attention_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.mnerf_window_attention_presplit.restype = C.c_int
     lib.mnerf_window_attention_presplit.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
+    lib.mnerf_qkv_wstream_floats.restype = i64
+    lib.mnerf_qkv_wstream_floats.argtypes = []
+    lib.mnerf_qkv_projection.restype = C.c_int
+    lib.mnerf_qkv_projection.argtypes = [fp, C.POINTER(C.c_int32), fp, fp, i32, fp, fp, fp, i32, i32, vp]
     lib.mnerf_instance_norm.restype = C.c_int
     lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, fp, vp]
     lib.mnerf_conv_wstream_floats.restype = i64
@@ -460,6 +464,26 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
             check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                              int(bool(shifted)), math, st), "mnerf_window_attention")
     return out
+
+
+def qkv_projection(wstream, ews, x_q, x_kv=None, kv_swap=False, stream=None):
+    """q, k, v = Wq x_q, Wk x_kv', Wv x_kv' of a GMFlow transformer layer in one launch (transformer.py:147-151);
+    x_* [n_seq, seq_len, 128]; ``kv_swap``: x_kv' = x_kv with its batch halves exchanged.  wstream / ews from
+    gmflow.pack_qkv."""
+    import torch
+    lib = load()
+    x_kv = x_q if x_kv is None else x_kv
+    _f32c(x_q, "x_q"), _f32c(x_kv, "x_kv"), _f32c(wstream, "wstream")
+    if x_q.dim() != 3 or x_q.shape[2] != 128 or x_kv.shape != x_q.shape:
+        raise MnerfError(f"qkv_projection: expected two [n_seq, seq_len, 128] tensors, got {tuple(x_q.shape)}, {tuple(x_kv.shape)}")
+    if wstream.numel() != lib.mnerf_qkv_wstream_floats():
+        raise MnerfError(f"qkv_projection: wstream has {wstream.numel()} floats, expected {lib.mnerf_qkv_wstream_floats()}")
+    q, k, v = (torch.empty_like(x_q) for _ in range(3))
+    ew = (C.c_int32 * 3)(*[int(e) for e in ews])
+    with _on(x_q.device, stream) as st:
+        check(lib.mnerf_qkv_projection(_ptr(wstream), ew, _ptr(x_q), _ptr(x_kv), int(bool(kv_swap)), _ptr(q), _ptr(k),
+                                       _ptr(v), x_q.shape[0], x_q.shape[1], st), "mnerf_qkv_projection")
+    return q, k, v
 
 
 def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):

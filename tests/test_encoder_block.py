@@ -159,3 +159,26 @@ def test_layer_forward_uses_the_kernel_and_matches_autograd_path():
         fast = layer(src, tgt, 8, 12, 2, True)
     slow = layer(src.requires_grad_(True), tgt, 8, 12, 2, True)
     assert slow.requires_grad and float((fast - slow.detach()).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv_swap,n_seq,seq_len", [(False, 3, 70), (True, 4, 50), (True, 6, 1280)])
+def test_qkv_projection_matches_float64(kv_swap, n_seq, seq_len):
+    """one-launch q|k|v projections (csrc/qkv.hip) against a float64 evaluation; tokens of very different magnitude
+    (per-token gains), cross attention reading the other batch half through kv_swap"""
+    from matchnerf_amd import hip
+    from matchnerf_amd.gmflow import pack_qkv
+    gen = torch.Generator().manual_seed(n_seq * 10 + seq_len)
+    ws = [torch.randn(128, 128, generator=gen) * s for s in (0.09, 0.3, 0.02)]
+    x = torch.randn(n_seq, seq_len, 128, generator=gen) * 2.0 ** torch.randint(-6, 7, (n_seq, seq_len, 1), generator=gen).float()
+    y = torch.randn(n_seq, seq_len, 128, generator=gen)
+    stream, ews = pack_qkv(*ws)
+    q, k, v = hip.qkv_projection(torch.from_numpy(stream).cuda(), ews, x.cuda(), y.cuda(), kv_swap)
+    ys = torch.cat([y[n_seq // 2:], y[:n_seq // 2]], 0) if kv_swap else y
+    for got, inp, w in ((q, x, ws[0]), (k, ys, ws[1]), (v, ys, ws[2])):
+        want = inp.double() @ w.double().t()
+        ref32 = (inp @ w.t()).double()
+        scale = want.abs().amax(-1, keepdim=True).clamp_min(1e-30)
+        err = float(((got.cpu().double() - want).abs() / scale).max())
+        err32 = float(((ref32 - want).abs() / scale).max())
+        assert err < 4 * err32 + 1e-7, (err, err32)
