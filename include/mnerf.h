@@ -278,6 +278,8 @@ int mnerf_instance_norm(const float* x, const float* residual, float* out, int64
  *                 `in`: mnerf_instance_norm, mnerf_conv2d (out_absmax) or mnerf_absmax
  *   add_bilinear2x : NULL, or [n_img, c_out, h_out/2, w_out/2] NCHW whose bilinear 2x up-sampling (align_corners=False,
  *                 as F.interpolate) is added to the result (superres.py:37: right = up(right) + conv(left))
+ *   out_pair_major : 1 = write the cost volume's feature layout instead of NCHW: [n_img/2][2][h_out][w_out][c_out],
+ *                 image i of the batched pair members [a-sides; b-sides] at (pair i mod n_img/2, side i div n_img/2)
  *   out_absmax  : absmax region or NULL; max |out| is merged into it with atomic maxima (zero it first). */
 #define MNERF_ABSMAX_SLOTS 64   /* an "absmax region" = SLOTS partial maxima, STRIDE floats apart: 2048 floats, zeroed */
 #define MNERF_ABSMAX_STRIDE 32  /* by the caller; producers merge with atomic maxima, the convolution reduces the slots */
@@ -292,8 +294,8 @@ typedef struct mnerf_conv {
 } mnerf_conv;
 int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize);
 int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
-                 const float* in_absmax, const float* add_bilinear2x, float* out, float* out_absmax, int32_t n_img,
-                 int32_t h_in, int32_t w_in, void* stream);
+                 const float* in_absmax, const float* add_bilinear2x, float* out, int32_t out_pair_major,
+                 float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream);
 /* max |x| of n floats merged into the absmax region `out` (atomic maxima; zero it first) */
 int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 

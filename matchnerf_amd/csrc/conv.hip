@@ -38,6 +38,7 @@ struct ConvParams {
   long long sc, sy, sx, si;   // element strides of the stored input: channel, row, column, image
   int ew, seg_steps, n_seg;
   float leaky;                // LeakyReLU slope applied to the result (1 = none)
+  int out_pair_major;         // 1: write [n_img/2][2][h][w][c_out] (image i -> slot (i mod P, i div P)), channel-last
 };
 
 // NMB: 32-row blocks of output channels; CONV_TPW: 32-pixel tiles per wave (2, or 1 when that is what it takes to give
@@ -192,12 +193,16 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
     const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
     const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
     const float* up0 = P.add_up ? P.add_up + (long long)oimg[t] * (32 * NMB) * hs * ws : nullptr;
+    const int half_n = P.n_img >> 1;
+    const int pm_slot = oimg[t] < half_n ? 2 * oimg[t] : 2 * (oimg[t] - half_n) + 1;
+    const long long pm_base = ((long long)pm_slot * hw_out + (oy[t] * P.w_out + ox[t])) * (32 * NMB);
 #pragma unroll
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *reinterpret_cast<const float4*>(bias_lds + 32 * m + 8 * g + 4 * hl);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        float bb4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int ch = 32 * m + 8 * g + 4 * hl + q;
@@ -208,8 +213,11 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
             v = (ly0 * (lx0 * pl[y0 * ws + x0] + lx1 * pl[y0 * ws + x1]) + ly1 * (lx0 * pl[y1 * ws + x0] + lx1 * pl[y1 * ws + x1])) + v;
           }
           omax = fmaxf(omax, fabsf(v));
-          P.out[obase[t] + (long long)ch * hw_out] = v;
+          if (!P.out_pair_major) P.out[obase[t] + (long long)ch * hw_out] = v;
+          bb4[q] = v;
         }
+        if (P.out_pair_major)  // the cost volume's layout (include/mnerf.h, mnerf_scene.feat): 16 bytes per lane and store
+          *reinterpret_cast<float4*>(P.out + pm_base + 32 * m + 8 * g + 4 * hl) = make_float4(bb4[0], bb4[1], bb4[2], bb4[3]);
       }
   }
   if (P.out_absmax) {  // one atomic per workgroup into the tensor's absmax region
@@ -267,8 +275,8 @@ extern "C" int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_
 }
 
 extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
-                            const float* in_absmax, const float* add_bilinear2x, float* out, float* out_absmax,
-                            int32_t n_img, int32_t h_in, int32_t w_in, void* stream) {
+                            const float* in_absmax, const float* add_bilinear2x, float* out, int32_t out_pair_major,
+                            float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream) {
   const char* who = "mnerf_conv2d";
   MNERF_REQUIRE(cv, MNERF_E_NULL, "%s: cv is NULL", who);
   MNERF_REQUIRE(cv->c_in >= 32 && cv->c_in % 32 == 0 && (cv->c_out == 64 || cv->c_out == 96 || cv->c_out == 128) &&
@@ -313,6 +321,9 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.seg_steps = conv_seg_steps(n_steps, nmb);
   p.n_seg = n_steps / p.seg_steps;
   p.leaky = cv->leaky_slope;
+  p.out_pair_major = out_pair_major ? 1 : 0;
+  MNERF_REQUIRE(!out_pair_major || (n_img % 2 == 0 && mnerf_aligned16(out)), MNERF_E_RANGE,
+                "%s: pair-major output needs an even number of images and a 16-byte aligned buffer", who);
   const long long n_pix = (long long)n_img * p.h_out * p.w_out;
   // two pixel tiles per wave share every weight fragment read; one tile per wave when that grid would leave CUs idle
   const int tpw = (n_pix + 255) / 256 >= 256 ? 2 : 1;

@@ -298,10 +298,12 @@ class UpSampler(nn.Module):
         self.conv_ls = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks)])
         self.conv_l2rs = nn.ModuleList([nn.Conv2d(n_feat, n_feat, 3, 1, 1) for _ in range(self.n_blocks + 1)])
 
-    def forward_tokens(self, x_cl):
+    def forward_tokens(self, x_cl, pair_major=False):
         """Inference on channel-last tokens [N,h,w,C] (what the transformer leaves): the convolutions read them as they
         are, the nearest up-sampling in front of ``conv_ls`` is index arithmetic inside the convolution, LeakyReLU and the
-        bilinear up-sampling + add of the other branch are epilogues (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like ``forward``."""
+        bilinear up-sampling + add of the other branch are epilogues (csrc/conv.hip).  Returns NCHW [N,C,2^b h,2^b w] like
+        ``forward``, or with ``pair_major`` the layout the cost volume reads, [N/2, 2, H, W, C] (first / second batch half
+        = a / b member of every pair), written by the last convolution itself."""
         scal = hip.absmax_regions(self.n_blocks + 1, x_cl.device)
         hip.absmax(x_cl, scal[0])
         right = _hip_conv(self.conv_l2rs[0], x_cl, scal[0], channels_last=True)
@@ -311,7 +313,8 @@ class UpSampler(nn.Module):
                              out_absmax=scal[i + 1])
             left_cl = False
             # right = up_bilinear(right) + conv(left): the up-sampling and the add are the convolution's epilogue
-            right = _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1], add_bilinear2x=right)
+            right = _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1], add_bilinear2x=right,
+                              pair_major_out=pair_major and i == self.n_blocks - 1)
         return right
 
     def forward(self, x):
@@ -390,12 +393,14 @@ class GMFlow(nn.Module):
             src = torch.cat([tok[bi, ia], tok[bi, ib]], 0).contiguous()       # [2P, hw, C]
             src = self.transformer(src, p_n, h, w, splits, wo_self_attn)
             outs0.append(torch.stack([src[:p_n], src[p_n:]], 1).reshape(p_n, 2, h, w, ch))
-            if _fused_norm(src):
-                up = self.featup_net.forward_tokens(src.reshape(2 * p_n, h, w, ch))
+            if _fused_norm(src) and self.featup_net.n_blocks >= 1:
+                outs1.append(self.featup_net.forward_tokens(src.reshape(2 * p_n, h, w, ch), pair_major=True))
             else:
                 up = self.featup_net(src.reshape(2 * p_n, h, w, ch).permute(0, 3, 1, 2))  # [2P,C,2h,2w]
-            up = up.permute(0, 2, 3, 1)
-            outs1.append(torch.stack([up[:p_n], up[p_n:]], 1).contiguous())
+                up = up.permute(0, 2, 3, 1)
+                outs1.append(torch.stack([up[:p_n], up[p_n:]], 1).contiguous())
+        if b == 1:  # the usual case: no batch copy
+            return [outs0[0].unsqueeze(0).contiguous(), outs1[0].unsqueeze(0).contiguous()]
         return [torch.stack(outs0, 0).contiguous(), torch.stack(outs1, 0).contiguous()]
 
 

@@ -116,8 +116,11 @@ def test_upsampler_fused_path_matches_op_chain(hip):
     tok = torch.randn(2, 16, 24, 128, device="cuda")
     with torch.no_grad():
         fused = net.forward_tokens(tok)
+        pm = net.forward_tokens(tok, pair_major=True)
         chain = net(tok.permute(0, 3, 1, 2))
     assert float((fused - chain).abs().max()) < 1e-5 * float(chain.abs().max())
+    # the cost volume's layout, written by the last convolution itself: [pairs, side, H, W, C]
+    assert torch.equal(pm, torch.stack([fused[:1], fused[1:]], 1).permute(0, 1, 3, 4, 2))
 
 
 @pytest.mark.gpu
