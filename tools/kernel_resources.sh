@@ -2,7 +2,7 @@
 # usage: tools/kernel_resources.sh matchnerf_amd/csrc/decoder.hip [extra hipcc flags]
 # One line per kernel: VGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, occupancy.
 src=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$src" -o /dev/null "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-use-amdgpu-trackers=1 -c "$src" -o /dev/null "$@" \
   -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import re, sys
 cur = None
