@@ -278,8 +278,10 @@ int mnerf_instance_norm(const float* x, const float* residual, float* out, int64
  *                 `in`: mnerf_instance_norm, mnerf_conv2d (out_absmax) or mnerf_absmax
  *   add_bilinear2x : NULL, or [n_img, c_out, h_out/2, w_out/2] NCHW whose bilinear 2x up-sampling (align_corners=False,
  *                 as F.interpolate) is added to the result (superres.py:37: right = up(right) + conv(left))
- *   out_pair_major : 1 = write the cost volume's feature layout instead of NCHW: [n_img/2][2][h_out][w_out][c_out],
- *                 image i of the batched pair members [a-sides; b-sides] at (pair i mod n_img/2, side i div n_img/2)
+ *   out_layout  : MNERF_CONV_OUT_NCHW, _CHANNEL_LAST (the transformer's tokens) or _PAIR_MAJOR (image i of the batched
+ *                 pair members [a-sides; b-sides] goes to (pair i mod n_img/2, side i div n_img/2))
+ *   add_channel_last : NULL, or a [h_out*w_out][c_out] tile added to every image of a channel-last result (the window
+ *                 position embedding, gmflow/utils.py:68-88, fused into the backbone's last convolution)
  *   out_absmax  : absmax region or NULL; max |out| is merged into it with atomic maxima (zero it first). */
 #define MNERF_ABSMAX_SLOTS 64   /* an "absmax region" = SLOTS partial maxima, STRIDE floats apart: 2048 floats, zeroed */
 #define MNERF_ABSMAX_STRIDE 32  /* by the caller; producers merge with atomic maxima, the convolution reduces the slots */
@@ -293,9 +295,12 @@ typedef struct mnerf_conv {
   float leaky_slope;
 } mnerf_conv;
 int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize);
+#define MNERF_CONV_OUT_NCHW 0
+#define MNERF_CONV_OUT_CHANNEL_LAST 1 /* tokens [n_img][h_out][w_out][c_out] */
+#define MNERF_CONV_OUT_PAIR_MAJOR 2   /* the cost volume's feature layout [n_img/2][2][h_out][w_out][c_out] */
 int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
-                 const float* in_absmax, const float* add_bilinear2x, float* out, int32_t out_pair_major,
-                 float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream);
+                 const float* in_absmax, const float* add_bilinear2x, const float* add_channel_last, float* out,
+                 int32_t out_layout, float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream);
 /* max |x| of n floats merged into the absmax region `out` (atomic maxima; zero it first) */
 int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 

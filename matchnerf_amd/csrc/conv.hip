@@ -38,7 +38,8 @@ struct ConvParams {
   long long sc, sy, sx, si;   // element strides of the stored input: channel, row, column, image
   int ew, seg_steps, n_seg;
   float leaky;                // LeakyReLU slope applied to the result (1 = none)
-  int out_pair_major;         // 1: write [n_img/2][2][h][w][c_out] (image i -> slot (i mod P, i div P)), channel-last
+  int out_layout;             // MNERF_CONV_OUT_*: NCHW, channel-last tokens, pair-major channel-last
+  const float* add_cl;        // [h_out * w_out][c_out] added to a channel-last result (position tile), or NULL
 };
 
 // NMB: 32-row blocks of output channels; CONV_TPW: 32-pixel tiles per wave (2, or 1 when that is what it takes to give
@@ -193,9 +194,10 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
     const int y1 = y0 + (y0 < hs - 1 ? 1 : 0), x1 = x0 + (x0 < ws - 1 ? 1 : 0);
     const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
     const float* up0 = P.add_up ? P.add_up + (long long)oimg[t] * (32 * NMB) * hs * ws : nullptr;
+    // channel-last image slot: the image itself, or (pair i mod P, side i div P) of the cost volume's pair-major layout
     const int half_n = P.n_img >> 1;
-    const int pm_slot = oimg[t] < half_n ? 2 * oimg[t] : 2 * (oimg[t] - half_n) + 1;
-    const long long pm_base = ((long long)pm_slot * hw_out + (oy[t] * P.w_out + ox[t])) * (32 * NMB);
+    const int cl_slot = P.out_layout != MNERF_CONV_OUT_PAIR_MAJOR ? oimg[t] : (oimg[t] < half_n ? 2 * oimg[t] : 2 * (oimg[t] - half_n) + 1);
+    const long long cl_base = ((long long)cl_slot * hw_out + (oy[t] * P.w_out + ox[t])) * (32 * NMB);
 #pragma unroll
     for (int m = 0; m < NMB; ++m)
 #pragma unroll
@@ -212,12 +214,21 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
             const float* pl = up0 + (long long)ch * hs * ws;
             v = (ly0 * (lx0 * pl[y0 * ws + x0] + lx1 * pl[y0 * ws + x1]) + ly1 * (lx0 * pl[y1 * ws + x0] + lx1 * pl[y1 * ws + x1])) + v;
           }
-          omax = fmaxf(omax, fabsf(v));
-          if (!P.out_pair_major) P.out[obase[t] + (long long)ch * hw_out] = v;
+          if (P.out_layout == MNERF_CONV_OUT_NCHW) {
+            omax = fmaxf(omax, fabsf(v));
+            P.out[obase[t] + (long long)ch * hw_out] = v;
+          }
           bb4[q] = v;
         }
-        if (P.out_pair_major)  // the cost volume's layout (include/mnerf.h, mnerf_scene.feat): 16 bytes per lane and store
-          *reinterpret_cast<float4*>(P.out + pm_base + 32 * m + 8 * g + 4 * hl) = make_float4(bb4[0], bb4[1], bb4[2], bb4[3]);
+        if (P.out_layout != MNERF_CONV_OUT_NCHW) {  // channel-last: 16 bytes per lane and store
+          const int c0 = 32 * m + 8 * g + 4 * hl;
+          if (P.add_cl) {
+            const float4 a4 = *reinterpret_cast<const float4*>(P.add_cl + (long long)(oy[t] * P.w_out + ox[t]) * (32 * NMB) + c0);
+            bb4[0] += a4.x; bb4[1] += a4.y; bb4[2] += a4.z; bb4[3] += a4.w;
+          }
+          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(bb4[0]), fabsf(bb4[1]))), fmaxf(fabsf(bb4[2]), fabsf(bb4[3])));
+          *reinterpret_cast<float4*>(P.out + cl_base + c0) = make_float4(bb4[0], bb4[1], bb4[2], bb4[3]);
+        }
       }
   }
   if (P.out_absmax) {  // one atomic per workgroup into the tensor's absmax region
@@ -275,8 +286,9 @@ extern "C" int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_
 }
 
 extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
-                            const float* in_absmax, const float* add_bilinear2x, float* out, int32_t out_pair_major,
-                            float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream) {
+                            const float* in_absmax, const float* add_bilinear2x, const float* add_channel_last,
+                            float* out, int32_t out_layout, float* out_absmax, int32_t n_img, int32_t h_in,
+                            int32_t w_in, void* stream) {
   const char* who = "mnerf_conv2d";
   MNERF_REQUIRE(cv, MNERF_E_NULL, "%s: cv is NULL", who);
   MNERF_REQUIRE(cv->c_in >= 32 && cv->c_in % 32 == 0 && (cv->c_out == 64 || cv->c_out == 96 || cv->c_out == 128) &&
@@ -321,9 +333,16 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.seg_steps = conv_seg_steps(n_steps, nmb);
   p.n_seg = n_steps / p.seg_steps;
   p.leaky = cv->leaky_slope;
-  p.out_pair_major = out_pair_major ? 1 : 0;
-  MNERF_REQUIRE(!out_pair_major || (n_img % 2 == 0 && mnerf_aligned16(out)), MNERF_E_RANGE,
-                "%s: pair-major output needs an even number of images and a 16-byte aligned buffer", who);
+  MNERF_REQUIRE(out_layout == MNERF_CONV_OUT_NCHW || out_layout == MNERF_CONV_OUT_CHANNEL_LAST ||
+                    out_layout == MNERF_CONV_OUT_PAIR_MAJOR, MNERF_E_RANGE, "%s: out_layout=%d", who, out_layout);
+  p.out_layout = out_layout;
+  p.add_cl = add_channel_last;
+  MNERF_REQUIRE(out_layout == MNERF_CONV_OUT_NCHW || mnerf_aligned16(out), MNERF_E_ALIGN,
+                "%s: a channel-last output must be 16-byte aligned", who);
+  MNERF_REQUIRE(out_layout != MNERF_CONV_OUT_PAIR_MAJOR || n_img % 2 == 0, MNERF_E_RANGE,
+                "%s: pair-major output needs an even number of images, got %d", who, n_img);
+  MNERF_REQUIRE(!add_channel_last || (out_layout != MNERF_CONV_OUT_NCHW && mnerf_aligned16(add_channel_last)), MNERF_E_RANGE,
+                "%s: add_channel_last needs a channel-last output layout and a 16-byte aligned tile", who);
   const long long n_pix = (long long)n_img * p.h_out * p.w_out;
   // two pixel tiles per wave share every weight fragment read; one tile per wave when that grid would leave CUs idle
   const int tpw = (n_pix + 255) / 256 >= 256 ? 2 : 1;

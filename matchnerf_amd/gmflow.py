@@ -122,7 +122,9 @@ class CNNEncoder(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x):
+    def forward(self, x, tokens_plus=None):
+        """``tokens_plus`` (inference): a [h*w, C] tile; the result is then the transformer's channel-last tokens
+        [N,h,w,C] with the tile added - layout change and position embedding are the last convolution's epilogue."""
         if _fused_norm(x):
             # the 7x7 stem (3 input channels) stays a library call; everything after it is HIP: 14 convolutions, 15 norms
             scal = hip.absmax_regions(13, x.device)  # max|.| of every convolution input (one fill kernel)
@@ -133,10 +135,12 @@ class CNNEncoder(nn.Module):
                 for blk in layer:
                     x, amax = blk.forward_fused(x, amax, scal[k:k + 2])
                     k += 2
+            if tokens_plus is not None:
+                return _hip_conv(self.conv2, x, amax, out_layout=hip.CONV_OUT_CHANNEL_LAST, add_channel_last=tokens_plus)
             return _hip_conv(self.conv2, x, amax)
         x = F.relu(F.instance_norm(self.conv1(x)))
-        x = self.layer3(self.layer2(self.layer1(x)))
-        return self.conv2(x)
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return x if tokens_plus is None else x.permute(0, 2, 3, 1) + tokens_plus.reshape(x.shape[2], x.shape[3], -1)
 
 
 EB_SEG_FLOATS = 32 * 256  # one weight segment of the encoder block kernel: 4 K16-steps x 4 blocks x [hi | lo] x 1 KiB
@@ -313,8 +317,9 @@ class UpSampler(nn.Module):
                              out_absmax=scal[i + 1])
             left_cl = False
             # right = up_bilinear(right) + conv(left): the up-sampling and the add are the convolution's epilogue
+            last = pair_major and i == self.n_blocks - 1
             right = _hip_conv(self.conv_l2rs[i + 1], left, scal[i + 1], add_bilinear2x=right,
-                              pair_major_out=pair_major and i == self.n_blocks - 1)
+                              out_layout=hip.CONV_OUT_PAIR_MAJOR if last else hip.CONV_OUT_NCHW)
         return right
 
     def forward(self, x):
@@ -377,13 +382,14 @@ class GMFlow(nn.Module):
         x = imgs.reshape(b * v, c, hh, ww)
         if hh == 756 and ww == 1008:  # IBRNet setting, gmflow.py:100-103
             x = F.interpolate(x, size=(768, 1024), mode="bilinear", align_corners=True)
-        feat = self.backbone((x - self._mean) / self._std)                    # [BV,128,h,w]
-        _, ch, h, w = feat.shape
+        h, w, ch = x.shape[2] // 8, x.shape[3] // 8, self.feature_channels
         if h % splits or w % splits:
             raise ValueError(f"feature map {h}x{w} is not divisible by attn_splits={splits}")
-        tok = feat.permute(0, 2, 3, 1)                                        # [BV,h,w,C] view
-        pe = sine_position_tokens(h // splits, w // splits, ch, feat.device).repeat(splits, splits, 1)
-        tok = (tok + pe).reshape(b, v, h * w, ch)
+        pe = sine_position_tokens(h // splits, w // splits, ch, x.device).repeat(splits, splits, 1).reshape(h * w, ch).contiguous()
+        # [BV,h,w,C] tokens with the window position tile added (by the backbone's last convolution at inference)
+        tok = self.backbone((x - self._mean) / self._std, tokens_plus=pe)
+        assert tuple(tok.shape[1:]) == (h, w, ch), tok.shape
+        tok = tok.reshape(b, v, h * w, ch)
         pairs = pair_list(v)
         ia = torch.tensor([a for a, _ in pairs], device=feat.device)
         ib = torch.tensor([bb for _, bb in pairs], device=feat.device)

@@ -67,6 +67,7 @@ WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
 WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
 WA_PRESPLIT_F16 = 3  # host-side selector only: routed to mnerf_window_attention_presplit
 ABSMAX_FLOATS = 64 * 32  # floats of one absmax region (MNERF_ABSMAX_FLOATS)
+CONV_OUT_NCHW, CONV_OUT_CHANNEL_LAST, CONV_OUT_PAIR_MAJOR = 0, 1, 2
 
 
 class ConvLayer(C.Structure):
@@ -143,7 +144,7 @@ def load():
     lib.mnerf_conv_wstream_floats.restype = i64
     lib.mnerf_conv_wstream_floats.argtypes = [i32, i32, i32]
     lib.mnerf_conv2d.restype = C.c_int
-    lib.mnerf_conv2d.argtypes = [C.POINTER(ConvLayer), fp, i32, i32, fp, fp, fp, i32, fp, i32, i32, i32, vp]
+    lib.mnerf_conv2d.argtypes = [C.POINTER(ConvLayer), fp, i32, i32, fp, fp, fp, fp, i32, fp, i32, i32, i32, vp]
     lib.mnerf_absmax.restype = C.c_int
     lib.mnerf_absmax.argtypes = [fp, i64, fp, vp]
     lib.mnerf_encoder_block_wstream_floats.restype = i64
@@ -530,11 +531,13 @@ def absmax(x, out, stream=None):
 
 
 def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.0, channels_last=False, upsample2x=False,
-           add_bilinear2x=None, pair_major_out=False, out_absmax=None, out=None, stream=None):
+           add_bilinear2x=None, out_layout=CONV_OUT_NCHW, add_channel_last=None, out_absmax=None, out=None, stream=None):
     """Split-fp16 implicit-GEMM convolution (csrc/conv.hip; gmflow/backbone.py, superres.py).  x [N,c_in,H,W], or
     [N,H,W,c_in] with ``channels_last``; ``wstream`` from gmflow.pack_conv; ``in_absmax``: absmax region filled by the
     producer of x; ``add_bilinear2x`` [N,c_out,H_out/2,W_out/2]: its bilinear 2x up-sampling is added to the result.
-    Returns [N,c_out,H_out,W_out], or with ``pair_major_out`` the cost volume's layout [N/2,2,H_out,W_out,c_out]."""
+    ``out_layout``: CONV_OUT_NCHW -> [N,c_out,H_out,W_out]; CONV_OUT_CHANNEL_LAST -> tokens [N,H_out,W_out,c_out]
+    (+ ``add_channel_last`` [H_out*W_out, c_out] added to every image); CONV_OUT_PAIR_MAJOR -> the cost volume's layout
+    [N/2,2,H_out,W_out,c_out]."""
     import torch
     lib = load()
     _f32c(x, "x"), _f32c(wstream, "wstream")
@@ -552,15 +555,21 @@ def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.
         if tuple(add_bilinear2x.shape) != (n, c_out, h_out // 2, w_out // 2):
             raise MnerfError(f"conv2d: add_bilinear2x {tuple(add_bilinear2x.shape)} vs output {(n, c_out, h_out, w_out)}")
     if out is None:
-        shape = (n // 2, 2, h_out, w_out, c_out) if pair_major_out else (n, c_out, h_out, w_out)
+        shape = {CONV_OUT_NCHW: (n, c_out, h_out, w_out), CONV_OUT_CHANNEL_LAST: (n, h_out, w_out, c_out),
+                 CONV_OUT_PAIR_MAJOR: (n // 2, 2, h_out, w_out, c_out)}[out_layout]
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    if add_channel_last is not None:
+        _f32c(add_channel_last, "add_channel_last")
+        if add_channel_last.numel() != h_out * w_out * c_out:
+            raise MnerfError(f"conv2d: add_channel_last {tuple(add_channel_last.shape)} vs {(h_out * w_out, c_out)}")
     cv = ConvLayer()
     cv.wstream, cv.wstream_floats = wstream.data_ptr(), wstream.numel()
     cv.bias = bias.data_ptr() if bias is not None else None
     cv.c_in, cv.c_out, cv.ksize, cv.stride, cv.ew, cv.leaky_slope = c_in, c_out, ksize, stride, int(ew), float(leaky)
     with _on(x.device, stream) as st:
         check(lib.mnerf_conv2d(C.byref(cv), _ptr(x), int(bool(channels_last)), up, _ptr(in_absmax), _ptr(add_bilinear2x),
-                               _ptr(out), int(bool(pair_major_out)), _ptr(out_absmax), n, h, w, st), "mnerf_conv2d")
+                               _ptr(add_channel_last), _ptr(out), int(out_layout), _ptr(out_absmax), n, h, w, st),
+              "mnerf_conv2d")
     return out
 
 

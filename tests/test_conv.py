@@ -109,6 +109,25 @@ def test_conv2d_adds_bilinear_upsampling(hip):
 
 
 @pytest.mark.gpu
+def test_conv2d_channel_last_tokens_with_position_tile(hip):
+    """the backbone's last convolution writes the transformer's tokens and adds the window position tile"""
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 128, 10, 12, generator=gen)
+    wt = torch.randn(128, 128, 1, 1, generator=gen) * 0.1
+    bias = torch.randn(128, generator=gen)
+    tile = torch.randn(120, 128, generator=gen)
+    ws, ew = G.pack_conv(wt)
+    scal = hip.absmax_regions(2, "cuda")
+    hip.absmax(x.cuda(), scal[0])
+    got = hip.conv2d(x.cuda(), torch.from_numpy(ws).cuda(), bias.cuda(), 128, 128, 1, 1, ew, scal[0],
+                     out_layout=hip.CONV_OUT_CHANNEL_LAST, add_channel_last=tile.cuda(), out_absmax=scal[1])
+    want = F.conv2d(x.double(), wt.double(), bias.double()).permute(0, 2, 3, 1) + tile.double().reshape(10, 12, 128)
+    assert got.shape == (3, 10, 12, 128)
+    assert float((got.cpu().double() - want).abs().max()) < 3e-6 * float(want.abs().max())
+    assert float(hip.absmax_value(scal[1])) == float(got.abs().max())
+
+
+@pytest.mark.gpu
 def test_upsampler_fused_path_matches_op_chain(hip):
     from matchnerf_amd.gmflow import UpSampler
     torch.manual_seed(1)
