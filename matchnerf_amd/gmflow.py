@@ -391,8 +391,8 @@ class GMFlow(nn.Module):
         assert tuple(tok.shape[1:]) == (h, w, ch), tok.shape
         tok = tok.reshape(b, v, h * w, ch)
         pairs = pair_list(v)
-        ia = torch.tensor([a for a, _ in pairs], device=feat.device)
-        ib = torch.tensor([bb for _, bb in pairs], device=feat.device)
+        ia = torch.tensor([a for a, _ in pairs], device=tok.device)
+        ib = torch.tensor([bb for _, bb in pairs], device=tok.device)
         p_n = len(pairs)
         outs0, outs1 = [], []
         for bi in range(b):
