@@ -985,290 +985,6 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
   }
 }
 
-template <int NQW>
-__global__ __launch_bounds__(NQW * 64, 2) void window_attention_pipe_kernel(
-    const float* __restrict__ q, const u32x4* __restrict__ img, const int* __restrict__ gains,
-    float* __restrict__ out, WinGeom G, int shifted, float scale, int n_batch, int xcd_map, unsigned long long* tl) {
-  extern __shared__ __attribute__((aligned(16))) float wa_smem[];  // three images: 96 KiB
-  const unsigned smem0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wa_smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 31, hl = lane >> 5;
-  // 1-D grid, XCD-aware: workgroups go to the 8 XCDs round-robin by their linear id, so id = 8 * slot + xcd; all query
-  // blocks of one window get the same xcd - the window's K / V images (1.3 MB at 1280 tokens) are then fetched into
-  // ONE L2 and hit there by its other query blocks, instead of missing in all eight
-  const int n_win = G.splits * G.splits;
-  const int n_qb = (G.Lw + NQW * 32 - 1) / (NQW * 32);
-  const int slot = xcd_map ? blockIdx.x >> 3 : blockIdx.x, wl = slot / n_qb;
-  const int qblock = slot - wl * n_qb, gwin = xcd_map ? wl * 8 + (blockIdx.x & 7) : wl;
-  if (gwin >= n_win * n_batch) return;
-  const int b = gwin / n_win, win = gwin - b * n_win;
-  const int wy = win / G.splits, wx = win - wy * G.splits;
-  const size_t seq_base = (size_t)b * G.h * G.w * WA_C;
-
-  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
-  const size_t tile0 = (size_t)gwin * n_tiles;
-  const u32x4* img_win = img + tile0 * (WA_IMG_BYTES / 16);
-  const int4* rec_win = reinterpret_cast<const int4*>(gains + WA_REC_INTS * tile0);
-  const int last_tile = n_tiles - 1;
-  wa_stage_image<NQW>(img_win, smem0, wave, lane);
-  wa_stage_image<NQW>(img_win + (size_t)(1 < n_tiles ? 1 : 0) * (WA_IMG_BYTES / 16), smem0 + WA_IMG_BYTES, wave, lane);
-  int4 ra = rec_win[0], rb = rec_win[1];  // (ek, ev, regions 0-7, 8-15), (regions 16-23, 24-31, -, -)
-
-  // ---- this lane's query, split once: K-step t holds channels 16t + 8 hl + j
-  const int qi_raw = (qblock * NQW + wave) * 32 + n;
-  const bool q_ok = qi_raw < G.Lw;
-  int q_region;
-  const int q_tok = win_token(G, wy, wx, q_ok ? qi_raw : (G.Lw - 1), q_region);
-  PartsH qp[8];
-  int eq;
-  {
-    const float4* src = reinterpret_cast<const float4*>(q + seq_base + (size_t)q_tok * WA_C + hl * 8);
-    float qv[64];
-    float qmax = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const float4 a = src[4 * t], c = src[4 * t + 1];
-      qv[8 * t + 0] = a.x; qv[8 * t + 1] = a.y; qv[8 * t + 2] = a.z; qv[8 * t + 3] = a.w;
-      qv[8 * t + 4] = c.x; qv[8 * t + 5] = c.y; qv[8 * t + 6] = c.z; qv[8 * t + 7] = c.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 64; ++i) qmax = fmaxf(qmax, fabsf(qv[i]));
-    qmax = fmaxf(qmax, __shfl_xor(qmax, 32, 64));
-    eq = gain_exp(qmax);
-    const float mq = pow2i(eq);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float v8[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v8[j] = qv[8 * t + j];
-      qp[t] = split8h(v8, mq);
-    }
-  }
-  f32x16 o[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) o[m] = (f32x16)(0.0f);
-  float m_run = -3.0e38f, l_run = 0.0f;
-  int ev_run = 0;  // V gain exponent the output accumulator currently carries (irrelevant while o == 0)
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- two-tile software pipeline: the 24 matrix instructions of the scores of tile t+1 are issued between the
-  // softmax instructions of tile t (one wave per SIMD: the phases of one tile cannot overlap each other).  Image t+2 is
-  // in flight meanwhile: three LDS images (t: V fragments, t+1: K fragments, t+2: landing).
-  constexpr int PPS = (WA_IMG_BYTES / 1024) / NQW / 8;  // pieces per slot and wave
-  const float l2e = 1.44269504088896f;
-  const float mask_l2 = -100.0f * l2e;
-  const bool ragged = (G.Lw & (WA_KT - 1)) != 0;
-#define WA_SLOT(slot)                                                                        \
-  do {                                                                                       \
-    _Pragma("unroll") for (int pp_ = 0; pp_ < PPS; ++pp_) {                                  \
-      const int piece = wave + NQW * ((slot)*PPS + pp_);                                     \
-      wa_glds16(reinterpret_cast<const float*>(img_next + piece * 64),                       \
-                __builtin_amdgcn_readfirstlane(lds_next + (unsigned)piece * 1024u));         \
-    }                                                                                        \
-  } while (0)
-  // K16-step group g (four steps) of the scores of the image at `kf`: three rows of four matrix instructions
-#define WA_ROW_LOHI(g) _Pragma("unroll") for (int a = 0; a < 4; ++a) sa[a & 1] = mfma16h(klo[a], qp[4 * (g) + a].hi, sa[a & 1])
-#define WA_ROW_HILO(g) _Pragma("unroll") for (int a = 0; a < 4; ++a) sa[a & 1] = mfma16h(khi[a], qp[4 * (g) + a].lo, sa[a & 1])
-#define WA_ROW_HIHI(g) _Pragma("unroll") for (int a = 0; a < 4; ++a) sa[a & 1] = mfma16h(khi[a], qp[4 * (g) + a].hi, sa[a & 1])
-#define WA_KREAD(g)                                                                \
-  _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                  \
-    klo[a] = __builtin_bit_cast(f16x8, kf[(2 * (4 * (g) + a) + 1) * 64]);          \
-    khi[a] = __builtin_bit_cast(f16x8, kf[(2 * (4 * (g) + a)) * 64]);              \
-  }
-  // one matrix instruction, then `n` VALU instructions, four times: the order the wave should issue a row in
-#define WA_MIX(n)                                             \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {          \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        \
-    __builtin_amdgcn_sched_group_barrier(0x002, (n), 0);      \
-  }
-
-  f32x16 s;  // scores of the current tile (raw sums)
-  {          // scores of tile 0
-    lds_u32x4_cptr kf = (lds_u32x4_cptr)(size_t)smem0 + lane;
-    f32x16 sa[2] = {(f32x16)(0.0f), (f32x16)(0.0f)};
-    f16x8 khi[4], klo[4];
-    WA_KREAD(0);
-    WA_ROW_LOHI(0);
-    WA_ROW_HILO(0);
-    WA_ROW_HIHI(0);
-    WA_KREAD(1);
-    WA_ROW_LOHI(1);
-    WA_ROW_HILO(1);
-    WA_ROW_HIHI(1);
-    s = sa[0] + sa[1];
-  }
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    const int kn = kt + 1 < n_tiles ? kt + 1 : last_tile;   // the last iteration repeats its own scores (discarded)
-    const int kd = kt + 2 < n_tiles ? kt + 2 : last_tile;   // ... and re-fetches the last image into the idle buffer
-    const u32x4* img_next = img_win + (size_t)kd * (WA_IMG_BYTES / 16) + lane;
-    const unsigned lds_next = smem0 + (unsigned)((kt + 2) % 3) * WA_IMG_BYTES;
-    lds_u32x4_cptr kf = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)(kt + 1 < n_tiles ? (kt + 1) % 3 : kt % 3) * WA_IMG_BYTES) + lane;
-    lds_u32x4_cptr frag = (lds_u32x4_cptr)(size_t)(smem0 + (unsigned)(kt % 3) * WA_IMG_BYTES) + lane;
-    const int ek = ra.x, ev = ra.y;
-    const unsigned regw[4] = {(unsigned)ra.z, (unsigned)ra.w, (unsigned)rb.x, (unsigned)rb.y};
-    const int4 ra_next = rec_win[2 * kn], rb_next = rec_win[2 * kn + 1];
-    // V fragments of the first key half: requested now, used after the softmax
-    f16x8 vhi[4], vlo[4], vhi1[4], vlo1[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      vlo[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * m + 1) * 64]);
-      vhi[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * m) * 64]);
-    }
-    f32x16 sa[2] = {(f32x16)(0.0f), (f32x16)(0.0f)};
-    f16x8 khi[4], klo[4];
-    WA_KREAD(0);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- softmax of tile kt (log2 domain) with the scores of tile kt+1 underneath
-    const float sscale = scale * l2e * pow2i(-(ek + eq));
-    WA_ROW_LOHI(0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      float sv = s[r] * sscale;
-      if (shifted) {
-        const int kreg = (int)((regw[r >> 2] >> (4 * (r & 3) + 16 * hl)) & 15u);
-        if (kreg != q_region) sv += mask_l2;
-      }
-      s[r] = sv;
-    }
-    WA_MIX(6);
-    WA_SLOT(0);
-    __builtin_amdgcn_sched_barrier(0);
-    WA_ROW_HILO(0);
-#pragma unroll
-    for (int r = 8; r < 16; ++r) {
-      float sv = s[r] * sscale;
-      if (shifted) {
-        const int kreg = (int)((regw[r >> 2] >> (4 * (r & 3) + 16 * hl)) & 15u);
-        if (kreg != q_region) sv += mask_l2;
-      }
-      s[r] = sv;
-    }
-    if (ragged && kt == last_tile) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kt * WA_KT + (r & 3) + 8 * (r >> 2) + 4 * hl >= G.Lw) s[r] = -3.0e38f;
-    }
-    WA_MIX(6);
-    WA_SLOT(1);
-    __builtin_amdgcn_sched_barrier(0);
-    WA_ROW_HIHI(0);
-    float tmax = -3.0e38f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-    {
-      float lo, hi;
-      wa_halves(tmax, lo, hi);
-      tmax = fmaxf(lo, hi);
-    }
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    WA_MIX(4);
-    WA_SLOT(2);
-    __builtin_amdgcn_sched_barrier(0);
-    WA_KREAD(1);
-    WA_ROW_LOHI(1);
-    float psum = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
-      s[r] = p;
-      psum += p;
-    }
-    WA_MIX(5);
-    WA_SLOT(3);
-    __builtin_amdgcn_sched_barrier(0);
-    WA_ROW_HILO(1);
-#pragma unroll
-    for (int r = 8; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
-      s[r] = p;
-      psum += p;
-    }
-    WA_MIX(5);
-    WA_SLOT(4);
-    __builtin_amdgcn_sched_barrier(0);
-    WA_ROW_HIHI(1);
-    {
-      float lo, hi;
-      wa_halves(psum, lo, hi);
-      psum = lo + hi;
-    }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    // the softmax correction and the change of V gain ride in one multiplication
-    const float corr = alpha * pow2i(ev - ev_run);
-    ev_run = ev;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[m][r] *= corr;
-    WA_MIX(16);
-    WA_SLOT(5);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- O^T += V^T P^T of tile kt
-    {
-      float pv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = s[j];
-      const PartsH pp = split8h(pv, 16384.0f);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo[m], pp.hi, o[m]);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) vlo1[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 + m) + 1) * 64]);
-      WA_SLOT(6);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.lo, o[m]);
-      WA_SLOT(7);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi[m], pp.hi, o[m]);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) vhi1[m] = __builtin_bit_cast(f16x8, frag[(WA_IMG_VOFF / 64 + 2 * (4 + m)) * 64]);
-    }
-    {
-      float pv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pv[j] = s[8 + j];
-      const PartsH pp = split8h(pv, 16384.0f);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vlo1[m], pp.hi, o[m]);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi1[m], pp.lo, o[m]);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) o[m] = mfma16h(vhi1[m], pp.hi, o[m]);
-    }
-    s = sa[0] + sa[1];  // scores of tile kt + 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ra = ra_next;
-    rb = rb_next;
-  }
-#undef WA_SLOT
-#undef WA_ROW_LOHI
-#undef WA_ROW_HILO
-#undef WA_ROW_HIHI
-#undef WA_KREAD
-#undef WA_MIX
-  if (q_ok) {
-    const float inv_l = pow2i(-(ev_run + 14)) / l_run;
-    float* dst = out + seq_base + (size_t)q_tok * WA_C;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 t = make_float4(o[m][4 * g4] * inv_l, o[m][4 * g4 + 1] * inv_l,
-                                     o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
-        *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
-      }
-  }
-}
-
 static int wa_geometry(const char* who, int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
                        WinGeom& G, int& do_shift) {
   MNERF_REQUIRE(batch >= 0 && h >= 1 && w >= 1 && num_splits >= 1, MNERF_E_RANGE, "%s: batch=%d h=%d w=%d splits=%d",
@@ -1332,18 +1048,7 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
   const bool four = wgs4 >= mnerf_tune().wa_min4;
   const int n_qb = four ? (G.Lw + 127) / 128 : (G.Lw + 63) / 64;
   const dim3 grid((unsigned)(8 * win_groups * n_qb));
-  if (mnerf_tune().wa_pipe) {
-    const size_t lds3 = 3 * WA_IMG_BYTES;
-    static std::atomic<unsigned long long> attr3{0};
-    if (mnerf_once_per_device(attr3)) {
-      (void)hipFuncSetAttribute((const void*)window_attention_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      (void)hipFuncSetAttribute((const void*)window_attention_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-    }
-    if (four)
-      hipLaunchKernelGGL(window_attention_pipe_kernel<4>, grid, dim3(256), lds3, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
-    else
-      hipLaunchKernelGGL(window_attention_pipe_kernel<2>, grid, dim3(128), lds3, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
-  } else if (four)
+  if (four)
     hipLaunchKernelGGL(window_attention_pre_kernel<4>, grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
   else
     hipLaunchKernelGGL(window_attention_pre_kernel<2>, grid, dim3(128), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
