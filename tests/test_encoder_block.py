@@ -182,3 +182,23 @@ def test_qkv_projection_matches_float64(kv_swap, n_seq, seq_len):
         err = float(((got.cpu().double() - want).abs() / scale).max())
         err32 = float(((ref32 - want).abs() / scale).max())
         assert err < 4 * err32 + 1e-7, (err, err32)
+
+
+def test_pack_qkv_encodes_three_scaled_matrices():
+    """CPU: the q|k|v stream decodes back to the three weight matrices (fragment layout of csrc/qkv.hip: unit (step t,
+    block m) = [hi | lo] x 64 lanes x 8, lane (n, half) holds W[32 m + n][16 t + 8 half + j] * 2^ew)."""
+    rng = np.random.default_rng(4)
+    ws = [(rng.standard_normal((128, 128)) * s).astype(np.float32) for s in (0.05, 1.7, 0.004)]
+    stream, ews = G.pack_qkv(*ws)
+    assert stream.size == 3 * 8 * 4 * 512 and len(ews) == 3
+    halfs = stream.view(np.float16).reshape(3, 8, 4, 2, 64, 8).astype(np.float64)
+    lane = np.arange(64)
+    for p in range(3):
+        full = halfs[p, :, :, 0] + halfs[p, :, :, 1]                      # [t, m, lane, j]
+        mat = np.zeros((128, 128))
+        for t in range(8):
+            for m in range(4):
+                for j in range(8):
+                    mat[32 * m + (lane & 31), 16 * t + 8 * (lane >> 5) + j] = full[t, m, lane, j]
+        assert np.abs(np.ldexp(mat, -ews[p]) - ws[p]).max() < 2.0 ** -20 * np.abs(ws[p]).max()
+        assert 2.0 ** 13 <= np.abs(np.ldexp(ws[p].astype(np.float64), ews[p])).max() < 2.0 ** 14 * 1.0001
