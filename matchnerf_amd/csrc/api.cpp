@@ -47,7 +47,6 @@ static mnerf_tuning read_tuning() {
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = plain
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
-  t.conv_stagger = env_int("MNERF_CONV_STAGGER", 0);
   t.wa_xcd = env_int("MNERF_WA_XCD", 1);          // query blocks of a window share an XCD (its L2 holds the K / V images)
   t.render_fused = env_int("MNERF_RENDER_FUSED", 0);  // 1: mnerf_render_chunk takes the one-launch form where it applies
   return t;

@@ -37,7 +37,6 @@ struct mnerf_tuning {
   int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
   int wa_min4;
-  int conv_stagger;  // split-fp16 convolution: start delay of the second resident workgroup of a CU (x 64 cycles)
   int wa_xcd;  // pre-split window attention: all query blocks of a window on one XCD (1) or launch order (0)
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies
 };

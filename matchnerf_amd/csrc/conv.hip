@@ -38,7 +38,6 @@ struct ConvParams {
   long long sc, sy, sx, si;   // element strides of the stored input: channel, row, column, image
   int ew, seg_steps, n_seg;
   float leaky;                // LeakyReLU slope applied to the result (1 = none)
-  int stagger;                // start delay (x s_sleep 1 = 64 cycles) of the workgroup in the odd hardware wave slot
   int out_layout;             // MNERF_CONV_OUT_*: NCHW, channel-last tokens, pair-major channel-last
   const float* add_cl;        // [h_out * w_out][c_out] added to a channel-last result (position tile), or NULL
 };
@@ -62,11 +61,6 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
       glds16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
   };
   stage(0);
-  // Two workgroups share a CU (one wave of each per SIMD).  Started together they run in phase - both splitting
-  // operands, then both issuing matrix instructions; the one in the odd hardware wave slot waits half an iteration once
-  // (decoder.hip, "Phase stagger").  Speed only.
-  if (P.stagger > 0 && (__builtin_amdgcn_s_getreg((4) | (0 << 6) | (3 << 11)) & 1u))
-    for (int i = 0; i < P.stagger; ++i) __builtin_amdgcn_s_sleep(1);
 
   // ---- this lane's output pixels
   const int hw_out = P.h_out * P.w_out;
@@ -339,7 +333,6 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.seg_steps = conv_seg_steps(n_steps, nmb);
   p.n_seg = n_steps / p.seg_steps;
   p.leaky = cv->leaky_slope;
-  p.stagger = mnerf_tune().conv_stagger;
   MNERF_REQUIRE(out_layout == MNERF_CONV_OUT_NCHW || out_layout == MNERF_CONV_OUT_CHANNEL_LAST ||
                     out_layout == MNERF_CONV_OUT_PAIR_MAJOR, MNERF_E_RANGE, "%s: out_layout=%d", who, out_layout);
   p.out_layout = out_layout;

@@ -1,4 +1,4 @@
-"""Kernel time of the split-fp16 convolution at the encoder's main shapes (env MNERF_CONV_STAGGER is read at load)."""
+"""Kernel time of the split-fp16 convolution at the encoder's main shapes ."""
 import os
 import sys
 
@@ -25,4 +25,4 @@ for (n, ci, co, k, s, h, w) in shapes:
     e1.record()
     torch.cuda.synchronize()
     out.append("%dx%d@%dx%d %.1f us" % (ci, co, h, w, e0.elapsed_time(e1) / 20 * 1e3))
-print("stagger=%s  " % os.environ.get("MNERF_CONV_STAGGER", "0") + " | ".join(out))
+print(" | ".join(out))
