@@ -22,7 +22,7 @@
  *   - launches go to the calling thread's CURRENT HIP device (hipSetDevice / torch.cuda.device):
  *     every pointer and the stream must belong to it;
  *   - process-wide state: none that a caller can observe.  Debug / tuning knobs (MNERF_DECODER_GRID,
- *     MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID, MNERF_WA_MIN4) are read from the
+ *     MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID, MNERF_WA_MIN4, MNERF_WA_XCD, MNERF_RENDER_FUSED) are read from the
  *     environment ONCE, when the library is loaded; the library keeps one bit per (kernel, device) to
  *     remember that the kernel's dynamic-LDS attribute has been raised on that device.
  */
@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 3
+#define MNERF_ABI_VERSION 4
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.

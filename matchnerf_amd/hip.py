@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 3
+MNERF_ABI_VERSION = 4
 MNERF_MAX_VIEWS = 16
 MNERF_COND_STRIDE_MAX, MNERF_COND_STRIDE_MAX_F32 = 96, 64
 SMALL_FIXED = 32  # floats of the `small` parameter block (LayerNorm weight|bias) before the ray-posenc table
