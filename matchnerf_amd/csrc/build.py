@@ -20,17 +20,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def source_hash():
-    """sha256 over everything the decoder kernel is compiled from (its sources, the ABI header, the compiler flags):
-    identifies the build that profile-derived numbers (profiles/decoder_counters.json) belong to, so that bench.py can
-    tell when they have gone stale.  (Other kernels' sources are left out: a change in the encoder does not change the
-    decoder's counters.)"""
+    """sha256 over everything the decoder kernel is compiled from (its sources, the argument structs it takes from the
+    ABI header, the compiler flags): identifies the build that profile-derived numbers (profiles/decoder_counters.json)
+    belong to, so that bench.py can tell when they have gone stale.  (Other kernels' sources and the rest of the header
+    are left out: a change in the encoder does not change the decoder's counters.)"""
     import hashlib
+    import re
     h = hashlib.sha256(" ".join(FLAGS).encode())
     for name in sorted(DECODER_SOURCES):
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
-    with open(os.path.join(PKG, "..", "include", "mnerf.h"), "rb") as f:
-        h.update(b"mnerf.h\0" + f.read())
+    with open(os.path.join(PKG, "..", "include", "mnerf.h")) as f:
+        header = f.read()
+    for st in ("mnerf_view", "mnerf_rays", "mnerf_scene", "mnerf_decoder"):
+        m = re.search(r"typedef struct %s \{.*?\} %s;" % (st, st), header, re.S)
+        h.update(m.group(0).encode())
     return h.hexdigest()[:16]
 
 
