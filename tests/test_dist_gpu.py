@@ -55,8 +55,7 @@ def _worker(rank, world, port, height, width, q):
         q.put((rank, False, repr(e)))
 
 
-@pytest.mark.parametrize("height,width,world", [(32, 48, 2), (32, 48, 3)])  # even split; ragged one (11 + 11 + 10 rows)
-def test_sharded_frame_is_bit_identical(height, width, world):
+def _run_ranks(height, width, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -66,6 +65,17 @@ def test_sharded_frame_is_bit_identical(height, width, world):
     res = sorted(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+@pytest.mark.parametrize("height,width,world", [(32, 48, 2), (32, 48, 3)])  # even split; ragged one (11 + 11 + 10 rows)
+def test_sharded_frame_is_bit_identical(height, width, world):
+    res = _run_ranks(height, width, world)
+    if any(isinstance(r[2], str) for r in res):
+        # a worker died with an EXCEPTION (rendezvous port taken between _free_port() and init_process_group, ...):
+        # transport trouble, not a result - one more attempt on a fresh port.  A frame mismatch is never retried.
+        print("retrying after worker exception:", res)
+        res = _run_ranks(height, width, world)
     assert [r[:2] for r in res] == [(r, True) for r in range(world)], res
     assert len({r[2] for r in res}) == 1
 
