@@ -301,6 +301,13 @@ int64_t mnerf_conv_wstream_floats(int32_t c_in, int32_t c_out, int32_t ksize);
 int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_channels_last, int32_t upsample2x,
                  const float* in_absmax, const float* add_bilinear2x, const float* add_channel_last, float* out,
                  int32_t out_layout, float* out_absmax, int32_t n_img, int32_t h_in, int32_t w_in, void* stream);
+/* The backbone's stem: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (models/gmflow/backbone.py:45, 101), same
+ * arithmetic as mnerf_conv2d.  wstream: fragments of the [64, 147 -> 160] matrix (k = 3 (7 ky + kx) + c;
+ * matchnerf_amd/gmflow.py: pack_conv_stem; mnerf_conv_stem_wstream_floats() words).  in [n_img,3,h_in,w_in] ->
+ * out [n_img,64,(h_in-1)/2+1,(w_in-1)/2+1] NCHW. */
+int64_t mnerf_conv_stem_wstream_floats(void);
+int mnerf_conv_stem(const float* wstream, int32_t ew, const float* in, const float* in_absmax, float* out,
+                    int32_t n_img, int32_t h_in, int32_t w_in, void* stream);
 /* max |x| of n floats merged into the absmax region `out` (atomic maxima; zero it first) */
 int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 

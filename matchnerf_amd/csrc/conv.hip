@@ -365,3 +365,148 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
 #undef CONV_CASE
   return mnerf_check_launch(who);
 }
+
+// ============================================================================ the 7x7 stride-2 stem (3 -> 64 channels)
+// backbone.py:45, 101: conv1 = Conv2d(3, 64, 7, stride 2, padding 3, bias=False).  K = 49 taps x 3 channels = 147,
+// padded to ten K16-steps with zero weight columns; K index k = 3 tap + c.  The whole weight matrix (40 KiB of
+// fragments) sits in LDS for the lifetime of the workgroup; an LDS table gives every k its input offset and tap
+// displacement.  Lanes run along the output row (input pixels 8 bytes apart: stride 2).
+#define STEM_STEPS 10
+#define STEM_K 147
+#define STEM_W_BYTES (STEM_STEPS * 2 * H16_UNIT_BYTES)  // 40 KiB
+
+struct StemParams {
+  const float* in;       // [n_img, 3, h_in, w_in]
+  const float* wstream;  // STEM_STEPS x 2 units
+  float* out;            // [n_img, 64, h_out, w_out]
+  const float* in_absmax;
+  int n_img, h_in, w_in, h_out, w_out, ew;
+};
+
+__global__ __launch_bounds__(CONV_NW * 64, 2) void conv_stem_kernel(StemParams P) {
+  extern __shared__ __attribute__((aligned(16))) float stem_smem[];
+  const unsigned buf0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)stem_smem;
+  int* tab_off = reinterpret_cast<int*>(stem_smem) + STEM_W_BYTES / 4;  // [160] input offset of k from the centre pixel
+  int* tab_dy = tab_off + 16 * STEM_STEPS;                              // [160] dy (-3..3), 100 for the zero padding columns
+  int* tab_dx = tab_dy + 16 * STEM_STEPS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hl = lane >> 5;
+  {
+    const float* src = P.wstream + lane * 4;
+    for (int p = wave; p < STEM_W_BYTES / 1024; p += CONV_NW)
+      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(buf0 + (unsigned)p * 1024u));
+  }
+  const int hw_in = P.h_in * P.w_in;
+  for (int k = tid; k < 16 * STEM_STEPS; k += CONV_NW * 64) {
+    const int tap = k / 3, c = k - 3 * tap, dy = tap / 7 - 3, dx = tap % 7 - 3;
+    const bool real = k < STEM_K;
+    tab_off[k] = real ? c * hw_in + dy * P.w_in + dx : 0;
+    tab_dy[k] = real ? dy : 100;
+    tab_dx[k] = real ? dx : 100;
+  }
+  const int hw_out = P.h_out * P.w_out;
+  const long long n_pix = (long long)P.n_img * hw_out;
+  constexpr int TPW = 2;
+  int cy[TPW], cx[TPW];
+  long long ibase[TPW], obase[TPW];
+  bool live[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const long long p = ((long long)blockIdx.x * CONV_NW + wave) * (32 * TPW) + t * 32 + n;
+    live[t] = p < n_pix;
+    const long long pc = live[t] ? p : n_pix - 1;
+    const int img = (int)(pc / hw_out), rem = (int)(pc - (long long)img * hw_out);
+    const int oy = rem / P.w_out, ox = rem - oy * P.w_out;
+    cy[t] = 2 * oy;
+    cx[t] = 2 * ox;
+    ibase[t] = (long long)img * 3 * hw_in + (long long)cy[t] * P.w_in + cx[t];
+    obase[t] = (long long)img * 64 * hw_out + rem;
+  }
+  const int eg = gain_exp(mnerf_absmax_read(P.in_absmax));
+  const float mult = pow2i(eg);
+  f32x16 acc[TPW][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t][0] = acc[t][1] = (f32x16)(0.0f);
+  segment_wait();
+  __syncthreads();
+
+#pragma unroll 2
+  for (int s = 0; s < STEM_STEPS; ++s) {
+    const int k0 = 16 * s + 8 * hl;
+    int off[8], dy[8], dx[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int4 o4 = *reinterpret_cast<const int4*>(tab_off + k0 + 4 * q);
+      const int4 y4 = *reinterpret_cast<const int4*>(tab_dy + k0 + 4 * q);
+      const int4 x4 = *reinterpret_cast<const int4*>(tab_dx + k0 + 4 * q);
+      off[4 * q] = o4.x; off[4 * q + 1] = o4.y; off[4 * q + 2] = o4.z; off[4 * q + 3] = o4.w;
+      dy[4 * q] = y4.x; dy[4 * q + 1] = y4.y; dy[4 * q + 2] = y4.z; dy[4 * q + 3] = y4.w;
+      dx[4 * q] = x4.x; dx[4 * q + 1] = x4.y; dx[4 * q + 2] = x4.z; dx[4 * q + 3] = x4.w;
+    }
+    PartsH b[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int yy = cy[t] + dy[j], xx = cx[t] + dx[j];
+        const bool ok = live[t] && yy >= 0 && yy < P.h_in && xx >= 0 && xx < P.w_in;   // also false for padding columns
+        const float x = P.in[ok ? ibase[t] + off[j] : ibase[t]];
+        v8[j] = ok ? x : 0.0f;
+      }
+      b[t] = split8h(v8, mult);
+    }
+    lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)(buf0 + (unsigned)(2 * s) * H16_UNIT_BYTES) + lane;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f16x8 ah = __builtin_bit_cast(f16x8, a[m * 128]), al = __builtin_bit_cast(f16x8, a[m * 128 + 64]);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[t].lo, acc[t][m]);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(al, b[t].hi, acc[t][m]);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[t].hi, acc[t][m]);
+    }
+  }
+  const float cm = pow2i(-(P.ew + eg));
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (!live[t]) continue;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        P.out[obase[t] + (long long)(32 * m + 8 * (r >> 2) + 4 * hl + (r & 3)) * hw_out] = acc[t][m][r] * cm;
+  }
+}
+
+extern "C" int64_t mnerf_conv_stem_wstream_floats(void) { return STEM_W_BYTES / 4; }
+
+extern "C" int mnerf_conv_stem(const float* wstream, int32_t ew, const float* in, const float* in_absmax, float* out,
+                               int32_t n_img, int32_t h_in, int32_t w_in, void* stream) {
+  const char* who = "mnerf_conv_stem";
+  MNERF_REQUIRE(n_img >= 0 && h_in >= 1 && w_in >= 1, MNERF_E_RANGE, "%s: n_img=%d h_in=%d w_in=%d", who, n_img, h_in, w_in);
+  MNERF_REQUIRE((long long)3 * h_in * w_in <= 0x7fffffffLL, MNERF_E_RANGE, "%s: image too large", who);
+  if (n_img == 0) return MNERF_OK;
+  MNERF_REQUIRE(wstream && in && in_absmax && out, MNERF_E_NULL, "%s: NULL buffer", who);
+  MNERF_REQUIRE(mnerf_aligned16(wstream), MNERF_E_ALIGN, "%s: wstream must be 16-byte aligned", who);
+  StemParams p;
+  p.in = in;
+  p.wstream = wstream;
+  p.out = out;
+  p.in_absmax = in_absmax;
+  p.n_img = n_img;
+  p.h_in = h_in;
+  p.w_in = w_in;
+  p.h_out = (h_in + 6 - 7) / 2 + 1;
+  p.w_out = (w_in + 6 - 7) / 2 + 1;
+  p.ew = ew;
+  const long long n_pix = (long long)n_img * p.h_out * p.w_out;
+  const size_t lds = STEM_W_BYTES + 3 * 16 * STEM_STEPS * sizeof(int);
+  static std::atomic<unsigned long long> attr{0};
+  if (mnerf_once_per_device(attr))
+    (void)hipFuncSetAttribute((const void*)conv_stem_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(CONV_NW * 64), lds, (hipStream_t)stream, p);
+  return mnerf_check_launch(who);
+}

@@ -16,8 +16,9 @@ forward pass designed around what the render kernels consume:
   (reference: transformer.py:46-105);
 * the backbone and up-sampler convolutions after the 7x7 stem are split-fp16 implicit GEMMs (``mnerf_conv2d``), every
   InstanceNorm + activation (+ residual add) one kernel (``mnerf_instance_norm``), everything after the attention
-  inside a transformer layer one kernel (``mnerf_encoder_block``); the stem and the q|k|v projections are library ops
-  (MIOpen, rocBLAS).  Under autograd the reference's op chain is used throughout.
+  inside a transformer layer one kernel (``mnerf_encoder_block``), the q|k|v projections one kernel
+  (``mnerf_qkv_projection``): no library GEMM or convolution is left in the inference path.  Under autograd the
+  reference's op chain (MIOpen, rocBLAS) is used throughout.
 
 There is no CPU path: ``forward`` needs the HIP library and a GPU tensor.
 """
@@ -56,6 +57,20 @@ def pack_conv(weight):
     ew = CN.f16_weight_exponent(mat)
     cols = np.arange(mat.shape[1]).reshape(-1, 2, 8)
     halfs = CN._fragments_h(mat, cols, c_out // 32, ew)            # [steps, blocks, 2, 64, 8] fp16
+    return halfs.reshape(-1).view(np.float32).copy(), int(ew)
+
+
+def pack_conv_stem(weight):
+    """The stem's weight [64, 3, 7, 7] -> (wstream, ew) for ``mnerf_conv_stem``: matrix [64, 3 tap + c], 147 columns
+    padded with zeros to ten K16-steps."""
+    import numpy as np
+    from . import cond_nerf as CN
+    w = (weight.detach().cpu().numpy() if torch.is_tensor(weight) else np.asarray(weight)).astype(np.float32)
+    assert w.shape == (64, 3, 7, 7), w.shape
+    mat = np.zeros((64, 160), np.float32)
+    mat[:, :147] = w.transpose(0, 2, 3, 1).reshape(64, 147)
+    ew = CN.f16_weight_exponent(mat)
+    halfs = CN._fragments_h(mat, np.arange(160).reshape(10, 2, 8), 2, ew)
     return halfs.reshape(-1).view(np.float32).copy(), int(ew)
 
 
@@ -126,9 +141,15 @@ class CNNEncoder(nn.Module):
         """``tokens_plus`` (inference): a [h*w, C] tile; the result is then the transformer's channel-last tokens
         [N,h,w,C] with the tile added - layout change and position embedding are the last convolution's epilogue."""
         if _fused_norm(x):
-            # the 7x7 stem (3 input channels) stays a library call; everything after it is HIP: 14 convolutions, 15 norms
-            scal = hip.absmax_regions(13, x.device)  # max|.| of every convolution input (one fill kernel)
-            x = _conv_out(self.conv1, x)
+            # every convolution (stem: mnerf_conv_stem, the other 14: mnerf_conv2d) and all 15 norms are HIP kernels
+            scal = hip.absmax_regions(14, x.device)  # max|.| of every convolution input (one fill kernel)
+            x = x.contiguous()
+            hip.absmax(x, scal[13])
+            key = (int(self.conv1.weight._version), int(self.conv1.weight.data_ptr()), str(x.device))
+            if getattr(self, "_stem_pack", None) is None or self._stem_pack[0] != key:
+                ws, ew = pack_conv_stem(self.conv1.weight)
+                self._stem_pack = (key, torch.from_numpy(ws).to(x.device), ew)
+            x = hip.conv_stem(x, self._stem_pack[1], self._stem_pack[2], scal[13])
             hip.instance_norm(x, relu_inner=True, out=x, out_absmax=scal[0])
             amax, k = scal[0], 1
             for layer in (self.layer1, self.layer2, self.layer3):

@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -145,6 +145,10 @@ def load():
     lib.mnerf_conv_wstream_floats.argtypes = [i32, i32, i32]
     lib.mnerf_conv2d.restype = C.c_int
     lib.mnerf_conv2d.argtypes = [C.POINTER(ConvLayer), fp, i32, i32, fp, fp, fp, fp, i32, fp, i32, i32, i32, vp]
+    lib.mnerf_conv_stem_wstream_floats.restype = i64
+    lib.mnerf_conv_stem_wstream_floats.argtypes = []
+    lib.mnerf_conv_stem.restype = C.c_int
+    lib.mnerf_conv_stem.argtypes = [fp, i32, fp, fp, fp, i32, i32, i32, vp]
     lib.mnerf_absmax.restype = C.c_int
     lib.mnerf_absmax.argtypes = [fp, i64, fp, vp]
     lib.mnerf_encoder_block_wstream_floats.restype = i64
@@ -527,6 +531,24 @@ def absmax(x, out, stream=None):
     _f32c(x, "x")
     with _on(x.device, stream) as st:
         check(lib.mnerf_absmax(_ptr(x), x.numel(), _ptr(out), st), "mnerf_absmax")
+    return out
+
+
+def conv_stem(x, wstream, ew, in_absmax, out=None, stream=None):
+    """The backbone's 7x7 stride-2 stem (3 -> 64 channels, backbone.py:45) on the split-fp16 matrix path.
+    x [N,3,H,W] -> [N,64,(H-1)//2+1,(W-1)//2+1]; wstream / ew from gmflow.pack_conv_stem."""
+    import torch
+    lib = load()
+    _f32c(x, "x"), _f32c(wstream, "wstream")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise MnerfError(f"conv_stem: expected [N,3,H,W], got {tuple(x.shape)}")
+    if wstream.numel() != lib.mnerf_conv_stem_wstream_floats():
+        raise MnerfError(f"conv_stem: wstream has {wstream.numel()} floats, expected {lib.mnerf_conv_stem_wstream_floats()}")
+    n, _, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1, device=x.device, dtype=torch.float32)
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_conv_stem(_ptr(wstream), int(ew), _ptr(x), _ptr(in_absmax), _ptr(out), n, h, w, st), "mnerf_conv_stem")
     return out
 
 

@@ -143,6 +143,24 @@ def test_upsampler_fused_path_matches_op_chain(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 3, 64, 96), (1, 3, 37, 51), (2, 3, 128, 160)])
+def test_conv_stem_matches_float64(hip, shape):
+    """the 7x7 stride-2 stem (incl. odd sizes: ragged tiles, taps leaving the image on every side)"""
+    gen = torch.Generator().manual_seed(shape[2])
+    x = (torch.rand(shape, generator=gen) - 0.45) / 0.225
+    wt = torch.randn(64, 3, 7, 7, generator=gen) * 0.08
+    ws, ew = G.pack_conv_stem(wt)
+    reg = hip.absmax_regions(1, "cuda")
+    hip.absmax(x.cuda(), reg[0])
+    got = hip.conv_stem(x.cuda(), torch.from_numpy(ws).cuda(), ew, reg[0])
+    want = F.conv2d(x.double(), wt.double(), stride=2, padding=3)
+    assert got.shape == want.shape
+    err = float((got.cpu().double() - want).abs().max())
+    err32 = float((F.conv2d(x, wt, stride=2, padding=3).double() - want).abs().max())
+    assert err < 4 * err32 + 1e-6 * float(want.abs().max()), (err, err32)
+
+
+@pytest.mark.gpu
 def test_conv2d_argument_checks(hip):
     ws = torch.zeros(512 * 4, device="cuda")
     s = torch.ones(hip.ABSMAX_FLOATS, device="cuda")
