@@ -48,19 +48,7 @@ __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define H16_UNIT_BYTES 2048  // one (step, block): hi | lo fragments
-#define H16_TARGET_EXP 15
-// experiment: raise the wave's issue priority while it feeds the matrix pipe (the co-resident wave of the other
-// workgroup is usually in a VALU phase)
-#ifndef MNERF_MFMA_PRIO
-#define MNERF_MFMA_PRIO 0
-#endif
-#if MNERF_MFMA_PRIO
-#define MNERF_PRIO_UP() __builtin_amdgcn_s_setprio(MNERF_MFMA_PRIO)
-#define MNERF_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
-#else
-#define MNERF_PRIO_UP()
-#define MNERF_PRIO_DOWN()
-#endif    // largest operand of a sample is scaled into [2^14, 2^15)
+#define H16_TARGET_EXP 15    // largest operand of a sample is scaled into [2^14, 2^15)
 
 struct PartsH {
   f16x8 hi, lo;
@@ -140,7 +128,6 @@ __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, 
                                          float mult) {
   lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)base_lds + lane;
   u32x4 ch = a[0], cl = a[64];
-  MNERF_PRIO_UP();
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
     float vv[8];
@@ -162,7 +149,6 @@ __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, 
       cl = nl;
     }
   }
-  MNERF_PRIO_DOWN();
 }
 
 // NS K16-steps against NMB output blocks with operands that are ALREADY split (mlp.0's operands are the same for
