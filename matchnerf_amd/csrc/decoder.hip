@@ -1299,11 +1299,15 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[g][r]);
         } else {
+          // (an opaque copy of S: otherwise the SP comparisons are hoisted out of the tile loop as SP lane masks in
+          // 2 SP scalar registers - spilled, and paid for by the unpadded case too)
+          int s_keys = S;
+          asm volatile("" : "+s"(s_keys));
 #pragma unroll
           for (int g = 0; g < SP / 4; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float v = (4 * g + r < S) ? sc[g][r] : -3.0e38f;  // padded key slots
+              const float v = (4 * g + r < s_keys) ? sc[g][r] : -3.0e38f;  // padded key slots
               sc[g][r] = v;
               mx4[r] = fmaxf(mx4[r], v);
             }
