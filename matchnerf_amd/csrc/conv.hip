@@ -431,32 +431,48 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_stem_kernel(StemParams P
   segment_wait();
   __syncthreads();
 
-#pragma unroll 2
-  for (int s = 0; s < STEM_STEPS; ++s) {
-    const int k0 = 16 * s + 8 * hl;
-    int off[8], dy[8], dx[8];
+  // A tile whose 32 pixels keep all 49 taps inside the image (the usual case) loads without any per-tap test: the zero
+  // padding COLUMNS (k >= 147) have zero weights, so what they load (the centre pixel) does not matter.  Values of
+  // step s+1 are requested before the 12 matrix instructions of step s.
+  bool inside[TPW];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int4 o4 = *reinterpret_cast<const int4*>(tab_off + k0 + 4 * q);
-      const int4 y4 = *reinterpret_cast<const int4*>(tab_dy + k0 + 4 * q);
-      const int4 x4 = *reinterpret_cast<const int4*>(tab_dx + k0 + 4 * q);
-      off[4 * q] = o4.x; off[4 * q + 1] = o4.y; off[4 * q + 2] = o4.z; off[4 * q + 3] = o4.w;
-      dy[4 * q] = y4.x; dy[4 * q + 1] = y4.y; dy[4 * q + 2] = y4.z; dy[4 * q + 3] = y4.w;
-      dx[4 * q] = x4.x; dx[4 * q + 1] = x4.y; dx[4 * q + 2] = x4.z; dx[4 * q + 3] = x4.w;
+  for (int t = 0; t < TPW; ++t)
+    inside[t] = __all(live[t] && cy[t] >= 3 && cy[t] + 3 < P.h_in && cx[t] >= 3 && cx[t] + 3 < P.w_in);
+  float vn[TPW][8];
+  auto load_step = [&](int s) {
+    const int k0 = 16 * s + 8 * hl;
+    int off[8];
+    {
+      const int4 o0 = *reinterpret_cast<const int4*>(tab_off + k0), o1 = *reinterpret_cast<const int4*>(tab_off + k0 + 4);
+      off[0] = o0.x; off[1] = o0.y; off[2] = o0.z; off[3] = o0.w; off[4] = o1.x; off[5] = o1.y; off[6] = o1.z; off[7] = o1.w;
     }
-    PartsH b[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      float v8[8];
+      if (inside[t]) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int yy = cy[t] + dy[j], xx = cx[t] + dx[j];
-        const bool ok = live[t] && yy >= 0 && yy < P.h_in && xx >= 0 && xx < P.w_in;   // also false for padding columns
-        const float x = P.in[ok ? ibase[t] + off[j] : ibase[t]];
-        v8[j] = ok ? x : 0.0f;
+        for (int j = 0; j < 8; ++j) vn[t][j] = P.in[ibase[t] + off[j]];
+      } else {
+        int dy[8], dx[8];
+        const int4 y0 = *reinterpret_cast<const int4*>(tab_dy + k0), y1 = *reinterpret_cast<const int4*>(tab_dy + k0 + 4);
+        const int4 x0 = *reinterpret_cast<const int4*>(tab_dx + k0), x1 = *reinterpret_cast<const int4*>(tab_dx + k0 + 4);
+        dy[0] = y0.x; dy[1] = y0.y; dy[2] = y0.z; dy[3] = y0.w; dy[4] = y1.x; dy[5] = y1.y; dy[6] = y1.z; dy[7] = y1.w;
+        dx[0] = x0.x; dx[1] = x0.y; dx[2] = x0.z; dx[3] = x0.w; dx[4] = x1.x; dx[5] = x1.y; dx[6] = x1.z; dx[7] = x1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int yy = cy[t] + dy[j], xx = cx[t] + dx[j];
+          const bool ok = live[t] && yy >= 0 && yy < P.h_in && xx >= 0 && xx < P.w_in;   // also false for padding columns
+          const float x = P.in[ok ? ibase[t] + off[j] : ibase[t]];
+          vn[t][j] = ok ? x : 0.0f;
+        }
       }
-      b[t] = split8h(v8, mult);
     }
+  };
+  load_step(0);
+  for (int s = 0; s < STEM_STEPS; ++s) {
+    PartsH b[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) b[t] = split8h(vn[t], mult);
+    if (s + 1 < STEM_STEPS) load_step(s + 1);
     lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)(buf0 + (unsigned)(2 * s) * H16_UNIT_BYTES) + lane;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
