@@ -170,3 +170,54 @@ def test_conv2d_argument_checks(hip):
         hip.conv2d(torch.zeros(1, 64, 8, 8, device="cuda"), ws, None, 64, 64, 3, 1, 0, s)
     with pytest.raises(hip.MnerfError):  # missing operand scale
         hip.conv2d(torch.zeros(1, 32, 8, 8, device="cuda"), torch.zeros(512 * 4, device="cuda"), None, 32, 64, 1, 1, 0, None)
+
+
+def _emulated_conv(x, wt, stride, up=False):
+    """numpy restatement of csrc/conv.hip's data path on the CPU: packed fragments (pack_conv), one power-of-two
+    operand gain for the whole input tensor, operands split into fp16 hi + lo, products hi.lo + lo.hi + hi.hi in wide
+    accumulation, scale folded back.  x [N,C,H,W] fp32, wt [O,C,k,k] -> [N,O,Ho,Wo] float64."""
+    from matchnerf_amd import cond_nerf as CN
+    n, c, h, w = x.shape
+    o, _, k, _ = wt.shape
+    ws, ew = G.pack_conv(wt)
+    frag = ws.view(np.float16).reshape(k * k * c // 16, o // 32, 2, 64, 8).astype(np.float64)   # [step][block][hi|lo][lane][j]
+    xs = np.repeat(np.repeat(x, 2, 2), 2, 3) if up else x
+    pad = k // 2
+    xp = np.pad(xs, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    he, we = xs.shape[2], xs.shape[3]
+    ho, wo = (he + 2 * pad - k) // stride + 1, (we + 2 * pad - k) // stride + 1
+    cols = np.stack([xp[:, :, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride]
+                     for ky in range(k) for kx in range(k)], 1)                                  # [N, taps, C, ho, wo]
+    ops = cols.reshape(n, k * k * c, ho * wo).astype(np.float32)                                 # K index = tap * C + c
+    eg = (CN.F16_TARGET_EXP + 1) - np.frexp(np.float32(np.abs(x).max()))[1]
+    scaled = (ops * np.ldexp(np.float32(1), eg)).astype(np.float32)
+    hi = scaled.astype(np.float16)
+    lo = (scaled - hi.astype(np.float32)).astype(np.float16)
+    hi, lo = hi.astype(np.float64), lo.astype(np.float64)
+    lane = np.arange(64)
+    w_hi = np.zeros((o, k * k * c))
+    w_lo = np.zeros_like(w_hi)
+    for s in range(frag.shape[0]):                                                               # fragments -> matrices
+        for m in range(o // 32):
+            for j in range(8):
+                w_hi[32 * m + (lane & 31), 16 * s + 8 * (lane >> 5) + j] = frag[s, m, 0, lane, j]
+                w_lo[32 * m + (lane & 31), 16 * s + 8 * (lane >> 5) + j] = frag[s, m, 1, lane, j]
+    y = w_hi @ lo + w_lo @ hi + w_hi @ hi                                                        # [N, O, ho*wo] (broadcast matmul)
+    return (y * np.ldexp(1.0, -(ew + int(eg)))).reshape(n, o, ho, wo)
+
+
+@pytest.mark.parametrize("c_in,c_out,k,stride,up", [(64, 64, 3, 1, False), (64, 96, 1, 2, False), (96, 128, 3, 2, False),
+                                                    (128, 128, 3, 1, True)])
+def test_emulated_conv_data_path_matches_float64(c_in, c_out, k, stride, up):
+    """CPU: packer + operand scaling + split-fp16 product rule of the convolution kernel, without a GPU"""
+    rng = np.random.default_rng(c_in + c_out + k + stride)
+    x = (rng.standard_normal((2, c_in, 7, 9)) * (0.2 + 3 * rng.random((1, c_in, 1, 1)))).astype(np.float32)
+    x[0, 0, 0, 0] = 41.0                                                                         # sets the tensor's gain
+    wt = (rng.standard_normal((c_out, c_in, k, k)) / np.sqrt(c_in * k * k)).astype(np.float32)
+    got = _emulated_conv(x, wt, stride, up)
+    xr = torch.from_numpy(x).double()
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xr, torch.from_numpy(wt).double(), stride=stride, padding=k // 2).numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6 * np.abs(want).max()

@@ -202,3 +202,18 @@ def test_pack_qkv_encodes_three_scaled_matrices():
                     mat[32 * m + (lane & 31), 16 * t + 8 * (lane >> 5) + j] = full[t, m, lane, j]
         assert np.abs(np.ldexp(mat, -ews[p]) - ws[p]).max() < 2.0 ** -20 * np.abs(ws[p]).max()
         assert 2.0 ** 13 <= np.abs(np.ldexp(ws[p].astype(np.float64), ews[p])).max() < 2.0 ** 14 * 1.0001
+
+
+def test_emulated_qkv_data_path_matches_float64():
+    """CPU: pack_qkv + per-token gains + the split-fp16 product rule of csrc/qkv.hip"""
+    rng = np.random.default_rng(11)
+    ws = [(rng.standard_normal((128, 128)) * s).astype(np.float32) for s in (0.1, 0.4, 0.03)]
+    x = (rng.standard_normal((50, 128)) * np.ldexp(1.0, rng.integers(-8, 9, (50, 1)))).astype(np.float32)
+    stream, ews = G.pack_qkv(*ws)
+    frag = stream.view(np.float16).reshape(3, 8, 4, 2, 64, 8)
+    eg = _gain(np.abs(x).max(1))                                                    # one exponent per token
+    ops = (x.T.reshape(8, 2, 8, 50) * np.ldexp(np.float32(1), eg)).astype(np.float32)
+    for p in range(3):
+        y = _split_products(frag[p], ops) * np.ldexp(1.0, -(ews[p] + eg))           # [128, N]
+        want = ws[p].astype(np.float64) @ x.astype(np.float64).T
+        assert np.abs(y - want).max() < 2e-6 * np.abs(want).max()
