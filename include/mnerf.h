@@ -255,6 +255,17 @@ int64_t mnerf_qkv_wstream_floats(void);
 int mnerf_qkv_projection(const float* wstream, const int32_t* ew, const float* x_q, const float* x_kv, int32_t kv_swap,
                          float* q, float* k, float* v, int32_t n_seq, int32_t seq_len, void* stream);
 
+/* The same projections with K and V written directly as the window attention's operand images (no k / v tensors, no
+ * operand pre-pass): q [batch, h*w, 128] fp32 + `workspace` in the format mnerf_window_attention_images consumes
+ * (mnerf_window_attention_workspace_bytes(batch, h, w, num_splits) bytes).  The geometry arguments must be the ones the
+ * attention call will get. */
+int mnerf_qkv_window_images(const float* wstream, const int32_t* ew, const float* x_q, const float* x_kv, int32_t kv_swap,
+                            float* q, void* workspace, size_t workspace_bytes, int32_t batch, int32_t h, int32_t w,
+                            int32_t num_splits, int32_t shifted, void* stream);
+/* K6 on a workspace filled by mnerf_qkv_window_images (or by a previous mnerf_window_attention_presplit call) */
+int mnerf_window_attention_images(const float* q, float* out, int32_t batch, int32_t h, int32_t w, int32_t num_splits,
+                                  int32_t shifted, const void* workspace, size_t workspace_bytes, void* stream);
+
 /* InstanceNorm2d (no affine, biased variance, as torch.nn.functional.instance_norm) of an NCHW tensor fused with what
  * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):
  *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);

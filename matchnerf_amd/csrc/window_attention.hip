@@ -26,28 +26,7 @@
 // is in flight while tile t feeds 128 MFMAs per wave; one barrier per tile.
 #include <stdlib.h>
 
-#include "split_f16.hpp"
-
-#define WA_C 128
-#define WA_KT 32            // keys per tile
-
-struct WinGeom {
-  int h, w, wh, ww, sh, sw, splits, Lw;
-};
-
-// window-local index -> token id in the un-rolled [h*w] sequence, and the wrap region of its
-// rolled position (0..8), cf. transformer.py:24-36
-__device__ __forceinline__ int win_token(const WinGeom& G, int wy, int wx, int li, int& region) {
-  const int ly = li / G.ww, lx = li - ly * G.ww;
-  const int ry = wy * G.wh + ly, rx = wx * G.ww + lx;  // position after roll by (-sh,-sw)
-  int oy = ry + G.sh, ox = rx + G.sw;                  // original position
-  if (oy >= G.h) oy -= G.h;
-  if (ox >= G.w) ox -= G.w;
-  const int regy = (ry >= G.h - G.wh) + (ry >= G.h - G.sh);
-  const int regx = (rx >= G.w - G.ww) + (rx >= G.w - G.sw);
-  region = regy * 3 + regx;
-  return oy * G.w + ox;
-}
+#include "wa_common.hpp"
 
 // ---- LDS-DMA helpers (see decoder.hip: an asm global_load_lds is invisible to hipcc's
 // wait-count bookkeeping, so the prefetch of tile t+1 is not drained in front of tile t's reads)
@@ -608,9 +587,6 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_f16_kernel(
 // 32 x 1 KiB LDS-DMA pieces and reads every fragment with one conflict-free ds_read_b128; the tile gains come from a
 // scalar load issued one tile ahead, so nothing in the loop waits for a reduction any more (what made the in-loop
 // split-fp16 variant slower than split-bf16).  Same products, same accumulation order as window_attention_f16_kernel.
-#define WA_IMG_BYTES 32768
-#define WA_IMG_VOFF 1024  // u32x4 index of the V part inside an image
-#define WA_REC_INTS 8     // side record of a tile: ek, ev, 4 words of key wrap regions (one nibble per key), 2 pad
 
 __global__ __launch_bounds__(64) void wa_presplit_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                          u32x4* __restrict__ img, int* __restrict__ gains, WinGeom G) {
@@ -683,19 +659,8 @@ __global__ __launch_bounds__(64) void wa_presplit_kernel(const float* __restrict
         dst[(WA_IMG_VOFF / 64 + 2 * (4 * t + m) + 1) * 64] = __builtin_bit_cast(u32x4, vp.lo);
       }
   }
-  // ---- wrap region (0..8) of every key of the tile, one nibble per key (lane n < 32 owns key n)
-  unsigned nib;
-  {
-    int li = kt * WA_KT + n, region;
-    if (li >= G.Lw) li = G.Lw - 1;
-    (void)win_token(G, wy, wx, li, region);
-    nib = (unsigned)region << (4 * (n & 7));
-  }
-  nib |= __shfl_xor(nib, 1, 64);
-  nib |= __shfl_xor(nib, 2, 64);
-  nib |= __shfl_xor(nib, 4, 64);  // lanes 8g .. 8g+7 now hold word g
   int* rec = gains + WA_REC_INTS * tile;
-  if (lane < 32 && (lane & 7) == 0) rec[2 + (lane >> 3)] = (int)nib;
+  wa_store_regions(G, wy, wx, kt, lane, rec);
   if (lane == 0) {
     rec[0] = ek;
     rec[1] = ev;
@@ -985,30 +950,47 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
   }
 }
 
-static int wa_geometry(const char* who, int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
-                       WinGeom& G, int& do_shift) {
-  MNERF_REQUIRE(batch >= 0 && h >= 1 && w >= 1 && num_splits >= 1, MNERF_E_RANGE, "%s: batch=%d h=%d w=%d splits=%d",
-                who, batch, h, w, num_splits);
-  MNERF_REQUIRE(h % num_splits == 0 && w % num_splits == 0, MNERF_E_RANGE, "%s: %dx%d not divisible into %d splits",
-                who, h, w, num_splits);
-  MNERF_REQUIRE(batch <= 65535 && num_splits * num_splits <= 65535, MNERF_E_RANGE, "%s: grid too large", who);
-  G.h = h;
-  G.w = w;
-  G.splits = num_splits;
-  G.wh = h / num_splits;
-  G.ww = w / num_splits;
-  do_shift = (shifted && num_splits > 1) ? 1 : 0;
-  G.sh = do_shift ? G.wh / 2 : 0;
-  G.sw = do_shift ? G.ww / 2 : 0;
-  G.Lw = G.wh * G.ww;
-  return MNERF_OK;
+extern "C" size_t mnerf_window_attention_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t num_splits) {
+  return wa_workspace_bytes(batch, h, w, num_splits);
 }
 
-extern "C" size_t mnerf_window_attention_workspace_bytes(int32_t batch, int32_t h, int32_t w, int32_t num_splits) {
-  if (batch <= 0 || h < 1 || w < 1 || num_splits < 1 || h % num_splits || w % num_splits) return 0;
-  const size_t lw = (size_t)(h / num_splits) * (w / num_splits);
-  const size_t tiles = (size_t)batch * num_splits * num_splits * ((lw + WA_KT - 1) / WA_KT);
-  return tiles * (WA_IMG_BYTES + WA_REC_INTS * sizeof(int32_t));
+// the attention kernel over prepared images (filled by wa_presplit_kernel or by the q|k|v kernel, qkv.hip)
+static int wa_launch_main(const char* who, const float* q, float* out, const WinGeom& G, int do_shift, int32_t batch,
+                          int32_t num_splits, void* workspace, hipStream_t st) {
+  const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
+  const int n_win = num_splits * num_splits;
+  const u32x4* img = reinterpret_cast<const u32x4*>(workspace);
+  const int* gains = reinterpret_cast<const int*>(reinterpret_cast<const char*>(workspace) + (size_t)batch * n_win * n_tiles * WA_IMG_BYTES);
+  const float scale = 1.0f / sqrtf((float)WA_C);
+  const size_t lds = 2 * WA_IMG_BYTES;
+  static std::atomic<unsigned long long> attr{0};
+  if (mnerf_once_per_device(attr)) {
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  unsigned long long* tl = nullptr;
+#ifdef MNERF_TIMELINE
+  if (const char* e = getenv("MNERF_WA_TIMELINE_PTR")) tl = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+  const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
+  const long long win_groups = ((long long)n_win * batch + 7) / 8;  // windows per XCD
+  const int xcd = mnerf_tune().wa_xcd;
+  const bool four = wgs4 >= mnerf_tune().wa_min4;
+  const int n_qb = four ? (G.Lw + 127) / 128 : (G.Lw + 63) / 64;
+  const dim3 grid((unsigned)(8 * win_groups * n_qb));
+  if (four)
+    hipLaunchKernelGGL(window_attention_pre_kernel<4>, grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
+  else
+    hipLaunchKernelGGL(window_attention_pre_kernel<2>, grid, dim3(128), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
+  return mnerf_check_launch(who);
+}
+
+static int wa_check_workspace(const char* who, const void* workspace, size_t workspace_bytes, int32_t batch, int32_t h,
+                              int32_t w, int32_t num_splits) {
+  const size_t need = wa_workspace_bytes(batch, h, w, num_splits);
+  MNERF_REQUIRE(workspace && mnerf_aligned16(workspace), MNERF_E_ALIGN, "%s: workspace NULL or not 16-byte aligned", who);
+  MNERF_REQUIRE(workspace_bytes >= need, MNERF_E_RANGE, "%s: workspace %zu bytes < %zu", who, workspace_bytes, need);
+  return MNERF_OK;
 }
 
 extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, const float* v, float* out,
@@ -1022,37 +1004,28 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
   int do_shift;
   if (const int rc = wa_geometry(who, batch, h, w, num_splits, shifted, G, do_shift)) return rc;
   if (batch == 0) return MNERF_OK;
-  const size_t need = mnerf_window_attention_workspace_bytes(batch, h, w, num_splits);
-  MNERF_REQUIRE(workspace && mnerf_aligned16(workspace), MNERF_E_ALIGN, "%s: workspace NULL or not 16-byte aligned", who);
-  MNERF_REQUIRE(workspace_bytes >= need, MNERF_E_RANGE, "%s: workspace %zu bytes < %zu", who, workspace_bytes, need);
+  if (const int rc = wa_check_workspace(who, workspace, workspace_bytes, batch, h, w, num_splits)) return rc;
   const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
   const int n_win = num_splits * num_splits;
   u32x4* img = reinterpret_cast<u32x4*>(workspace);
   int* gains = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)batch * n_win * n_tiles * WA_IMG_BYTES);
-  const float scale = 1.0f / sqrtf((float)WA_C);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = 2 * WA_IMG_BYTES;
-  static std::atomic<unsigned long long> attr{0};
-  if (mnerf_once_per_device(attr)) {
-    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  unsigned long long* tl = nullptr;
-#ifdef MNERF_TIMELINE
-  if (const char* e = getenv("MNERF_WA_TIMELINE_PTR")) tl = (unsigned long long*)strtoull(e, nullptr, 0);
-#endif
   hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
-  const long long wgs4 = (long long)((G.Lw + 127) / 128) * n_win * batch;
-  const long long win_groups = ((long long)n_win * batch + 7) / 8;  // windows per XCD
-  const int xcd = mnerf_tune().wa_xcd;
-  const bool four = wgs4 >= mnerf_tune().wa_min4;
-  const int n_qb = four ? (G.Lw + 127) / 128 : (G.Lw + 63) / 64;
-  const dim3 grid((unsigned)(8 * win_groups * n_qb));
-  if (four)
-    hipLaunchKernelGGL(window_attention_pre_kernel<4>, grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
-  else
-    hipLaunchKernelGGL(window_attention_pre_kernel<2>, grid, dim3(128), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
-  return mnerf_check_launch(who);
+  return wa_launch_main(who, q, out, G, do_shift, batch, num_splits, workspace, st);
+}
+
+extern "C" int mnerf_window_attention_images(const float* q, float* out, int32_t batch, int32_t h, int32_t w,
+                                             int32_t num_splits, int32_t shifted, const void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+  const char* who = "mnerf_window_attention_images";
+  MNERF_REQUIRE(q && out, MNERF_E_NULL, "%s: NULL buffer", who);
+  MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(out), MNERF_E_ALIGN, "%s: buffers must be 16-byte aligned", who);
+  WinGeom G;
+  int do_shift;
+  if (const int rc = wa_geometry(who, batch, h, w, num_splits, shifted, G, do_shift)) return rc;
+  if (batch == 0) return MNERF_OK;
+  if (const int rc = wa_check_workspace(who, workspace, workspace_bytes, batch, h, w, num_splits)) return rc;
+  return wa_launch_main(who, q, out, G, do_shift, batch, num_splits, const_cast<void*>(workspace), (hipStream_t)stream);
 }
 
 extern "C" int mnerf_window_attention(const float* q, const float* k, const float* v, float* out,

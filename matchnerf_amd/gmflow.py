@@ -201,6 +201,25 @@ def pack_encoder_block(merge_w, mlp0_w=None, mlp2_w=None):
     return ws, tuple(int(e) for e in ews)
 
 
+def _k_row_order():
+    """Row permutation of Wk for ``mnerf_qkv_projection`` / ``mnerf_qkv_window_images``: accumulator row 32 m + n of the
+    transposed chain is register r = (n & 3) + 4 (n >> 3) of lane half (n >> 2) & 1; it is given output channel
+    16 t + 8 half + j with 8 t + j = 16 m + r, so that a lane's registers 8t..8t+7 are the eight channels it supplies to
+    K16-step t of the attention's S^T = K Q^T."""
+    import numpy as np
+    rows = np.zeros(128, np.int64)
+    for m in range(4):
+        for n in range(32):
+            r, half = (n & 3) + 4 * (n >> 3), (n >> 2) & 1
+            q = 16 * m + r
+            rows[32 * m + n] = 16 * (q >> 3) + 8 * half + (q & 7)
+    assert sorted(rows.tolist()) == list(range(128))
+    return rows
+
+
+K_ROW_ORDER = _k_row_order()
+
+
 def pack_qkv(wq, wk, wv):
     """q/k/v projection weights [128,128] -> (wstream float32 words, (ew_q, ew_k, ew_v)) for ``mnerf_qkv_projection``
     (csrc/qkv.hip): three matrices of 8 K16-steps x 4 row blocks, input features in natural order, each with its own
@@ -209,9 +228,11 @@ def pack_qkv(wq, wk, wv):
     from . import cond_nerf as CN
     natural = np.arange(128).reshape(8, 2, 8)
     parts, ews = [], []
-    for w in (wq, wk, wv):
+    for i, w in enumerate((wq, wk, wv)):
         w = (w.detach().cpu().numpy() if torch.is_tensor(w) else np.asarray(w)).astype(np.float32)
         assert w.shape == (128, 128), w.shape
+        if i == 1:
+            w = w[K_ROW_ORDER]  # accumulator registers 8t..8t+7 of a lane = the attention's K16-step t (csrc/qkv.hip)
         ews.append(CN.f16_weight_exponent(w))
         parts.append(CN._fragments_h(w, natural, 4, ews[-1]).reshape(-1))
     return np.concatenate(parts).view(np.float32).copy(), tuple(int(e) for e in ews)
@@ -263,7 +284,14 @@ class TransformerLayer(nn.Module):
         if source.is_cuda and not (torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or
                                                                 any(p.requires_grad for p in params))):
             ws, ews = self._packed_qkv(source.device)
-            q, k, v = hip.qkv_projection(ws, ews, source.contiguous(), target.contiguous(), kv_swap)  # one launch
+            if hip.wa_math() == hip.WA_PRESPLIT_F16:
+                # one launch: q rows + K / V written straight as the window attention's operand images
+                q, images = hip.qkv_window_images(ws, ews, source.contiguous(), target.contiguous(), kv_swap, h, w, splits,
+                                                  shifted)
+                msg = hip.window_attention_images(q, images, h, w, splits, shifted)
+            else:  # another attention arithmetic was asked for (MNERF_WA_MATH): q, k, v as tensors
+                q, k, v = hip.qkv_projection(ws, ews, source.contiguous(), target.contiguous(), kv_swap)
+                msg = hip.window_attention(q, k, v, h, w, splits, shifted)
         else:
             if kv_swap:
                 half = target.shape[0] // 2
@@ -271,7 +299,7 @@ class TransformerLayer(nn.Module):
             q = self.q_proj(source)
             k = self.k_proj(target)
             v = self.v_proj(target)
-        msg = window_attention(q, k, v, h, w, splits, shifted)  # HIP forward; torch re-evaluation backward
+            msg = window_attention(q, k, v, h, w, splits, shifted)  # HIP forward; torch re-evaluation backward
         if not torch.is_grad_enabled() or not (msg.requires_grad or source.requires_grad or self.merge.weight.requires_grad):
             ws, ln, ews = self._packed_block(source.device)
             b, n, c = source.shape

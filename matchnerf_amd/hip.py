@@ -26,7 +26,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -139,6 +139,10 @@ def load():
     lib.mnerf_qkv_wstream_floats.argtypes = []
     lib.mnerf_qkv_projection.restype = C.c_int
     lib.mnerf_qkv_projection.argtypes = [fp, C.POINTER(C.c_int32), fp, fp, i32, fp, fp, fp, i32, i32, vp]
+    lib.mnerf_qkv_window_images.restype = C.c_int
+    lib.mnerf_qkv_window_images.argtypes = [fp, C.POINTER(C.c_int32), fp, fp, i32, fp, vp, C.c_size_t, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_window_attention_images.restype = C.c_int
+    lib.mnerf_window_attention_images.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_instance_norm.restype = C.c_int
     lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, fp, vp]
     lib.mnerf_conv_wstream_floats.restype = i64
@@ -489,6 +493,48 @@ def qkv_projection(wstream, ews, x_q, x_kv=None, kv_swap=False, stream=None):
         check(lib.mnerf_qkv_projection(_ptr(wstream), ew, _ptr(x_q), _ptr(x_kv), int(bool(kv_swap)), _ptr(q), _ptr(k),
                                        _ptr(v), x_q.shape[0], x_q.shape[1], st), "mnerf_qkv_projection")
     return q, k, v
+
+
+def qkv_window_images(wstream, ews, x_q, x_kv, kv_swap, h, w, num_splits, shifted, stream=None):
+    """q|k|v projections with K and V written as the window attention's operand images (csrc/qkv.hip).
+    -> (q [B,h*w,128], workspace) for ``window_attention_images`` with the same geometry."""
+    import torch
+    lib = load()
+    x_kv = x_q if x_kv is None else x_kv
+    _f32c(x_q, "x_q"), _f32c(x_kv, "x_kv"), _f32c(wstream, "wstream")
+    b, n, c = x_q.shape
+    if c != 128 or n != h * w or x_kv.shape != x_q.shape:
+        raise MnerfError(f"qkv_window_images: expected two [B,{h * w},128] tensors, got {tuple(x_q.shape)}, {tuple(x_kv.shape)}")
+    if wstream.numel() != lib.mnerf_qkv_wstream_floats():
+        raise MnerfError(f"qkv_window_images: wstream has {wstream.numel()} floats, expected {lib.mnerf_qkv_wstream_floats()}")
+    q = torch.empty_like(x_q)
+    nbytes = int(lib.mnerf_window_attention_workspace_bytes(b, h, w, int(num_splits)))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x_q.device)
+    if stream is not None:
+        ws.record_stream(stream)
+    ew = (C.c_int32 * 3)(*[int(e) for e in ews])
+    with _on(x_q.device, stream) as st:
+        check(lib.mnerf_qkv_window_images(_ptr(wstream), ew, _ptr(x_q), _ptr(x_kv), int(bool(kv_swap)), _ptr(q),
+                                          C.c_void_p(ws.data_ptr()), nbytes, b, h, w, int(num_splits), int(bool(shifted)), st),
+              "mnerf_qkv_window_images")
+    return q, ws
+
+
+def window_attention_images(q, workspace, h, w, num_splits, shifted, out=None, stream=None):
+    """K6 on K / V operand images prepared by ``qkv_window_images`` (same geometry arguments)."""
+    import torch
+    lib = load()
+    _f32c(q, "q")
+    b, n, c = q.shape
+    if c != 128 or n != h * w:
+        raise MnerfError(f"window_attention_images: expected [B,{h * w},128], got {tuple(q.shape)}")
+    if out is None:
+        out = torch.empty_like(q)
+    with _on(q.device, stream) as st:
+        check(lib.mnerf_window_attention_images(_ptr(q), _ptr(out), b, h, w, int(num_splits), int(bool(shifted)),
+                                                C.c_void_p(workspace.data_ptr()), workspace.numel(), st),
+              "mnerf_window_attention_images")
+    return out
 
 
 def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):

@@ -186,7 +186,15 @@ def test_qkv_projection_matches_float64(kv_swap, n_seq, seq_len):
 
 def test_pack_qkv_encodes_three_scaled_matrices():
     """CPU: the q|k|v stream decodes back to the three weight matrices (fragment layout of csrc/qkv.hip: unit (step t,
-    block m) = [hi | lo] x 64 lanes x 8, lane (n, half) holds W[32 m + n][16 t + 8 half + j] * 2^ew)."""
+    block m) = [hi | lo] x 64 lanes x 8, lane (n, half) holds W[32 m + n][16 t + 8 half + j] * 2^ew), Wk with its rows
+    in the attention's operand order: register 16 m + r = 8 t + j of lane half `half` <-> channel 16 t + 8 half + j."""
+    order = G.K_ROW_ORDER
+    for m in range(4):
+        for r in range(16):
+            for half in range(2):
+                row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * half          # accumulator row of register (m, r)
+                t, j = (16 * m + r) >> 3, (16 * m + r) & 7
+                assert order[row] == 16 * t + 8 * half + j
     rng = np.random.default_rng(4)
     ws = [(rng.standard_normal((128, 128)) * s).astype(np.float32) for s in (0.05, 1.7, 0.004)]
     stream, ews = G.pack_qkv(*ws)
@@ -200,7 +208,8 @@ def test_pack_qkv_encodes_three_scaled_matrices():
             for m in range(4):
                 for j in range(8):
                     mat[32 * m + (lane & 31), 16 * t + 8 * (lane >> 5) + j] = full[t, m, lane, j]
-        assert np.abs(np.ldexp(mat, -ews[p]) - ws[p]).max() < 2.0 ** -20 * np.abs(ws[p]).max()
+        want = ws[p][G.K_ROW_ORDER] if p == 1 else ws[p]   # Wk's rows are stored in the attention's operand order
+        assert np.abs(np.ldexp(mat, -ews[p]) - want).max() < 2.0 ** -20 * np.abs(ws[p]).max()
         assert 2.0 ** 13 <= np.abs(np.ldexp(ws[p].astype(np.float64), ews[p])).max() < 2.0 ** 14 * 1.0001
 
 
@@ -215,5 +224,33 @@ def test_emulated_qkv_data_path_matches_float64():
     ops = (x.T.reshape(8, 2, 8, 50) * np.ldexp(np.float32(1), eg)).astype(np.float32)
     for p in range(3):
         y = _split_products(frag[p], ops) * np.ldexp(1.0, -(ews[p] + eg))           # [128, N]
-        want = ws[p].astype(np.float64) @ x.astype(np.float64).T
+        want = (ws[p][G.K_ROW_ORDER] if p == 1 else ws[p]).astype(np.float64) @ x.astype(np.float64).T
         assert np.abs(y - want).max() < 2e-6 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv_swap,shifted,b,h,w,splits", [(False, False, 2, 8, 12, 2), (True, True, 4, 10, 10, 2),
+                                                          (True, True, 6, 64, 80, 2), (False, False, 2, 6, 6, 1)])
+def test_qkv_window_images_path_equals_the_tensor_path(kv_swap, shifted, b, h, w, splits):
+    """q|k|v with K / V written as attention operand images + attention on those images against the same projections
+    as tensors + attention with its own operand pre-pass (the two share every product and gain rule), and against the
+    oracle's window attention on float64 projections."""
+    from matchnerf_amd import hip
+    from matchnerf_amd.gmflow import pack_qkv
+    from oracle import matchnerf_oracle as O
+    gen = torch.Generator().manual_seed(b * 100 + h)
+    ws = [torch.randn(128, 128, generator=gen) * 0.09 for _ in range(3)]
+    x = torch.randn(b, h * w, 128, generator=gen) * 2.0 ** torch.randint(-2, 3, (b, h * w, 1), generator=gen).float()
+    y = x if not kv_swap else torch.randn(b, h * w, 128, generator=gen)
+    stream, ews = pack_qkv(*ws)
+    sd = torch.from_numpy(stream).cuda()
+    q1, img = hip.qkv_window_images(sd, ews, x.cuda(), y.cuda(), kv_swap, h, w, splits, shifted)
+    out1 = hip.window_attention_images(q1, img, h, w, splits, shifted)
+    q2, k2, v2 = hip.qkv_projection(sd, ews, x.cuda(), y.cuda(), kv_swap)
+    out2 = hip.window_attention(q2, k2, v2, h, w, splits, shifted, math=hip.WA_PRESPLIT_F16)
+    assert torch.equal(q1, q2)
+    assert float((out1 - out2).abs().max()) <= 1e-6 * float(out2.abs().max())
+    ys = torch.cat([y[b // 2:], y[:b // 2]], 0) if kv_swap else y
+    qd, kd, vd = (inp.double() @ wt.double().t() for inp, wt in ((x, ws[0]), (ys, ws[1]), (ys, ws[2])))
+    ref = O.window_attention(qd.float(), kd.float(), vd.float(), h, w, splits, shifted)
+    assert float((out1.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
