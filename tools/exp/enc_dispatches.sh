@@ -6,11 +6,8 @@ python - <<PY
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("/tmp/enc_prof/**/*.db", recursive=True)[0])
 rows = db.cursor().execute("select name,start,end from kernels order by start").fetchall()
-wa = [i for i, r in enumerate(rows) if "wa_presplit" in r[0]]
-first = [i for i in wa if all("wa_presplit" not in rows[j][0] for j in range(max(0, i - 300), i) if rows[i][1] - rows[j][1] < 2e6)]
-a = first[-1]
-while a > 0 and rows[a][1] - rows[a - 1][2] < 3e5 and a > first[-1] - 80: a -= 1
-b = len(rows)
+stem = [i for i, r in enumerate(rows) if "conv_stem_kernel" in r[0]]
+a, b = stem[-2], stem[-1]   # one steady-state pass: from one stem convolution to the next
 tot = 0.0
 for n, s, e in rows[a:b]:
     tot += (e - s) / 1e3
