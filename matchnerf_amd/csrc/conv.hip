@@ -42,9 +42,9 @@ struct ConvParams {
   const float* add_cl;        // [h_out * w_out][c_out] added to a channel-last result (position tile), or NULL
 };
 
-// NMB: 32-row blocks of output channels; CONV_TPW: 32-pixel tiles per wave (2, or 1 when that is what it takes to give
+// NMB: 32-row blocks of output channels; TPW: 32-pixel tiles per wave (2, or 1 when that is what it takes to give
 // every CU a workgroup); CL: the input is stored channel-last (a lane's 8 channels are two float4)
-template <int NMB, int CONV_TPW, bool CL>
+template <int NMB, int TPW, bool CL>
 __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   extern __shared__ __attribute__((aligned(16))) float conv_smem[];
   const unsigned buf0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)conv_smem;
@@ -65,12 +65,12 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   // ---- this lane's output pixels
   const int hw_out = P.h_out * P.w_out;
   const long long n_pix = (long long)P.n_img * hw_out;
-  int oy[CONV_TPW], ox[CONV_TPW], oimg[CONV_TPW];
-  long long ibase[CONV_TPW], obase[CONV_TPW];
-  bool live[CONV_TPW];
+  int oy[TPW], ox[TPW], oimg[TPW];
+  long long ibase[TPW], obase[TPW];
+  bool live[TPW];
 #pragma unroll
-  for (int t = 0; t < CONV_TPW; ++t) {
-    const long long p = ((long long)blockIdx.x * CONV_NW + wave) * (32 * CONV_TPW) + t * 32 + n;
+  for (int t = 0; t < TPW; ++t) {
+    const long long p = ((long long)blockIdx.x * CONV_NW + wave) * (32 * TPW) + t * 32 + n;
     live[t] = p < n_pix;
     const long long pc = live[t] ? p : n_pix - 1;
     const int img = (int)(pc / hw_out), rem = (int)(pc - (long long)img * hw_out);
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   // i+1 are requested before the 12..24 x 2 matrix instructions of iteration i, so an L2 round trip fits under them.
   // Loads are unconditional from a clamped address and zeroed by a select (padding): no branches in the loop.
   int tap = 0, cpair = 0;
-  long long toff[CONV_TPW];
-  bool tok[CONV_TPW];
+  long long toff[TPW];
+  bool tok[TPW];
   auto tap_geometry = [&]() {
     const int dy = tap / P.ksize - pad, dx = tap % P.ksize - pad;
 #pragma unroll
-    for (int t = 0; t < CONV_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       const int yy = oy[t] * P.stride + dy, xx = ox[t] * P.stride + dx;
       tok[t] = live[t] && yy >= 0 && yy < h_eff && xx >= 0 && xx < w_eff;
       const int yc = min(max(yy, 0), h_eff - 1), xc = min(max(xx, 0), w_eff - 1);
@@ -104,11 +104,11 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
     }
   };
   const int cpairs = P.c_in >> 5, n_iter = n_steps >> 1;
-  float vn[CONV_TPW][16];  // [tile][K16-step of the pair * 8 + j], as loaded: the padding mask is applied at the USE
-  bool vok[CONV_TPW];      // (a select next to the load would make the wave wait for the data one iteration early)
+  float vn[TPW][16];  // [tile][K16-step of the pair * 8 + j], as loaded: the padding mask is applied at the USE
+  bool vok[TPW];      // (a select next to the load would make the wave wait for the data one iteration early)
   auto load_pair = [&]() {
 #pragma unroll
-    for (int t = 0; t < CONV_TPW; ++t) {
+    for (int t = 0; t < TPW; ++t) {
       const float* src = P.in + toff[t] + (long long)(32 * cpair) * P.sc;
       vok[t] = tok[t];
 #pragma unroll
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   tap_geometry();
   load_pair();
 
-  f32x16 acc[CONV_TPW][NMB];
+  f32x16 acc[TPW][NMB];
 #pragma unroll
-  for (int t = 0; t < CONV_TPW; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int m = 0; m < NMB; ++m) acc[t][m] = (f32x16)(0.0f);
 
@@ -146,11 +146,11 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
     if (seg + 1 < P.n_seg) stage(seg + 1);
     const unsigned cur = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
     for (int it = 0; it < seg_iters; ++it, ++iter) {
-      PartsH b[2][CONV_TPW];
+      PartsH b[2][TPW];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < CONV_TPW; ++t) {
+        for (int t = 0; t < TPW; ++t) {
           float v8[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v8[j] = vok[t] ? vn[t][8 * u + j] : 0.0f;
@@ -166,11 +166,11 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
           const f16x8 ah = __builtin_bit_cast(f16x8, a[unit * 128]), al = __builtin_bit_cast(f16x8, a[unit * 128 + 64]);
           // the two pixel tiles alternate: no matrix instruction has the accumulator of its predecessor
 #pragma unroll
-          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].lo, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].lo, acc[t][m]);
 #pragma unroll
-          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(al, b[u][t].hi, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(al, b[u][t].hi, acc[t][m]);
 #pragma unroll
-          for (int t = 0; t < CONV_TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].hi, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].hi, acc[t][m]);
         }
     }
     segment_wait();   // this wave's pieces of the next segment (and its operand prefetch) have landed
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   __syncthreads();
   float omax = 0.0f;
 #pragma unroll
-  for (int t = 0; t < CONV_TPW; ++t) {
+  for (int t = 0; t < TPW; ++t) {
     if (!live[t]) continue;
     // F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) of `add_up` at this pixel (superres.py:37):
     // source index max(0.5 (dst + 0.5) - 0.5, 0), second tap clamped at the border - torch's formula and order
