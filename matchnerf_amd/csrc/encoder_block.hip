@@ -81,8 +81,24 @@ __device__ __forceinline__ void eb_layer_norm(f32x16 (&v)[4], const float* ln_w,
     }
 }
 
-// nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2))
-__device__ __forceinline__ float eb_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// nn.GELU() (exact): 0.5 x (1 + erf(x / sqrt 2)).  The kernel evaluates it 512 times per lane and FFN layer, and the
+// library erff (~50 VALU instructions, two code paths) made the kernel VALU-bound: 27.8 k VALU against 2.5 k matrix
+// instructions per wave (PMC, profiles/r2_07_encoder_pmc_summary.txt).  erf here is Abramowitz & Stegun 7.1.26,
+//   erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + 0.3275911 z),  z >= 0,
+// |error| <= 1.5e-7 ABSOLUTE - which is what GELU needs: erf enters as 1 + erf, so the error of the result is
+// <= 0.75e-7 |x|, a relative 1.5e-7 wherever GELU is not itself vanishing.  16 instructions, no branch.
+__device__ __forceinline__ float eb_gelu(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = 1.061405429f;
+  p = __builtin_fmaf(p, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float erfc_z = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // 1 - erf(|x| / sqrt 2)
+  // 1 + erf(x / sqrt 2) = 2 - erfc_z for x >= 0, erfc_z for x < 0
+  return 0.5f * x * (x >= 0.0f ? 2.0f - erfc_z : erfc_z);
+}
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
