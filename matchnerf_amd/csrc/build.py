@@ -10,8 +10,21 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "decoder.hip", "encoder_block.hip", "geometry.hip",
-           "instance_norm.hip", "qkv.hip", "render_chunk.hip", "window_attention.hip"]
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "decoder.hip", "decoder_fused", "encoder_block.hip",
+           "geometry.hip", "instance_norm.hip", "qkv.hip", "render_chunk.hip", "window_attention.hip"]
+# objects that are a second compilation of another source: object name -> (source, extra flags).
+# decoder_fused: the one-launch ray chunk (decoder.hip, MNERF_DECODER_PART=1).  Its workgroups run the cost-volume walk on
+# SIMDs where another workgroup issues 16-bit 32x32x16 matrix instructions; packed-fp32 vector instructions lose results
+# in lanes 48-63 there, so that object is built without them: the walk's channel-pair arithmetic is
+# one instruction per channel (cv_walk.hpp) and the SLP vectoriser is off (EXTRA_FLAGS below).
+DERIVED = {"decoder_fused": ("decoder.hip", ["-DMNERF_DECODER_PART=1"])}
+# per-source extra flags.  cost_volume.hip: the same rule for the stand-alone kernel (it may share SIMDs with 16-bit MFMA
+# waves of ANY kernel on another stream; measured next to this library's decoder), and the same arithmetic as the walk
+# inside the one-launch form, so that the two forms stay bit-identical.
+# decoder.hip (both parts): the same flag — the two forms of the ray chunk are bit-identical only if their trunks are
+# compiled alike, and the trunk's own packed multiplies sat next to the partner workgroup's matrix instructions too;
+# measured neutral (19.60 vs 19.75 ms per frame).
+EXTRA_FLAGS = {"cost_volume.hip": ["-fno-slp-vectorize"], "decoder.hip": ["-fno-slp-vectorize"]}
 DECODER_SOURCES = ["decoder.hip", "split_f16.hpp", "cv_walk.hpp", "common.hpp"]  # what decoder_kernel is compiled from
 # -amdgpu-use-amdgpu-trackers: the AMDGPU register-pressure trackers in the scheduler; the fused decoder spills 57 instead
 # of 108 vector registers with them (decoder 20.8 -> 20.15 ms per frame on MI355X), everything else is unchanged
@@ -26,7 +39,7 @@ def source_hash():
     are left out: a change in the encoder does not change the decoder's counters.)"""
     import hashlib
     import re
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256(" ".join(FLAGS + EXTRA_FLAGS.get("decoder.hip", [])).encode())
     for name in sorted(DECODER_SOURCES):
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
@@ -51,15 +64,24 @@ def build(force=False, verbose=True):
     deps = [os.path.join(HERE, h) for h in ("common.hpp", "cv_walk.hpp", "split_f16.hpp")] + [os.path.join(PKG, "..", "include", "mnerf.h")]
     objs = []
     for src in SOURCES:
+        extra = []
+        name = os.path.splitext(src)[0]
+        if src in DERIVED:
+            src, extra = DERIVED[src]
+        extra = extra + EXTRA_FLAGS.get(src, [])
         sp = os.path.join(HERE, src)
         if not os.path.exists(sp):
             raise FileNotFoundError(sp)
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        if force or _newer(sp, obj) or any(_newer(d, obj) for d in deps):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+        obj = os.path.join(objdir, name + ".o")
+        cmd = [hipcc] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+        stamp = obj + ".cmd"  # the command line an object was built with: a change of flags rebuilds it
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _newer(sp, obj) or any(_newer(d, obj) for d in deps):
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
         objs.append(obj)
     if force or any(_newer(o, OUT) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs

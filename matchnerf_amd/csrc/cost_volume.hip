@@ -59,9 +59,14 @@ __device__ __forceinline__ float group_reduce(float v, int lanes_per_group) {
 #ifndef CV_WAVES_PER_SIMD
 #define CV_WAVES_PER_SIMD 2
 #endif
+#ifdef CV_PROBE_DUP
+#define CV_DBG_PARAM , unsigned* __restrict__ dbg
+#else
+#define CV_DBG_PARAM
+#endif
 __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mnerf_scene sc, mnerf_rays R,
                                                           int cond_stride,
-                                                          float* __restrict__ cond) {
+                                                          float* __restrict__ cond CV_DBG_PARAM) {
   const int sub = threadIdx.x & 7;
   const int slot_in_wg = threadIdx.x >> 3;  // 32 sample slots per workgroup
   const int S = R.n_samples;
@@ -160,6 +165,29 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
       const Bilin b = bilin_setup(u, w_, R.height, R.width);
       const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
       const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+#ifdef CV_PROBE_DUP
+      {  // race probe: the same four taps loaded a second time (opaque addresses); any difference is recorded
+        int o00 = b.o00, o01 = b.o01, o10 = b.o10, o11 = b.o11;
+        asm volatile("" : "+v"(o00), "+v"(o01), "+v"(o10), "+v"(o11));
+        const float4 r00 = img[o00], r01 = img[o01], r10 = img[o10], r11 = img[o11];
+        const bool d0 = t00.x != r00.x || t00.y != r00.y || t00.z != r00.z, d1 = t01.x != r01.x || t01.y != r01.y || t01.z != r01.z,
+                   d2 = t10.x != r10.x || t10.y != r10.y || t10.z != r10.z, d3 = t11.x != r11.x || t11.y != r11.y || t11.z != r11.z;
+        if (dbg && (d0 || d1 || d2 || d3)) {
+          const unsigned k = atomicAdd(dbg, 1u);
+          if (k < 64) {
+            unsigned* o = dbg + 16 + k * 40;
+            o[0] = threadIdx.x & 63, o[1] = (unsigned)ray, o[2] = (unsigned)j, o[3] = (unsigned)v;
+            o[4] = (d0 ? 1u : 0u) | (d1 ? 2u : 0u) | (d2 ? 4u : 0u) | (d3 ? 8u : 0u);
+            o[5] = (unsigned)o00, o[6] = (unsigned)o01, o[7] = (unsigned)o10, o[8] = (unsigned)o11;
+            const float f[24] = {t00.x, t00.y, t00.z, t01.x, t01.y, t01.z, t10.x, t10.y, t10.z, t11.x, t11.y, t11.z,
+                                 r00.x, r00.y, r00.z, r01.x, r01.y, r01.z, r10.x, r10.y, r10.z, r11.x, r11.y, r11.z};
+            for (int q = 0; q < 24; ++q) o[9 + q] = __float_as_uint(f[q]);
+            o[33] = __float_as_uint(b.w00), o[34] = __float_as_uint(b.w01), o[35] = __float_as_uint(b.w10), o[36] = __float_as_uint(b.w11);
+            o[37] = blockIdx.x, o[38] = (unsigned)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+          }
+        }
+      }
+#endif
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
       if (live) {
@@ -291,8 +319,15 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
       hipLaunchKernelGGL(cost_volume_lean_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                          *scene, *rays, cond_stride, cond);
   } else {
+#ifdef CV_PROBE_DUP
+    unsigned* dbg = nullptr;
+    if (const char* e = getenv("MNERF_CVDBG_PTR")) dbg = (unsigned*)strtoull(e, nullptr, 0);
+    hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       *scene, *rays, cond_stride, cond, dbg);
+#else
     hipLaunchKernelGGL(cost_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        *scene, *rays, cond_stride, cond);
+#endif
   }
   return mnerf_check_launch("mnerf_cost_volume");
 }

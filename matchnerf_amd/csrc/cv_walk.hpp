@@ -63,6 +63,30 @@ __device__ __forceinline__ Bilin bilin_setup(float u, float v, int h, int w) {
 // a wave's four slots rarely cross a texel boundary in the same step.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+// Interpolation / dot-product arithmetic on channel pairs, WITHOUT packed-fp32 vector instructions (one v_fma_f32 / v_mul_f32
+// per channel; the two source files that include this header are also compiled with -fno-slp-vectorize, build.py).
+// Measured on MI355X (tools/exp/race_probe.py): v_pk_fma_f32 / v_pk_mul_f32 of a wave lose their
+// result in lanes 48-63 now and then while ANOTHER wave of the same SIMD issues v_mfma_f32_32x32x16_{f16,bf16} — the
+// one-launch ray chunk (walk and MFMA trunk in co-resident workgroups) and this kernel next to the decoder on a second
+// stream both produced a few wrong conditioning rows per launch, always in the last 16 lanes of a wave, one walk step at a
+// time; never next to the exact-f32 decoder, never alone, never in this form.  The packed form (CVW_PK=1, probe builds) is
+// not faster either: the kernel is bound by the texture-address unit (9.9 vs 10.1 ms per frame).
+#ifndef CVW_PK
+#define CVW_PK 0
+#endif
+#if !CVW_PK
+__device__ __forceinline__ float cvw_opaque(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { return v2f{cvw_opaque(a.x * b.x), cvw_opaque(a.y * b.y)}; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) {
+  return v2f{cvw_opaque(__builtin_fmaf(a.x, b.x, c.x)), cvw_opaque(__builtin_fmaf(a.y, b.y, c.y))};
+}
+#else
+__device__ __forceinline__ v2f pk_mul(v2f a, v2f b) { return a * b; }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 
 // pass-1 record of one (sample, view, scale).  The four taps of a quad are kept in four register
 // sets named by the PARITY of the texel's row and column (E/O), not by their position in the quad:
@@ -96,6 +120,18 @@ __device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {  /
   return r;
 }
 
+#ifndef CVW_PROBE
+#define CVW_PROBE 0  // race probes (tools/exp/race_probe.py): 3 shuffles instead of DPP, 4 unconditional tap reloads,
+#endif               // 5 / 7 hard waits at the slot-local LDS hand-offs, 6 no LDS atomic
+// slot-local LDS hand-off between lanes of one wave
+__device__ __forceinline__ void cvw_handoff() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#if CVW_PROBE == 5 || CVW_PROBE == 7
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #ifndef CVW_SEG
 #define CVW_SEG 16  // samples per walk of the stand-alone kernel (the fused ray-chunk kernel walks 8)
 #endif
@@ -124,6 +160,11 @@ __device__ __forceinline__ void tap_load(v2f (&t)[CPL / 2], const float* __restr
     t[2 * k] = a.lo;
     t[2 * k + 1] = a.hi;
   }
+#ifdef CVW_DEBUG_WAIT
+  // probe build: every tap load is complete before anything else is issued (would hide a result consumed early)
+#pragma unroll
+  for (int k = 0; k < CPL / 2; ++k) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[k]) : : "memory");
+#endif
 }
 
 // Expanded walk record of one (sample, view) at the scale being walked: texel held by each parity set
@@ -149,6 +190,13 @@ template <int CPL>
 __device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __restrict__ map, const float4 ix,
                                             unsigned lane_bytes) {
   const int i00 = __float_as_int(ix.x), i01 = __float_as_int(ix.y), i10 = __float_as_int(ix.z), i11 = __float_as_int(ix.w);
+#if CVW_PROBE == 4
+  tap_load<CPL>(q.t[0][0], map, i00, lane_bytes);
+  tap_load<CPL>(q.t[0][1], map, i01, lane_bytes);
+  tap_load<CPL>(q.t[1][0], map, i10, lane_bytes);
+  tap_load<CPL>(q.t[1][1], map, i11, lane_bytes);
+  return;
+#endif
   if (i00 != q.idx[0][0]) { tap_load<CPL>(q.t[0][0], map, i00, lane_bytes); q.idx[0][0] = i00; }
   if (i01 != q.idx[0][1]) { tap_load<CPL>(q.t[0][1], map, i01, lane_bytes); q.idx[0][1] = i01; }
   if (i10 != q.idx[1][0]) { tap_load<CPL>(q.t[1][0], map, i10, lane_bytes); q.idx[1][0] = i10; }
@@ -164,6 +212,11 @@ __device__ __forceinline__ float dpp_add(float v) {
 // all-reduce over LPG adjacent lanes (LPG | 16, aligned): same pairing tree as the xor butterfly
 template <int LPG>
 __device__ __forceinline__ float dpp_group_sum(float v) {
+#if CVW_PROBE == 3
+#pragma unroll
+  for (int m = 1; m < LPG; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
   if (LPG >= 2) v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
   if (LPG >= 4) v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
   if (LPG >= 8) v = dpp_add<0x141>(v);  // row_half_mirror
@@ -190,17 +243,17 @@ __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const fl
     v2f dot2 = {0.f, 0.f}, na2 = {0.f, 0.f}, nb2 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < CPL / 2; ++k) {
-      v2f fa = qa.t[0][0][k] * A00;
-      fa = __builtin_elementwise_fma(qa.t[0][1][k], A01, fa);
-      fa = __builtin_elementwise_fma(qa.t[1][0][k], A10, fa);
-      fa = __builtin_elementwise_fma(qa.t[1][1][k], A11, fa);
-      v2f fb = qb.t[0][0][k] * B00;
-      fb = __builtin_elementwise_fma(qb.t[0][1][k], B01, fb);
-      fb = __builtin_elementwise_fma(qb.t[1][0][k], B10, fb);
-      fb = __builtin_elementwise_fma(qb.t[1][1][k], B11, fb);
-      dot2 = __builtin_elementwise_fma(fa, fb, dot2);
-      na2 = __builtin_elementwise_fma(fa, fa, na2);
-      nb2 = __builtin_elementwise_fma(fb, fb, nb2);
+      v2f fa = pk_mul(qa.t[0][0][k], A00);
+      fa = pk_fma(qa.t[0][1][k], A01, fa);
+      fa = pk_fma(qa.t[1][0][k], A10, fa);
+      fa = pk_fma(qa.t[1][1][k], A11, fa);
+      v2f fb = pk_mul(qb.t[0][0][k], B00);
+      fb = pk_fma(qb.t[0][1][k], B01, fb);
+      fb = pk_fma(qb.t[1][0][k], B10, fb);
+      fb = pk_fma(qb.t[1][1][k], B11, fb);
+      dot2 = pk_fma(fa, fb, dot2);
+      na2 = pk_fma(fa, fa, na2);
+      nb2 = pk_fma(fb, fb, nb2);
     }
     const float dot = dpp_group_sum<LPG>(dot2.x + dot2.y);
     const float na = dpp_group_sum<LPG>(na2.x + na2.y);
@@ -225,7 +278,11 @@ __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const fl
       const float c = k_dot / (da * db);
 #endif
       const int js_mine = js - (LPG - 1) + (sub & (LPG - 1));
+#if CVW_PROBE == 6
+      cs_group[js_mine * cs_stride] += c;
+#else
       __hip_atomic_fetch_add(cs_group + js_mine * cs_stride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
     }
   }
 }
@@ -292,7 +349,11 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
       uv_lds[(js * V + v) * 2 + 1] = w_;
       const Bilin b = bilin_setup(u, w_, R.height, R.width);
       const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
-      const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+      float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+#if CVW_PROBE == 9
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" : "+v"(t00.x), "+v"(t00.y), "+v"(t00.z), "+v"(t01.x), "+v"(t01.y), "+v"(t01.z),
+                   "+v"(t10.x), "+v"(t10.y), "+v"(t10.z), "+v"(t11.x), "+v"(t11.y), "+v"(t11.z) : : "memory");
+#endif
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
       if (live) {
@@ -310,9 +371,7 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
   }
   for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
   // slot-local LDS hand-off: the lanes of a slot belong to one wave => wave-level ordering
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  cvw_handoff();
 
   // ---- pass 2: walk the segment once per (pair, scale) with the two texel quads in registers
   int p = 0;
@@ -330,8 +389,7 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
         const int goff = s ? G0 : 0;
         float* cs_group = cs_lds + goff + sub / lpg;  // this lane's channel group; it owns sample jb + sub % lpg
         // walk records of this (pair, scale): lane `sub` expands samples sub, sub+LPS, .. of views a and b
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the previous walk's reads of wrec_lds are done
-        __builtin_amdgcn_wave_barrier();
+        cvw_handoff();  // the previous walk's reads of wrec_lds are done
 #pragma unroll
         for (int half = 0; half < SPL; ++half) {
           const int js = sub + LPS * half;
@@ -346,9 +404,7 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
             wrec_lds[(js * 2 + side) * 2 + 1] = rw;
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        cvw_handoff();
         switch (lpg) {
           case 1: lean_walk<CPL, 1, SEG>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
           case 2: lean_walk<CPL, 2, SEG>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes); break;
@@ -361,15 +417,14 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  cvw_handoff();
   // ---- write the averaged cosines: lane `sub` writes samples sub, sub+LPS, ..
 #pragma unroll
   for (int half = 0; half < SPL; ++half) {
     const int js = sub + LPS * half;
     if (js < SEG && ray_live && (j0 + js < S)) {
       float* out = row0 + (size_t)js * cond_stride;
+#pragma clang loop vectorize(disable) interleave(disable)  // (a vectorised multiply is a packed-fp32 instruction)
       for (int c = 0; c < sumG; ++c) cv_store<NT>(out + c, cs_lds[js * cs_stride + c] * inv_pairs);
     }
   }

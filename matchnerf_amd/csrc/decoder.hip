@@ -38,6 +38,15 @@
 // overlap the other's MFMA phases.
 #include <stdlib.h>
 
+// This file is compiled TWICE (matchnerf_amd/csrc/build.py): MNERF_DECODER_PART 0 = the staged decoder kernels and their
+// entry points (decoder.o), 1 = the one-launch form with the cost-volume walk inside (decoder_fused.o).  The second
+// part is built without packed-fp32 vector instructions in the walk (cv_walk.hpp + -fno-slp-vectorize), because its
+// workgroups share SIMDs with workgroups that issue 16-bit 32x32x16 matrix instructions: see "packed fp32 next to
+// 16-bit MFMA" in DESIGN.md (section 4) — what round 2 recorded as an unexplained race of co-resident fused workgroups.
+#ifndef MNERF_DECODER_PART
+#define MNERF_DECODER_PART 0
+#endif
+
 #include "cv_walk.hpp"
 #include "split_f16.hpp"
 
@@ -69,6 +78,15 @@ struct DecSched {
 #ifdef MNERF_TIMELINE
   unsigned long long* tl;
 #endif
+#ifdef MNERF_FUSED_DEBUG
+  // debug build of the one-launch form (tools/exp/race_probe.py): what the trunk consumed, where each tile ran
+  unsigned dbg_flags;   // 2 drain DMA + barrier before the walk, 4 first weight segment requested after the walk,
+                        // 8 full wait + barrier after the FiLM inputs are read, 32 NaN-poison of the walk's LDS,
+                        // 64 weight segments copied with plain loads + LDS stores instead of LDS-DMA
+  float* dbg_rows;      // [rays*S][32] conditioning inputs as read by the trunk
+  float* dbg_nv;        // [rays*S] mask sum as read by the trunk
+  unsigned* dbg_tile;   // [tiles][4] blockIdx, HW_ID, XCC_ID, low clock word
+#endif
   int stagger_sleeps;  // one-time start delay (x s_sleep 127) of the 2nd resident workgroup of a CU
   int stagger_mode;    // which workgroups wait: 0 odd HW wave slot, 1 upper half of grid, 2 (b>>3)&1, 3 all
   int n_seg;
@@ -89,6 +107,16 @@ __device__ __forceinline__ void prefetch_segment(const float* __restrict__ wstre
   if (seg >= sch.n_seg) return;
   const float* src = wstream + sch.seg_off[seg] + lane * 4;
   const int pieces = sch.seg_floats[seg] >> 8;
+#ifdef MNERF_FUSED_DEBUG
+  if (sch.dbg_flags & 64u) {  // no LDS-DMA at all: plain loads + LDS stores (compiler-tracked)
+    typedef v4f32 __attribute__((address_space(3)))* lds_v4f32_ptr;
+    for (int p = wave; p < pieces; p += NW) {
+      const v4f32 t = *reinterpret_cast<const v4f32*>(src + p * 256);
+      *((lds_v4f32_ptr)(size_t)(base + (unsigned)p * 1024u + (unsigned)lane * 16u)) = t;
+    }
+    return;
+  }
+#endif
   for (int p = wave; p < pieces; p += NW)
     glds16(src + p * 256, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
 }
@@ -380,13 +408,16 @@ struct Smem {
 // (the FiLM weights: 17 KiB at <= 32 conditioning inputs); both are dead before the weight pipeline needs them.
 #define CVF_SEG 8
 #define CVF_COND_OFF_FLOATS (17 * 256)
-// The fused form asks for more than half of a CU's 160 KiB of LDS, i.e. ONE of its workgroups per CU.  Measured on
-// MI355X: with two co-resident workgroups a handful of rays per 327,680-ray frame (<= 14, |error| <= 4e-3) differed
-// from run to run and from the staged form; with one workgroup per CU (this setting, or a 256-workgroup grid) every
-// run is bit-identical to the staged form.  The cause was not found: the walk phase has no inter-wave communication,
-// and zero-filling LDS, draining the weight DMA before the walk and extra workgroup barriers changed nothing.  The
-// fused form is the slower one either way (the walk needs the stand-alone kernel's 16 waves per CU).
-#define CVF_LDS_BYTES (84 * 1024)
+// Two workgroups of the fused form share a CU like those of the staged decoder (68.25 KiB of LDS each).  Round 2 saw a
+// handful of wrong rays per frame in that configuration and reserved the CU (84 KiB) without finding the cause.  Round 3
+// found it (tools/exp/race_probe.py): the conditioning rows were wrong, always in lanes 48-63 of a
+// wave, one walk step (or one pass-1 view) at a time — packed-fp32 vector instructions (v_pk_fma_f32 / v_pk_mul_f32) of
+// the walk lose their result in the last lane quarter while ANOTHER wave of the SIMD issues v_mfma_f32_32x32x16_{f16,
+// bf16}; the stand-alone cost volume shows the same faults when it runs next to this decoder on a second stream, not next
+// to the exact-f32 decoder, and none once it is built without packed-fp32 instructions.  This part of the file is
+// therefore compiled with -fno-slp-vectorize (build.py; the walk's own arithmetic is unpacked in cv_walk.hpp), and the
+// occupancy restriction is gone.
+#define CVF_LDS_BYTES 0  // 0: the natural footprint (two workgroups per CU); bytes: reserve more (probes)
 #ifndef MNERF_DECODER_MINBLOCKS
 #define MNERF_DECODER_MINBLOCKS 2  // experiments: 1 = 512 registers per wave (one workgroup per CU), no spills
 #endif
@@ -539,7 +570,29 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
 
     const EncBase encb = enc_base(x, y, z, freq_mul);  // shared by the two positional-encoding stages (L0, L5)
     int seg = 0;   // running segment index; segment k lives in buffer (k & 1)
+#ifdef MNERF_FUSED_DEBUG
+    const unsigned dflags = CVF ? sch.dbg_flags : 0u;
+    if (CVF && sch.dbg_tile && tid == 0) {
+      sch.dbg_tile[tile * 4 + 0] = blockIdx.x;
+      sch.dbg_tile[tile * 4 + 1] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_ID
+      sch.dbg_tile[tile * 4 + 2] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
+      sch.dbg_tile[tile * 4 + 3] = (unsigned)__builtin_amdgcn_s_memtime();
+    }
+    if (!(dflags & 4u))
+#endif
     if (!seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
+#ifdef MNERF_FUSED_DEBUG
+    if (dflags & 2u) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (dflags & 32u) {
+      __syncthreads();
+      for (int i = tid; i < SEG_CAP_FLOATS; i += NW * 64) wbuf1[i] = __builtin_nanf("");
+      for (int i = CVF_COND_OFF_FLOATS + tid; i < SEG_CAP_FLOATS; i += NW * 64) wbuf0[i] = __builtin_nanf("");
+      __syncthreads();
+    }
+#endif
     if constexpr (CVF) {
       // ---- K1+K2 for this tile: slot = 16 lanes, unit = CVF_SEG consecutive samples of one ray
       const int nv_ = scene.n_views;
@@ -561,6 +614,23 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
     }
     load_tile_inputs(tile);  // issued before the geometry above is consumed: latency overlaps it
     const bool q_valid = n_valid > 1.0f;
+#ifdef MNERF_FUSED_DEBUG
+    if constexpr (CVF && FMT >= 1) {
+      if (sch.dbg_rows && ray_ok && jp < S) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
+          *reinterpret_cast<float4*>(sch.dbg_rows + gs * 32 + o) = cpre[i];
+        }
+        if (hl == 0) sch.dbg_nv[gs] = n_valid;
+      }
+      if (dflags & 8u) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      if (dflags & 4u) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
+    }
+#endif
     segment_wait();
     __syncthreads();  // publishes weight segment 0; in the fused form also: every lane holds its FiLM inputs, so
                       // weight buffer 1 (walk scratch) and the rows above segment 0 may be overwritten from here on
@@ -1455,6 +1525,9 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
     // weight segment now, under the compositing
     {
       seg0_in_flight = tile + tile_step < tile_end;
+#ifdef MNERF_FUSED_DEBUG
+      if (dflags & 4u) seg0_in_flight = false;
+#endif
       if (seg0_in_flight) prefetch_segment<NW>(D.wstream, sch, 0, wbuf0_lds, wave, lane);
     }
 
@@ -1537,6 +1610,18 @@ static void finish_schedule(DecSched* sch, int n, int film_steps, int enc_steps)
 #ifdef MNERF_TIMELINE
   sch->tl = nullptr;
   if (const char* e = getenv("MNERF_TIMELINE_PTR")) sch->tl = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
+#ifdef MNERF_FUSED_DEBUG
+  {
+    auto envp = [](const char* k) -> unsigned long long {
+      const char* e = getenv(k);
+      return (e && *e) ? strtoull(e, nullptr, 0) : 0ull;
+    };
+    sch->dbg_flags = (unsigned)envp("MNERF_FDBG_FLAGS");
+    sch->dbg_rows = (float*)envp("MNERF_FDBG_ROWS");
+    sch->dbg_nv = (float*)envp("MNERF_FDBG_NV");
+    sch->dbg_tile = (unsigned*)envp("MNERF_FDBG_TILE");
+  }
 #endif
   sch->stagger_sleeps = mnerf_tune().decoder_stagger;  // ~130k cycles ~ half a tile
   sch->stagger_mode = mnerf_tune().decoder_stagger_mode;
@@ -1628,6 +1713,7 @@ static bool known_format(int f) {
   return f == MNERF_WSTREAM_F32 || f == MNERF_WSTREAM_BF16X3 || f == MNERF_WSTREAM_F16X2;
 }
 
+#if MNERF_DECODER_PART == 0
 extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_stride, int32_t L_3D,
                                                 int32_t wstream_format) {
   if (!known_format(wstream_format)) return -1;
@@ -1641,12 +1727,30 @@ extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_s
   return build_schedule(&d, &s);
 }
 
+#endif  // MNERF_DECODER_PART == 0
+
 static int pick_padded_samples(int S) {
   if (S <= 32) return 32;
   if (S <= 64) return 64;
   if (S <= 128) return 128;
   if (S <= 256) return 256;
   return -1;
+}
+
+#ifdef MNERF_FUSED_DEBUG
+#define MNERF_FUSED_DEBUG_ON 1
+#else
+#define MNERF_FUSED_DEBUG_ON 0
+#endif
+// dynamic LDS of the one-launch form (see CVF_LDS_BYTES); the debug build can ask for the co-resident footprint
+static size_t mnerf_fused_lds_bytes(size_t natural) {
+#ifdef MNERF_FUSED_DEBUG
+  if (const char* e = getenv("MNERF_FDBG_LDS_KB")) {
+    const size_t kb = (size_t)atoi(e);
+    return kb == 0 ? natural : kb * 1024;
+  }
+#endif
+  return CVF_LDS_BYTES ? (size_t)CVF_LDS_BYTES : natural;
 }
 
 // Shared by mnerf_decoder_chunk (rays rebuilt in-kernel, composited outputs) and mnerf_decoder_samples
@@ -1687,38 +1791,45 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     const int tiles = (rays->n_rays + rpt - 1) / rpt;                                                \
     const int grid = tiles < resident ? tiles : resident;                                            \
     size_t lds = Smem<NW_, SP_>::TOTAL_FLOATS * sizeof(float);                                       \
-    if (CVF_) lds = CVF_LDS_BYTES; /* the fused form takes a CU for itself (see CVF_LDS_BYTES) */    \
+    if (CVF_) lds = mnerf_fused_lds_bytes(lds);                                                      \
     static std::atomic<unsigned long long> attr_set{0};                                              \
-    if (mnerf_once_per_device(attr_set))                                                             \
+    if (mnerf_once_per_device(attr_set) || MNERF_FUSED_DEBUG_ON)                                     \
       (void)hipFuncSetAttribute((const void*)decoder_kernel<NW_, SP_, FMT_, CVF_>,                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
     hipLaunchKernelGGL((decoder_kernel<NW_, SP_, FMT_, CVF_>), dim3(grid), dim3(NW_ * 64), lds, st,  \
                        *dec, sch, *view0, *rays, cond, rgb, depth, opacity, rgb_s, sigma, ext_ndc,   \
                        ext_dir, *scn);                                                               \
   } while (0)
+#if MNERF_DECODER_PART == 1
+  MNERF_REQUIRE(fused_scene, MNERF_E_NULL, "%s: the one-launch form needs the scene", who);
+#define MNERF_LAUNCH_DECODER_FMT(NW_, SP_) MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1)
+#else
+  MNERF_REQUIRE(!fused_scene, MNERF_E_UNSUPPORTED, "%s: the one-launch form lives in decoder_fused.o", who);
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_)                                   \
   do {                                                                       \
-    if (fused_scene)                                                         \
-      MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1);                                  \
-    else if (dec->wstream_format == MNERF_WSTREAM_F16X2)                     \
+    if (dec->wstream_format == MNERF_WSTREAM_F16X2)                          \
       MNERF_LAUNCH_DECODER(NW_, SP_, 2, 0);                                  \
     else if (dec->wstream_format == MNERF_WSTREAM_BF16X3)                    \
       MNERF_LAUNCH_DECODER(NW_, SP_, 1, 0);                                  \
     else                                                                     \
       MNERF_LAUNCH_DECODER(NW_, SP_, 0, 0);                                  \
   } while (0)
+#endif
   switch (Sp) {
     case 32: MNERF_LAUNCH_DECODER_FMT(4, 32); break;
     case 64: MNERF_LAUNCH_DECODER_FMT(4, 64); break;
     case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
     default:  // 128 < S <= 256: one 8-wave workgroup per CU, VALU ray attention
-      MNERF_REQUIRE(!fused_scene, MNERF_E_UNSUPPORTED, "%s: the one-launch form needs sample_intvs <= 128", who);
+#if MNERF_DECODER_PART == 1
+      MNERF_REQUIRE(false, MNERF_E_UNSUPPORTED, "%s: the one-launch form needs sample_intvs <= 128", who);
+#else
       if (dec->wstream_format == MNERF_WSTREAM_F16X2)
         MNERF_LAUNCH_DECODER(8, 256, 2, 0);
       else if (dec->wstream_format == MNERF_WSTREAM_BF16X3)
         MNERF_LAUNCH_DECODER(8, 256, 1, 0);
       else
         MNERF_LAUNCH_DECODER(8, 256, 0, 0);
+#endif
       break;
   }
 #undef MNERF_LAUNCH_DECODER_FMT
@@ -1726,6 +1837,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   return mnerf_check_launch(who);
 }
 
+#if MNERF_DECODER_PART == 1
 // The fused ray-chunk form (one launch, no workspace) exists for the shipped configuration class: split-fp16
 // stream, S <= 128, at most 32 conditioning inputs (<= 5 views), cosine groups of at most 8 lanes (G >= 2) and
 // walk scratch that fits one weight buffer.
@@ -1745,10 +1857,16 @@ bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec,
 
 int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays, float* rgb,
                               float* depth, float* opacity, void* stream) {
-  return launch_decoder("mnerf_render_chunk", dec, &sc->views[0], rays, nullptr, rgb, depth, opacity, nullptr, nullptr,
+  float *rgb_s = nullptr, *sigma = nullptr;
+#ifdef MNERF_FUSED_DEBUG
+  if (const char* e = getenv("MNERF_FDBG_RGBS")) rgb_s = (float*)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("MNERF_FDBG_SIGMA")) sigma = (float*)strtoull(e, nullptr, 0);
+#endif
+  return launch_decoder("mnerf_render_chunk", dec, &sc->views[0], rays, nullptr, rgb, depth, opacity, rgb_s, sigma,
                         nullptr, nullptr, sc, stream);
 }
 
+#else  // MNERF_DECODER_PART == 0
 extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,
                                    const mnerf_rays* rays, const float* cond, float* rgb,
                                    float* depth, float* opacity, float* dbg_rgb_s,
@@ -1778,3 +1896,4 @@ extern "C" int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, i
   return launch_decoder("mnerf_decoder_samples", dec, &none, &rays, cond, nullptr, nullptr, nullptr, rgb_s, sigma,
                         x_ndc, dir, nullptr, stream);
 }
+#endif  // MNERF_DECODER_PART

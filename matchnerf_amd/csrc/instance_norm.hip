@@ -54,9 +54,9 @@ __device__ __forceinline__ void in_merge_absmax(float m, float* red, float* out_
 }
 
 template <int THREADS, int VPT>
-__global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const float* x,
                                                                        const float* __restrict__ residual,
-                                                                       float* __restrict__ out, int plane_size, float eps,
+                                                                       float* out, int plane_size, float eps,
                                                                        int relu_inner, int relu_outer,
                                                                        float* __restrict__ out_absmax) {
   __shared__ float red[THREADS / 64];
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
 }
 
 // any plane size: three passes (the plane of a running workgroup stays in L2 / Infinity Cache between them)
-__global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256) void instance_norm_stream_kernel(const float* x,
                                                                    const float* __restrict__ residual,
-                                                                   float* __restrict__ out, int plane_size, float eps,
+                                                                   float* out, int plane_size, float eps,
                                                                    int relu_inner, int relu_outer,
                                                                    float* __restrict__ out_absmax) {
   __shared__ float red[4];

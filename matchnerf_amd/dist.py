@@ -62,8 +62,13 @@ def gather_tiles(local, counts=None):
         allc = torch.empty(world, dtype=torch.int64, device=mine.device)
         dist.all_gather_into_tensor(allc, mine)
         counts = [int(c) for c in allc.tolist()]
-    if len(counts) != world or counts[rank] != local.shape[0]:
-        raise ValueError(f"gather_tiles: rank {rank} holds {local.shape[0]} rows, counts={list(counts)} (world {world})")
+    # every rank must raise together: a rank that raised alone would leave the others waiting in the collective
+    bad_here = len(counts) != world or counts[rank] != local.shape[0]
+    flag = torch.tensor([1 if bad_here else 0], dtype=torch.int32, device="cpu" if on_host else local.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise ValueError(f"gather_tiles: rank {rank} holds {local.shape[0]} rows, counts={list(counts)} (world {world})"
+                         + ("" if bad_here else " [another rank's tile disagrees with its count]"))
     width = max(counts)
     send = local
     if local.shape[0] != width:

@@ -280,9 +280,12 @@ class TransformerLayer(nn.Module):
 
     def forward(self, source, target, h, w, splits, shifted, kv_swap=False):
         """``kv_swap`` (inference only): ``target`` is given un-swapped and read with its batch halves exchanged"""
-        params = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
-        if source.is_cuda and not (torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or
-                                                                any(p.requires_grad for p in params))):
+        # ONE decision per layer: if anything this layer touches needs a gradient, the whole layer takes the autograd
+        # path (with partial freezing, e.g. merge frozen but mlp / norm2 trainable, the fused kernels would leave the
+        # trainable parameters without a gradient and without an error)
+        needs_grad = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if source.is_cuda and not needs_grad:
             ws, ews = self._packed_qkv(source.device)
             if hip.wa_math() == hip.WA_PRESPLIT_F16:
                 # one launch: q rows + K / V written straight as the window attention's operand images
@@ -300,7 +303,7 @@ class TransformerLayer(nn.Module):
             k = self.k_proj(target)
             v = self.v_proj(target)
             msg = window_attention(q, k, v, h, w, splits, shifted)  # HIP forward; torch re-evaluation backward
-        if not torch.is_grad_enabled() or not (msg.requires_grad or source.requires_grad or self.merge.weight.requires_grad):
+        if not needs_grad:
             ws, ln, ews = self._packed_block(source.device)
             b, n, c = source.shape
             out = hip.encoder_block(msg.reshape(b * n, c), source.reshape(b * n, c).contiguous(), ws, ln, not self.no_ffn, ews)
@@ -431,13 +434,18 @@ class GMFlow(nn.Module):
         x = imgs.reshape(b * v, c, hh, ww)
         if hh == 756 and ww == 1008:  # IBRNet setting, gmflow.py:100-103
             x = F.interpolate(x, size=(768, 1024), mode="bilinear", align_corners=True)
-        h, w, ch = x.shape[2] // 8, x.shape[3] // 8, self.feature_channels
+        def _down8(n):  # three stride-2 convolutions (7x7 pad 3, 3x3 pad 1, 3x3 pad 1): ceil-like sizes
+            for _ in range(3):
+                n = (n - 1) // 2 + 1
+            return n
+        h, w, ch = _down8(x.shape[2]), _down8(x.shape[3]), self.feature_channels
         if h % splits or w % splits:
             raise ValueError(f"feature map {h}x{w} is not divisible by attn_splits={splits}")
         pe = sine_position_tokens(h // splits, w // splits, ch, x.device).repeat(splits, splits, 1).reshape(h * w, ch).contiguous()
         # [BV,h,w,C] tokens with the window position tile added (by the backbone's last convolution at inference)
         tok = self.backbone((x - self._mean) / self._std, tokens_plus=pe)
-        assert tuple(tok.shape[1:]) == (h, w, ch), tok.shape
+        if tuple(tok.shape[1:]) != (h, w, ch):
+            raise ValueError(f"backbone output {tuple(tok.shape[1:])} != expected {(h, w, ch)} for a {hh}x{ww} input")
         tok = tok.reshape(b, v, h * w, ch)
         pairs = pair_list(v)
         ia = torch.tensor([a for a, _ in pairs], device=tok.device)

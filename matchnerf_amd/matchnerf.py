@@ -60,6 +60,7 @@ class MatchNeRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ forward (matchnerf.py:32-73)
     def forward(self, batch, mode=None, render_video=False, render_path_mode="interpolate"):
+        self._frame = None  # the launch context below never outlives one forward (see _frame_ctx)
         ref_images = batch.images[:, :self.n_src_views]
         ref_feats_list = self.get_img_feat(ref_images, attn_splits_list=self.opts.encoder.attn_splits_list,
                                            cur_n_src_views=self.n_src_views)
@@ -165,16 +166,19 @@ class MatchNeRF(torch.nn.Module):
         """Launch context of one source set, built once and shared by every target pose rendered from it (all
         frames of a video, all chunks of a frame): host copies of the source cameras (they travel by value in the
         kernel arguments) and the channel-last RGBA copy of the source images.  Keyed on the identity and version
-        of the tensors, so in-place edits or a new batch rebuild it."""
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in
-                    (ref_images, ref_poses["extrinsics"], ref_poses["intrinsics"], ref_poses["near_fars"]))
+        of the tensors, so in-place edits or a new batch rebuild it; the entry holds the keyed tensors themselves, so
+        their storage cannot be freed and handed to a NEW batch at the same address while the entry lives (the caching
+        allocator does exactly that in the reference's coach loop), and ``forward`` drops the entry at its top: a
+        context is shared by the poses and chunks of ONE forward, never by two batches."""
+        keyed = (ref_images, ref_poses["extrinsics"], ref_poses["intrinsics"], ref_poses["near_fars"])
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in keyed)
         if self._frame is None or self._frame[0] != key:
             b, v, _, h, w = ref_images.shape
             ref_host = (self._host(ref_poses["extrinsics"]), self._host(ref_poses["intrinsics"]),
                         self._host(ref_poses["near_fars"]))
             images_cl = torch.zeros(b, v, h, w, 4, device=ref_images.device)
             images_cl[..., :3] = ref_images.detach().permute(0, 1, 3, 4, 2)
-            self._frame = (key, ref_host, images_cl)
+            self._frame = (key, ref_host, images_cl, keyed)
         return self._frame[1], self._frame[2]
 
     def _tgt_host(self, tgt_pose):

@@ -240,3 +240,32 @@ def test_coach_test_model_reports_psnr(tmp_path, monkeypatch):
     rep = c.test_model()
     assert list(rep) == ["dtu"] and len(rep["dtu"]) == 1
     assert all(np.isfinite(v) and 0 < v < 60 for v in rep["dtu"].values())
+
+
+def test_two_same_shaped_batches_do_not_share_launch_context():
+    """the per-source-set launch context (host cameras + RGBA source images) must never survive from
+    one batch to the next.  Batch A is rendered and FREED, batch B of the same shape is then allocated (the caching
+    allocator hands out the same addresses, version 0, same shapes: the old cache key matched) and rendered by the same
+    model; the result must equal a fresh model's."""
+    g, cfg, sd, _ = golden_case("c1_default")
+    opt, model = build_model(g["meta"])
+    batch_a = to_batch(g)
+    with torch.no_grad():
+        model(batch_a, mode="test")
+    ptr_a = batch_a.images.data_ptr()
+    del batch_a
+    gb = {k: np.array(g[k]) for k in ("images", "extrinsics", "intrinsics", "near_fars")}
+    gb["images"] = np.ascontiguousarray(gb["images"][..., ::-1, :]) * 0.5 + 0.25   # other colours
+    gb["extrinsics"][0, :, 0, 3] += 0.05                                            # other cameras
+    batch_b = to_batch(gb)
+    same_address = batch_b.images.data_ptr() == ptr_a   # the situation the advisor describes (not guaranteed)
+    with torch.no_grad():
+        out_b = model(batch_b, mode="test")
+        _, fresh = build_model(g["meta"])
+        ref_b = fresh(to_batch(gb), mode="test")
+    assert torch.equal(out_b.rgb, ref_b.rgb) and torch.equal(out_b.depth, ref_b.depth), same_address
+    # and the context is dropped at the top of every forward
+    model._frame = ("stale",)
+    with torch.no_grad():
+        again = model(batch_b, mode="test")
+    assert torch.equal(again.rgb, ref_b.rgb)

@@ -1,0 +1,101 @@
+"""Stress tests of the two ray-chunk forms under co-residency (DESIGN.md section 4 "packed fp32
+next to 16-bit MFMA").
+
+Round 2 saw run-to-run different wrong rays when two workgroups of the one-launch (fused) form shared a CU.  The cause
+(tools/exp/race_probe.py): packed-fp32 vector instructions of the cost-volume walk lose their result in lanes 48-63 of a
+wave while another wave of the same SIMD issues 16-bit 32x32x16 matrix instructions.  The fused form is now built
+without packed-fp32 instructions in the walk and runs two workgroups per CU again; these tests hammer exactly that
+configuration and compare bit for bit."""
+import pytest
+import torch
+
+from helpers import linf
+from gpu_helpers import make_decoder_struct, make_rays_struct, make_scene_struct
+from test_hip_kernels import _case_on_gpu  # noqa: F401  (golden case -> device tensors)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from matchnerf_amd import hip as H
+    H.load()
+    return H
+
+
+@pytest.mark.parametrize("name", ["c1_default", "v4"])
+def test_fused_two_workgroups_per_cu_60_frames_equal_staged_and_goldens(hip, name):
+    """60 frames of a golden case through the one-launch form (two workgroups per CU: the kernel asks for its natural
+    68 KiB of LDS): every frame is bit-identical to the staged form and within the golden tolerances."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math="f16x3")
+    h, w = batch["images"].shape[-2:]
+    n = h * w
+    rays = make_rays_struct(cfg, batch, n)
+    assert hip.render_is_fused(sc, dec, rays)
+    cond = hip.cost_volume(sc, rays, dec.cond_stride)
+    staged = hip.decoder_chunk(dec, sc.views[0], rays, cond)
+    assert linf(staged[0], g["rgb"][0]) < 1e-4
+    assert linf(staged[2], g["opacity"][0, :, 0]) < 1e-4 and linf(staged[1], g["depth"][0, :, 0]) < 3e-4
+    bad = 0
+    for frame in range(60):
+        out = [torch.full((n, 3), -1.0, device="cuda"), torch.full((n,), -1.0, device="cuda"), torch.full((n,), -1.0, device="cuda")]
+        hip.render_chunk(sc, dec, rays, None, *out, fused=True)
+        bad += int(((out[0] != staged[0]).any(1) | (out[1] != staged[1]) | (out[2] != staged[2])).sum())
+    assert bad == 0, f"{bad} rays of the fused form differ from the staged form over 60 frames"
+
+
+def test_fused_bench_frame_is_bit_identical_to_staged_over_50_launches():
+    """BASELINE config[1] (512x640, 3 views, S=64): 10 frames x 5 launches of 65,536 rays through the one-launch form with
+    two workgroups per CU against the staged form of the same launch, bit for bit (the configuration in which round 2
+    saw up to 14 wrong rays per frame)."""
+    import bench
+    from matchnerf_amd import camera, hip
+    dev = torch.device("cuda:0")
+    opt, model, _ = bench.build_model(dev)
+    _, batch = bench.make_batch(dev, 0)
+    with torch.no_grad():
+        feats = model.get_img_feat(batch.images[:, :3], cur_n_src_views=3)
+    tgt_pose, ref_poses = model.extract_poses(batch)
+    ref_host, images_cl = model._frame_ctx(ref_poses, batch.images[:, :3])
+    tgt_ex, tgt_in, tgt_nf = model._tgt_host(tgt_pose)
+    sc = model._scene(0, ref_host, feats, images_cl)
+    dec = model._decoder(bench.S, dev)
+    kinv, c2w = camera.target_ray_consts(tgt_ex[0], tgt_in[0], True)
+    n_rays, chunk = bench.H * bench.W, 65536
+
+    def rays_of(c):
+        m = min(chunk, n_rays - c)
+        return hip.make_rays(m, bench.S, bench.H, bench.W, kinv, c2w, tgt_nf[0, 0], tgt_nf[0, 1], ray_begin=c, legacy=True), m
+
+    refs = {}
+    for c in range(0, n_rays, chunk):
+        rays, m = rays_of(c)
+        refs[c] = hip.decoder_chunk(dec, sc.views[0], rays, hip.cost_volume(sc, rays, dec.cond_stride))
+    wrong = 0
+    for frame in range(10):
+        for c in range(0, n_rays, chunk):
+            rays, m = rays_of(c)
+            out = [torch.full((m, 3), -1.0, device=dev), torch.full((m,), -1.0, device=dev), torch.full((m,), -1.0, device=dev)]
+            hip.render_chunk(sc, dec, rays, None, *out, fused=True)
+            ref = refs[c]
+            wrong += int(((out[0] != ref[0]).any(1) | (out[1] != ref[1]) | (out[2] != ref[2])).sum())
+    assert wrong == 0, f"{wrong} wrong rays in 50 fused launches"
+
+
+def test_staged_decoder_two_workgroups_per_cu_is_reproducible_over_40_launches(hip):
+    """The staged decoder always ran two workgroups per CU (same weight pipeline): 40 launches of one golden frame give
+    the same bits every time and stay within the golden tolerances."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math="f16x3")
+    h, w = batch["images"].shape[-2:]
+    rays = make_rays_struct(cfg, batch, h * w)
+    cond = hip.cost_volume(sc, rays, dec.cond_stride)
+    first = hip.decoder_chunk(dec, sc.views[0], rays, cond)
+    assert linf(first[0], g["rgb"][0]) < 1e-4
+    for _ in range(40):
+        again = hip.decoder_chunk(dec, sc.views[0], rays, hip.cost_volume(sc, rays, dec.cond_stride))
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)

@@ -1,6 +1,2 @@
 #!/bin/bash
-set -e
-cd "$(dirname "$0")/../../matchnerf_amd/csrc"
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-use-amdgpu-trackers=1 -DMNERF_TIMELINE"
-hipcc $F -shared -o ../libmnerf_hip_tl.so -x hip api.cpp backward.hip composite.hip conv.hip cost_volume.hip decoder.hip encoder_block.hip geometry.hip instance_norm.hip qkv.hip render_chunk.hip window_attention.hip
-echo built ../libmnerf_hip_tl.so
+exec "$(dirname "$0")/build_variant.sh" tl "-DMNERF_TIMELINE" decoder.hip
