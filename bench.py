@@ -189,6 +189,11 @@ def respawn_under_launcher(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.shard != "views":
+        cmd += ["--shard", args.shard]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver only supports dmabuf IPC; without it RCCL's buffer exchange
+    # between the rank processes fails with `hipIpcGetMemHandle: invalid argument` (environment note of the GPU boxes;
+    # already exported there — set here only when the caller's environment lacks it)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -200,6 +205,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config[2] / config[4] timings")
+    ap.add_argument("--shard", choices=["views", "rows"], default="views",
+                    help="N > 1: 'views' = every rank renders its own target view (weak scaling, the default); 'rows' = ONE "
+                         "frame per step, row bands sharded over the ranks (strong scaling, dist.render_frame_sharded)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -211,7 +219,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path is HIP-only (no CPU fallback)")
     if "MNERF_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < int(os.environ.get("WORLD_SIZE", "1")):
-        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible to this process "
+                         f"(one rank per GPU; set MNERF_FORCE_DEVICE=0 MNERF_DIST_BACKEND=gloo for a dry run on one GPU)")
     rank, world, device = mdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -222,12 +231,26 @@ def main():
     scene, batch = make_batch(device, target_shift=rank)
     n_rays = H * W
 
+    rows_mode = args.shard == "rows" and world > 1
+    spans = []  # per step: (start, after the render, after the gather) events of this rank
+
     def step(timer=None):
         model.kernel_timer = timer
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         with torch.no_grad():
-            out = model(batch, mode="test")
-        tile = torch.cat([out.rgb[0], out.depth[0], out.opacity[0]], -1)  # [HW,5]
-        full = mdist.gather_tiles(tile)                                    # RCCL all_gather (N>1)
+            if rows_mode:  # strong scaling: one frame, this rank renders its band of rows; the gather is inside
+                out = mdist.render_frame_sharded(model, batch)
+                ev[1].record()
+                full = torch.cat([out.rgb[0], out.depth[0], out.opacity[0]], -1)
+            else:
+                out = model(batch, mode="test")
+                tile = torch.cat([out.rgb[0], out.depth[0], out.opacity[0]], -1)  # [HW,5]
+                ev[1].record()
+                full = mdist.gather_tiles(tile)                                    # RCCL all_gather (N>1)
+        ev[2].record()
+        if timer is not None:
+            spans.append(ev)
         return full
 
     for _ in range(args.warmup):
@@ -241,7 +264,12 @@ def main():
     torch.cuda.synchronize()
     mdist.barrier()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device)
-    assert full.shape == (world * n_rays, 5) and bool(torch.isfinite(full).all())
+    assert full.shape == ((1 if rows_mode else world) * n_rays, 5) and bool(torch.isfinite(full).all())
+    # per-rank milliseconds per step (frame incl. encoder | of it the gather), collected on every rank
+    mine = torch.tensor([sum(a.elapsed_time(c) for a, _, c in spans) / max(len(spans), 1),
+                         sum(b.elapsed_time(c) for _, b, c in spans) / max(len(spans), 1)], device=device)
+    per_rank = mdist.gather_tiles(mine[None]) if world > 1 else mine[None]
+    per_rank = [[round(float(x), 3) for x in row] for row in per_rank.cpu()]
 
     ksum = timer.summary()
     model.kernel_timer = None
@@ -323,7 +351,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * n_rays * args.steps / elapsed
+        value = (1 if rows_mode else world) * n_rays * args.steps / elapsed
         fused = "render_fused" in ksum
         dec = ksum["render_fused"] if fused else ksum["decoder"]
         cv_ms = None if fused else ksum["cost_volume"]["total_ms"] / args.steps
@@ -343,7 +371,8 @@ def main():
         line = {
             "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
             "config": {
                 "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
                             "(327680 rays) per step incl. GMFlow encoder; fp32 parity mode",
@@ -354,7 +383,10 @@ def main():
                                  "f32": "f32: exact-f32 MFMA"}[math],
                 "other_decoder_math": other_math or None,
                 "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(launch_rays),
-                "parallelism": f"target views x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"row bands of one frame x{world} (strong scaling)" if rows_mode else
+                                f"target views x{world}") if world > 1 else "single GPU",
+                "per_rank_ms_per_step": {"what": "[step incl. encoder and gather, of it the gather] per rank, device events",
+                                         "ranks": per_rank},
                 "encoder_ms": round(enc_ms, 3), "render_kernels_ms_per_frame": round(render_ms, 3),
                 "render_only_rays_per_s_per_gpu": round(render_rate, 1),
                 "ray_chunk_form": ("fused: cost volume + decoder + compositing in ONE launch per 65536 rays, conditioning rows "

@@ -27,7 +27,7 @@ def init_from_env(backend=None):
     if use_cuda:
         torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}" if use_cuda else "cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("MNERF_DIST_INIT_ALWAYS")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
@@ -48,12 +48,14 @@ def shard_rows(height, width, rank, world):
     return r0 * width, nr * width
 
 
-def gather_tiles(local, counts=None):
+def gather_tiles(local, counts=None, always=False):
     """All ranks receive the concatenation of every rank's ``local`` [n_r, C] tile, in rank
     order.  ``counts`` = per-rank row counts; when omitted they are exchanged first (one int per rank), so
     ragged tiles (height % world != 0) never reach the collective with mismatched sizes.  Tiles are padded to
-    the largest and trimmed after the collective, so a single all_gather_into_tensor suffices."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    the largest and trimmed after the collective, so a single all_gather_into_tensor suffices.
+    ``always``: run the collectives also in a one-rank group (tests: the RCCL calls on device tensors execute on a
+    single GPU exactly as they do on eight)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     on_host = dist.get_backend() == "gloo"
@@ -110,13 +112,13 @@ def render_frame_sharded(model, batch, mode="test"):
     return edict(rgb=full[..., :3].contiguous(), depth=full[..., 3:4].contiguous(), opacity=full[..., 4:5].contiguous())
 
 
-def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(always=False):
+    if dist.is_initialized() and (dist.get_world_size() > 1 or always):
         dist.barrier()
 
 
-def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(value, device, always=False):
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
         return float(value)
     t = torch.tensor([float(value)], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

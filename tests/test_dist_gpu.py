@@ -98,3 +98,35 @@ def test_bench_self_spawns_two_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0 and j["steps"] == 1
     assert j["config"]["rays_per_step_per_gpu"] == 512 * 640 and "roofline" in j
+
+
+def _nccl_one_rank_worker(port, q):
+    try:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          MNERF_DIST_INIT_ALWAYS="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.environ.pop("MNERF_DIST_BACKEND", None)
+        from matchnerf_amd import dist as mdist
+        rank, world, dev = mdist.init_from_env()
+        assert torch.distributed.get_backend() == "nccl" and dev.type == "cuda"
+        tile = torch.arange(11 * 5, dtype=torch.float32, device=dev).reshape(11, 5)
+        full = mdist.gather_tiles(tile, always=True)                    # count exchange + all_gather_into_tensor on device tensors
+        full2 = mdist.gather_tiles(tile, counts=[11], always=True)
+        mdist.barrier(always=True)
+        mx = mdist.max_over_ranks(3.25, dev, always=True)
+        ok = torch.equal(full, tile) and torch.equal(full2, tile) and full.is_cuda and mx == 3.25
+        torch.distributed.destroy_process_group()
+        q.put((bool(ok), ""))
+    except Exception as e:  # noqa: BLE001
+        q.put((False, repr(e)))
+
+
+def test_rccl_collectives_execute_on_one_gpu():
+    """The nccl (= RCCL) branch of dist.py — device-tensor all_gather_into_tensor, all_reduce, barrier — has never run on
+    the one-GPU boxes (every multi-rank test goes through gloo).  A ONE-rank RCCL group runs the very same calls."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    ok, err = q.get(timeout=240)
+    p.join(60)
+    assert ok, err

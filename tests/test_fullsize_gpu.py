@@ -148,6 +148,28 @@ def test_fullsize_opacity_closed_form_and_cost_volume_range(full_frame):
     assert float((c[..., 22] - 1).abs().max()) == 0
 
 
+def test_fullsize_slab_matches_oracle(full_frame):
+    """BASELINE config[1] itself: 256 rays of the 512x640 headline frame rendered by the CPU
+    oracle from the very feature maps the GPU encoder produced, against the frame the HIP path rendered: rgb / opacity
+    1e-4 (north_star's gate), depth 3e-4."""
+    opt, model, batch, scene, rgb, depth, opacity = full_frame
+    sd = syn.to_torch(syn.seeded_state_dict(syn.state_dict_spec(n_src_views=3), 1))  # the weights build() loads
+    first = 256 * 640 + 213
+    idx = torch.arange(first, first + 256)
+    with torch.no_grad():
+        feats = model.get_img_feat(batch.images[:, :3], cur_n_src_views=3)
+    pair_feats = [(f[0, :, 0].permute(0, 3, 1, 2).cpu(), f[0, :, 1].permute(0, 3, 1, 2).cpu()) for f in feats]
+    b = {k: torch.from_numpy(val) for k, val in scene.items()}
+    cfg = O.OracleConfig(n_src_views=3, sample_intvs=64)
+    te, ti, tn = b["extrinsics"][0, -1, :3], b["intrinsics"][0, -1], b["near_fars"][0, -1]
+    se, si, sn = b["extrinsics"][0, :-1, :3], b["intrinsics"][0, :-1], b["near_fars"][0, :-1]
+    with torch.no_grad():
+        ref = O.render_rays(cfg, sd, idx, te, ti, tn, se, si, sn, b["images"][0, :3], pair_feats, False)
+    assert linf(rgb[0, idx], ref[0]) < 1e-4
+    assert linf(opacity[0, idx], ref[2]) < 1e-4
+    assert linf(depth[0, idx], ref[1]) < 3e-4
+
+
 # ----------------------------------------------------------------------------- config[2] / config[4] at full size
 
 FULL_CASES = {
