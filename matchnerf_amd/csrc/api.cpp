@@ -49,6 +49,8 @@ static mnerf_tuning read_tuning() {
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
   t.wa_xcd = env_int("MNERF_WA_XCD", 1);          // query blocks of a window share an XCD (its L2 holds the K / V images)
   t.render_fused = env_int("MNERF_RENDER_FUSED", 0);  // 1: mnerf_render_chunk takes the one-launch form where it applies
+  t.decoder_pp = env_int("MNERF_DECODER_PP", 1);
+  t.decoder_pp_grid = env_int("MNERF_DECODER_PP_GRID", 256);
   return t;
 }
 

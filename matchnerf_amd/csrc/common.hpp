@@ -39,6 +39,8 @@ struct mnerf_tuning {
   int wa_min4;
   int wa_xcd;  // pre-split window attention: all query blocks of a window on one XCD (1) or launch order (0)
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies
+  int decoder_pp;       // MNERF_DECODER_PP (default 1): the ping-pong form of the split-fp16 decoder where it applies
+  int decoder_pp_grid;  // MNERF_DECODER_PP_GRID (default 256): its persistent grid, one 8-wave workgroup per CU
 };
 const mnerf_tuning& mnerf_tune();
 // true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device

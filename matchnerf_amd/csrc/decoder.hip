@@ -1603,6 +1603,714 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
   }
 }
 
+#if MNERF_DECODER_PART == 0
+// =====================================================================================================================
+// Ping-pong form of the split-fp16 decoder (round 3): ONE 8-wave workgroup per CU, two TEAMS of four waves, each team
+// owns 128 samples (whole rays) of a 256-sample tile.  Every SIMD holds one wave of each team, and the two teams run the
+// same straight-line phase sequence ONE PHASE APART (team B enters the tile loop one barrier late):
+//     phase 2s   = V_s: everything the vector ALU has to do before stage s (FiLM multiply + ReLU of the previous layer,
+//                  per-sample gain, operand split into fp16 hi | lo fragments that stay in registers)
+//     phase 2s+1 = M_s: stage s's matrix instructions, fed from those registers and from the weight fragments in LDS
+// so while one wave of a SIMD issues back-to-back MFMAs its partner does VALU work, by construction instead of by the
+// luck of two unsynchronised workgroups (the staged kernel above: matrix pipe 43 % busy, VALU 46 %).  One workgroup
+// barrier per phase.  A weight segment is streamed ONCE per 256 samples (staged kernel: once per 128): stage s lives in
+// ring slots 2 (s & 1) (+1), team A reads it in global step 2s+1, team B in step 2s+2; it is requested in two halves from VALU
+// phases (team B the even 1-KiB pieces at the end of its V_{s-1}, step 2s-1: the slot pair's previous tenant, stage s-2, was
+// last read in step 2s-2; team A the odd pieces at the start of its V_s, step 2s), each team waits for its own pieces in
+// step 2s.  (Requests between the matrix instructions were measured: the LDS-DMA path drains ~11 B/clk per CU, a stage's
+// 65 KiB takes 5.7 k cycles, and a wave that issues faster than that stalls inside its MFMA phase.)  Resident for the whole kernel: the tail segment (ray-transformer weights)
+// and the 1-KiB headers (biases, weight scales) of all stages, so that a V phase can also load the next accumulators.
+// The conditioning rows of the next tile are copied to LDS during the tail phases (half of ring slot 1 per team).
+// Same arithmetic in the same order as decoder_kernel<.., 2, 0>: results are bit-identical (tests).
+// Scope: the shipped decoder shape (L_3D = 10, <= 32 conditioning inputs, S <= 128); anything else takes the kernel above.
+#define PP_STAGES 12
+#define PP_PHASES 28
+struct PPSched {
+  int seg_first[PP_STAGES];  // first weight segment of the stage (index into DecSched)
+  int n_seg[PP_STAGES];      // 1 or 2
+};
+
+template <int SP>
+struct SmemPP {
+  static constexpr int TEAM = 128, TILE = 256;
+  static constexpr int RING_FLOATS = 4 * SEG_CAP_FLOATS;
+  static constexpr int TAIL_F = ((TAIL_FLOATS + 255) / 256) * 256;
+  static constexpr int HDR_FLOATS = PP_STAGES * 256;     // the 1-KiB headers (biases, weight scale) of all stages, resident
+  static constexpr int RS_FLOATS = TILE * 4;
+  static constexpr int TOTAL_FLOATS = RING_FLOATS + TAIL_F + HDR_FLOATS + RS_FLOATS + 64;
+  static_assert(TEAM * 64 <= SEG_CAP_FLOATS, "a team's attention scratch must fit one ring slot");
+  static_assert(TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
+};
+// one-KiB pieces of the two weight segments of every stage (the shipped decoder shape; checked against the schedule on the host)
+__device__ __host__ constexpr int pp_p0(int s) {
+  constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 33, 32, 17, 33, 17, 9};
+  return t[s];
+}
+__device__ __host__ constexpr int pp_p1(int s) {
+  constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 0, 32, 0, 32, 20, 0};
+  return t[s];
+}
+
+template <int SP>
+__global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
+    mnerf_decoder D, DecSched sch, PPSched pps, mnerf_view view0, mnerf_rays R, const float* __restrict__ cond,
+    float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_opacity,
+    float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma, const float* __restrict__ ext_ndc,
+    const float* __restrict__ ext_dir) {
+  constexpr int Sp = SP;
+  using SM = SmemPP<SP>;
+  constexpr int TEAM = SM::TEAM;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const unsigned ring_lds = __builtin_amdgcn_groupstaticsize();
+  const unsigned tail_lds = ring_lds + SM::RING_FLOATS * 4u;
+  const unsigned hdr_lds = tail_lds + SM::TAIL_F * 4u;
+  float* tail = smem + SM::RING_FLOATS;                 // resident [w_qs;w_ks;w_vs | fc | out_alpha.0 | out_alpha.2]
+  float* rs_all = tail + SM::TAIL_F + SM::HDR_FLOATS;   // [TILE][4] rgb.xyz, sigma.w
+  float* ln_lds = rs_all + SM::RS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, tw = wave & 3;
+  const int n = lane & 31, hl = lane >> 5;
+  const int S = R.n_samples;
+  const int rays_per_team = TEAM / Sp, rays_per_tile = 2 * rays_per_team;
+  const int n_tiles = (R.n_rays + rays_per_tile - 1) / rays_per_tile;
+  const int CS = D.cond_stride;
+  const float freq_mul = R.legacy_coord ? 1.0f : 3.14159265358979323846f;
+  const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
+  const unsigned voff = (unsigned)lane * 16u;
+  float* rs_lds = rs_all + team * TEAM * 4;
+  // a team's ray-attention scratch: ring slot 3 (team A) / 2 (team B), free while that team is in its tail phases
+  float* att = smem + (team == 0 ? 3 : 2) * SEG_CAP_FLOATS;
+  float* k_lds = att;
+  float* vt_lds = att + TEAM * 16;
+  float* q_lds = att + TEAM * 32;
+  float* o_lds = att + TEAM * 48;
+  // the team's conditioning rows of the NEXT tile: half of ring slot 1 (free between the views stage and layer 1 of the next tile)
+  float* rows_lds = smem + 1 * SEG_CAP_FLOATS + team * 4096;
+  const unsigned rows_lds_addr = ring_lds + (unsigned)(1 * SEG_CAP_FLOATS + team * 4096) * 4u;
+
+#define PP_SLOT_LDS(s_, i_) (ring_lds + (unsigned)(2 * ((s_)&1) + (i_)) * (SEG_CAP_FLOATS * 4u))
+#define PP_HDR_LDS(s_) (hdr_lds + (unsigned)(s_) * 1024u)
+#define PP_SEG_SRC(s_, i_) (D.wstream + sch.seg_off[pps.seg_first[s_] + (i_)])
+
+  // ---- prologue: LayerNorm parameters, the resident tail segment, the stage headers, stage 0 of the first tile
+  if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
+  {
+    const int seg = sch.n_seg - 1;
+    const int pieces = sch.seg_floats[seg] >> 8;
+    for (int p = wave; p < pieces; p += 8)
+      glds16_s(D.wstream + sch.seg_off[seg] + p * 256, voff, __builtin_amdgcn_readfirstlane(tail_lds + (unsigned)p * 1024u));
+    for (int s = wave; s < PP_STAGES; s += 8) glds16_s(PP_SEG_SRC(s, 0), voff, __builtin_amdgcn_readfirstlane(PP_HDR_LDS(s)));
+    for (int p = wave; p < pp_p0(0); p += 8)
+      glds16_s(PP_SEG_SRC(0, 0) + p * 256, voff, __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(0, 0) + (unsigned)p * 1024u));
+  }
+  segment_wait();
+  __syncthreads();
+  if (team == 1) __syncthreads();  // team B runs one phase behind team A from here on
+
+  int tile_begin = blockIdx.x, tile_end = n_tiles, tile_step = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int xcd = blockIdx.x & 7;
+    tile_begin = (int)((long long)n_tiles * xcd / 8) + (int)(blockIdx.x >> 3);
+    tile_end = (int)((long long)n_tiles * (xcd + 1) / 8);
+    tile_step = ((int)gridDim.x - xcd + 7) >> 3;
+  }
+#ifdef MNERF_TIMELINE
+  // debug build (tools/exp/pp_timeline.py): per wave and phase, s_memtime at the end of the work and after the barrier
+  int pp_tl_tile = -1, pp_ph = 0;
+#define PP_SYNC()                                                                                              \
+  do {                                                                                                         \
+    unsigned long long* o_ = (sch.tl && lane == 0 && blockIdx.x < 32 && pp_tl_tile >= 0 && pp_tl_tile < 4)     \
+                                 ? sch.tl + ((((size_t)blockIdx.x * 4 + pp_tl_tile) * 8 + wave) * PP_PHASES + pp_ph) * 2 \
+                                 : nullptr;                                                                    \
+    if (o_) o_[0] = __builtin_amdgcn_s_memtime();                                                              \
+    __syncthreads();                                                                                           \
+    if (o_) o_[1] = __builtin_amdgcn_s_memtime();                                                              \
+    ++pp_ph;                                                                                                   \
+  } while (0)
+#else
+#define PP_SYNC() __syncthreads()
+#endif
+  // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
+  auto stage_dma = [&](int s, int half) {
+    for (int i = 0; i < pps.n_seg[s]; ++i) {
+      const float* src = PP_SEG_SRC(s, i);
+      const int pieces = sch.seg_floats[pps.seg_first[s] + i] >> 8;
+      const unsigned base = PP_SLOT_LDS(s, i);
+      const int first = half == 2 ? tw : 2 * tw + half, step = half == 2 ? 4 : 8;
+      for (int p = first; p < pieces; p += step) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+    }
+  };
+#define PP_BEGIN_V(stage_)                    \
+  do {                                        \
+    if (team == 0) stage_dma(stage_, 1);      \
+  } while (0)
+#define PP_END_V(next_stage_)                                       \
+  do {                                                              \
+    if (team == 1) { if ((next_stage_) >= 0) stage_dma(next_stage_, 0); } \
+    else segment_wait();                                            \
+    PP_SYNC();                                                      \
+  } while (0)
+#define PP_END_M()                   \
+  do {                               \
+    if (team == 1) segment_wait();   \
+    PP_SYNC();                       \
+  } while (0)
+  // M_s: stage s's matrix instructions (+ team A: the requests for stage NXT_)
+#ifndef MNERF_PP_PAIRS
+#define MNERF_PP_PAIRS 0  // 1: the two blocks of a pair interleaved, no back-to-back dependent MFMAs (measured: no faster, more spills)
+#endif
+#if MNERF_PP_PAIRS
+#define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
+  ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+#else
+#define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
+  ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+#endif
+#define PP_MFMA1(NS0_, acc_, s_, hdr_bytes_, hs_) \
+  ksteps_presplit2<1, NS0_, 0>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+
+#ifdef MNERF_PP_BIDLE
+  // timing experiment: team B only keeps the barriers company (its outputs are garbage): how long are team A's phases alone?
+  if (team == 1) {
+    for (int tile = tile_begin; tile < tile_end; tile += tile_step)
+      for (int ph = 0; ph < PP_PHASES; ++ph) __syncthreads();
+    return;
+  }
+#endif
+  bool rows_in_lds = false;  // this tile's conditioning rows were copied to LDS during the previous tile's tail
+  for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+#ifdef MNERF_TIMELINE
+    ++pp_tl_tile;
+    pp_ph = 0;
+#endif
+    const bool has_next = tile + tile_step < tile_end;
+    // ------------------------------------------------------------ per-lane sample identity
+    const int s_local = tw * 32 + n;                  // sample within the team
+    const int ray_t = s_local / Sp;                   // ray within the team
+    const int jp = s_local - ray_t * Sp;
+    const int ray_raw = tile * rays_per_tile + team * rays_per_team + ray_t;
+    const bool ray_ok = ray_raw < R.n_rays;
+    const int ray = ray_ok ? ray_raw : (R.n_rays - 1);
+    const int j = jp < S ? jp : (S - 1);
+    const size_t gs = (size_t)ray * S + j;
+
+    // ============================================================ phase 0 = V_0: inputs, geometry, FiLM operands
+    float4 cpre[4];
+    float n_valid;
+    if (rows_in_lds) {
+      const float* crow = rows_lds + s_local * CS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
+        cpre[i] = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float* mrow = crow + (D.cond_dim - D.n_views);
+      float nv = 0.0f;
+      for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
+      n_valid = nv;
+    } else {
+      const float* crow = cond + gs * CS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
+        cpre[i] = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float* mrow = crow + (D.cond_dim - D.n_views);
+      float nv = 0.0f;
+      for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
+      n_valid = nv;
+    }
+    float x, y, z, dx, dy, dz;
+    if (ext_ndc) {
+      x = ext_ndc[gs * 3 + 0];
+      y = ext_ndc[gs * 3 + 1];
+      z = ext_ndc[gs * 3 + 2];
+      dx = ext_dir[gs * 3 + 0];
+      dy = ext_dir[gs * 3 + 1];
+      dz = ext_dir[gs * 3 + 2];
+    } else {
+      const RayGeom g = make_ray(R, ray);
+      const float dpt = sample_depth(R, ray, j);
+      float wx_, wy_, wz_;
+      ray_point(g, dpt, wx_, wy_, wz_);
+      project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
+      const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
+      const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
+      dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
+      dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
+      dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
+    }
+    const EncBase encb = enc_base(x, y, z, freq_mul);
+    const float enc_max = fmaxf(fmaxf(1.0f, fabsf(x)), fmaxf(fabsf(y), fabsf(z)));
+    const bool q_valid = n_valid > 1.0f;
+
+    PartsH hs[8];  // operands of the coming matrix stage: 8 K16-steps of fp16 hi | lo fragments (64 registers)
+    f32x16 film[4];
+    int ecf;
+    {
+      const float v0[8] = {cpre[0].x, cpre[0].y, cpre[0].z, cpre[0].w, cpre[1].x, cpre[1].y, cpre[1].z, cpre[1].w};
+      const float v1[8] = {cpre[2].x, cpre[2].y, cpre[2].z, cpre[2].w, cpre[3].x, cpre[3].y, cpre[3].z, cpre[3].w};
+      hs[0] = split8h(v0, (float)(1 << (H16_TARGET_EXP - 1)));
+      hs[1] = split8h(v1, (float)(1 << (H16_TARGET_EXP - 1)));
+      const int ew = header_ew(PP_HDR_LDS(0));
+      ecf = -(ew + (H16_TARGET_EXP - 1));
+      bias_init_h<4>(film, PP_HDR_LDS(0), hl, pow2i(ew + (H16_TARGET_EXP - 1)));
+    }
+    PP_END_V(1);
+    // ============================================================ phase 1 = M_0: FiLM = pts_bias(cond)
+    PP_MFMA(4, 2, 0, film, 0, 1024u, hs);
+    PP_END_M();
+    // ============================================================ phase 2 = V_1: positional encoding operands (layer 0)
+    PP_BEGIN_V(1);
+    f32x16 acc[4];
+    int ew_cur = 0, ec, em;
+    auto split_enc = [&](float mult) {  // 32 encoding operands -> hs[0..3]
+      {
+        const f32x16 e0 = enc_block16_L10<0>(encb, hl, x, y, z);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = e0[r];
+        hs[0] = split8h(v, mult);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = e0[8 + r];
+        hs[1] = split8h(v, mult);
+      }
+      {
+        const f32x16 e1 = enc_block16_L10<16>(encb, hl, x, y, z);
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = e1[r];
+        hs[2] = split8h(v, mult);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = e1[8 + r];
+        hs[3] = split8h(v, mult);
+      }
+    };
+    auto split_blocks = [&](const f32x16 (&b)[4], float mult) {  // 128 operands held in four 16-register blocks -> hs[0..7]
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = b[m][r];
+        hs[2 * m] = split8h(v, mult);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = b[m][8 + r];
+        hs[2 * m + 1] = split8h(v, mult);
+      }
+    };
+    // dst <- max(acc * film, 0) (dst may be acc itself: the accumulators are dead once the activations exist, and a
+    // separate copy would cost 64 registers); returns the sample's largest new activation
+    auto film_relu = [&](f32x16 (&dst)[4]) -> float {
+      float mx = 0.0f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float t = fmaxf(acc[m][r] * film[m][r], 0.0f);
+          dst[m][r] = t;
+          mx = fmaxf(mx, t);
+        }
+      return fmaxf(mx, __shfl_xor(mx, 32, 64));
+    };
+    em = gain_exp(enc_max);
+    split_enc(pow2i(em));
+    ew_cur = header_ew(PP_HDR_LDS(1));
+    bias_init_h<4>(acc, PP_HDR_LDS(1), hl, pow2i(ew_cur + em));
+    ec = -em - ew_cur + ecf;
+    PP_END_V(2);
+    // ============================================================ phase 3 = M_1: layer 0
+    PP_MFMA(4, 4, 0, acc, 1, 1024u, hs);
+    PP_END_M();
+    // ============================================================ layers 1..4: V_s (FiLM, ReLU, gain, split, next biases), M_s
+    float hmax;
+#define PP_HIDDEN_LAYER(ST_)                                                \
+  do {                                                                      \
+    PP_BEGIN_V(ST_);                                                        \
+    hmax = film_relu(acc);                                                  \
+    em = gain_exp(hmax);                                                    \
+    split_blocks(acc, pow2i(em));                                           \
+    ew_cur = header_ew(PP_HDR_LDS(ST_));                                    \
+    bias_init_h<4>(acc, PP_HDR_LDS(ST_), hl, pow2i(ew_cur + (em - ec)));    \
+    ec = ec - em - ew_cur + ecf;                                            \
+    PP_END_V((ST_) + 1);                                                    \
+    PP_MFMA(4, 4, 4, acc, ST_, 1024u, hs);            \
+    PP_END_M();                                                             \
+  } while (0)
+    PP_HIDDEN_LAYER(2);
+    PP_HIDDEN_LAYER(3);
+    PP_HIDDEN_LAYER(4);
+    PP_HIDDEN_LAYER(5);
+#undef PP_HIDDEN_LAYER
+    // ============================================================ layer 5 = [enc, h] -> 128 (stages 6: enc part, 7: h part)
+    // V_6: FiLM + ReLU of layer 4 into h (its operands are split in V_7), encoding operands with the common gain
+    int eg;
+    f32x16 h5[4];  // layer 4's activations wait here while the accumulators take the encoding part of layer 5
+    PP_BEGIN_V(6);
+    {
+      hmax = film_relu(h5);
+      eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
+      split_enc(pow2i(eg));
+      ew_cur = header_ew(PP_HDR_LDS(6));
+      bias_init_h<4>(acc, PP_HDR_LDS(6), hl, pow2i(ew_cur + eg));
+    }
+    PP_END_V(7);
+    PP_MFMA(4, 4, 0, acc, 6, 1024u, hs);  // M_6
+    PP_END_M();
+    PP_BEGIN_V(7);
+    split_blocks(h5, pow2i(eg + ec));  // V_7
+    ec = -eg - ew_cur + ecf;
+    PP_END_V(8);
+    PP_MFMA(4, 4, 4, acc, 7, 0u, hs);  // M_7
+    PP_END_M();
+    // ============================================================ alpha head (stage 8) and feature_linear (stage 9): same operands
+    PP_BEGIN_V(8);
+    hmax = film_relu(acc);  // V_8
+    const int em5 = gain_exp(hmax);
+    split_blocks(acc, pow2i(em5));
+    f32x16 al[1];
+    const int ew_a = header_ew(PP_HDR_LDS(8));
+    bias_init_h<1>(al, PP_HDR_LDS(8), hl, pow2i(ew_a + em5 - ec));
+    PP_END_V(9);
+    PP_MFMA1(8, al, 8, 1024u, hs);  // M_8: alpha head 128 -> 16
+    PP_END_M();
+    float av[8];
+    PP_BEGIN_V(9);
+    {  // V_9: the alpha activations (they wait in 8 registers for the ray transformer); biases of feature_linear
+      const float ca = pow2i(ec - em5 - ew_a);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float t = al[0][r] * ca;
+        t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+        av[r] = t;
+      }
+      if (D.raytrans_posenc) {
+        const float* tab = D.small_ + SMALL_FIXED + (size_t)j * 16;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) av[r] += tab[(r & 3) + 8 * (r >> 2) + 4 * hl];
+      }
+      ew_cur = header_ew(PP_HDR_LDS(9));
+      bias_init_h<4>(acc, PP_HDR_LDS(9), hl, pow2i(ew_cur + (em5 - ec)));
+    }
+    const int ecfeat = ec - em5 - ew_cur;
+    PP_END_V(10);
+    PP_MFMA(4, 4, 4, acc, 9, 1024u, hs);  // M_9: feature_linear 128 -> 128, no activation
+    PP_END_M();
+    // ============================================================ views_linear (stage 10): [feat, dir] -> 64
+    int egv, ecv;
+    PartsH hsd;
+    f32x16 hv[2];
+    PP_BEGIN_V(10);
+    {  // V_10
+      egv = gain_exp(fmaxf(1.0f, sample_absmax<4>(acc) * pow2i(ecfeat)));
+      split_blocks(acc, pow2i(egv + ecfeat));
+      const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      hsd = split8h(v, pow2i(egv));
+      const int ew = header_ew(PP_HDR_LDS(10));
+      bias_init_h<2>(hv, PP_HDR_LDS(10), hl, pow2i(ew + egv));
+      ecv = -egv - ew;
+    }
+    PP_END_V(11);
+    PP_MFMA(2, 4, 4, hv, 10, 1024u, hs);  // M_10
+    ksteps_presplit<2, 1>(hv, PP_SLOT_LDS(10, 1) + 8 * H16_UNIT_BYTES, lane, &hsd);
+    PP_END_M();
+    // ============================================================ rgb_linear (stage 11): 64 -> 3, sigmoid
+    f32x16 c3[1];
+    float cc;
+    PP_BEGIN_V(11);
+    {  // V_11
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[m][r] = fmaxf(hv[m][r], 0.0f);
+      const int emr = gain_exp(sample_absmax<2>(hv));
+      const float mult = pow2i(emr);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = hv[m][r];
+        hs[2 * m] = split8h(v, mult);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = hv[m][8 + r];
+        hs[2 * m + 1] = split8h(v, mult);
+      }
+      const int ew = header_ew(PP_HDR_LDS(11));
+      bias_init_h<1>(c3, PP_HDR_LDS(11), hl, pow2i(ew + emr - ecv));
+      cc = pow2i(ecv - emr - ew);
+    }
+    PP_END_V(-1);
+    {  // M_11
+      PP_MFMA1(4, c3, 11, 1024u, hs);
+      if (hl == 0) {
+        const float cr = 1.0f / (1.0f + expf(-c3[0][0] * cc));
+        const float cg = 1.0f / (1.0f + expf(-c3[0][1] * cc));
+        const float cb = 1.0f / (1.0f + expf(-c3[0][2] * cc));
+        rs_lds[s_local * 4 + 0] = cr;
+        rs_lds[s_local * 4 + 1] = cg;
+        rs_lds[s_local * 4 + 2] = cb;
+        if (dbg_rgb_s && ray_ok && jp < S) {
+          dbg_rgb_s[gs * 3 + 0] = cr;
+          dbg_rgb_s[gs * 3 + 1] = cg;
+          dbg_rgb_s[gs * 3 + 2] = cb;
+        }
+      }
+    }
+    PP_END_M();
+    // ============================================================ phase 24 = T1: q | k | v of the ray transformer -> team scratch
+    // The team's conditioning rows of the next tile travel to LDS meanwhile (its half of ring slot 1, free between the views
+    // stage and layer 1 of the next tile): phase V_0 then starts from LDS instead of waiting ~8 k cycles for global loads.
+    bool next_rows = false;
+    if (S == Sp && has_next) {
+      const int first_ray = (tile + tile_step) * rays_per_tile + team * rays_per_team;
+      next_rows = first_ray + rays_per_team <= R.n_rays;
+      if (next_rows) {
+        const float* src = cond + (size_t)first_ray * S * CS;
+        const int pieces = (TEAM * CS) >> 8;  // CS is a multiple of 8: 128 rows = CS / 2 KiB
+        for (int p = tw; p < pieces; p += 4) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(rows_lds_addr + (unsigned)p * 1024u));
+      }
+    }
+    f32x16 qkv[2];
+    qkv[0] = (f32x16)(0.0f);
+    qkv[1] = (f32x16)(0.0f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) step2(qkv, tail + TAIL_QKV, r, lane, av[r]);
+    const float qs = q_valid ? 0.5f * 1.4426950408889634f : 0.0f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int head = hl + 2 * hh;
+      *reinterpret_cast<float4*>(k_lds + ((ray_t * 4 + head) * Sp + jp) * 4) =
+          make_float4(qkv[0][8 + 4 * hh], qkv[0][9 + 4 * hh], qkv[0][10 + 4 * hh], qkv[0][11 + 4 * hh]);
+      float* vcol = vt_lds + (ray_t * 4 + head) * 4 * Sp + jp;
+      vcol[0] = qkv[1][4 * hh];
+      vcol[Sp] = qkv[1][4 * hh + 1];
+      vcol[2 * Sp] = qkv[1][4 * hh + 2];
+      vcol[3 * Sp] = qkv[1][4 * hh + 3];
+      *reinterpret_cast<float4*>(q_lds + s_local * 16 + head * 4) =
+          make_float4(qkv[0][4 * hh] * qs, qkv[0][4 * hh + 1] * qs, qkv[0][4 * hh + 2] * qs, qkv[0][4 * hh + 3] * qs);
+    }
+    PP_SYNC();
+    // ============================================================ phase 25 = T2: ray attention on the matrix pipe (lane = query)
+    {
+      int a_ray, a_hp, a_jq;
+      if constexpr (SP >= 64) {
+        constexpr int CH = SP / 64;
+        int idx = tw;
+        const int chunk = idx % CH;
+        idx /= CH;
+        a_hp = idx & 1;
+        a_ray = idx >> 1;
+        a_jq = chunk * 64 + lane;
+      } else {
+        a_ray = tw;
+        a_hp = lane >> 5;
+        a_jq = lane & 31;
+      }
+      const int s_q = a_ray * Sp + a_jq;
+      constexpr int HEAD_UNROLL = SP >= 128 ? 1 : 2;
+#pragma unroll HEAD_UNROLL
+      for (int hh = 0; hh < 2; ++hh) {
+        const int head = 2 * a_hp + hh;
+        const float4 q4 = *reinterpret_cast<const float4*>(q_lds + s_q * 16 + head * 4);
+        const float* kb = k_lds + ((a_ray * 4 + head) * Sp + (lane & 3)) * 4;
+        f32x4 sc[SP / 4];
+#pragma unroll
+        for (int g = 0; g < SP / 4; ++g) {
+          const float4 kk = *reinterpret_cast<const float4*>(kb + g * 16);
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          t = mfma4(kk.x, q4.x, t);
+          t = mfma4(kk.y, q4.y, t);
+          t = mfma4(kk.z, q4.z, t);
+          t = mfma4(kk.w, q4.w, t);
+          sc[g] = t;
+        }
+        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        if (S == Sp) {
+#pragma unroll
+          for (int g = 0; g < SP / 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[g][r]);
+        } else {
+          int s_keys = S;
+          asm volatile("" : "+s"(s_keys));
+#pragma unroll
+          for (int g = 0; g < SP / 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = (4 * g + r < s_keys) ? sc[g][r] : -3.0e38f;
+              sc[g][r] = v;
+              mx4[r] = fmaxf(mx4[r], v);
+            }
+        }
+        const float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        float ls4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < SP / 4; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(sc[g][r] - mx);
+            sc[g][r] = pr;
+            ls4[r] += pr;
+          }
+        const float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
+        const float* vb = vt_lds + ((a_ray * 4 + head) * 4 + (lane & 3)) * Sp;
+        f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < SP / 4; g += 2) {
+          const float4 va = *reinterpret_cast<const float4*>(vb + 4 * g);
+          const float4 vc = *reinterpret_cast<const float4*>(vb + 4 * g + 4);
+          oa = mfma4(va.x, sc[g][0], oa);
+          ob = mfma4(vc.x, sc[g + 1][0], ob);
+          oa = mfma4(va.y, sc[g][1], oa);
+          ob = mfma4(vc.y, sc[g + 1][1], ob);
+          oa = mfma4(va.z, sc[g][2], oa);
+          ob = mfma4(vc.z, sc[g + 1][2], ob);
+          oa = mfma4(va.w, sc[g][3], oa);
+          ob = mfma4(vc.w, sc[g + 1][3], ob);
+        }
+        const float il = 1.0f / lsum;
+        *reinterpret_cast<float4*>(o_lds + s_q * 16 + head * 4) =
+            make_float4((oa[0] + ob[0]) * il, (oa[1] + ob[1]) * il, (oa[2] + ob[2]) * il, (oa[3] + ob[3]) * il);
+      }
+    }
+    segment_wait();  // the team's rows of the next tile
+    PP_SYNC();
+    // ============================================================ phase 26 = T3: fc + residual + LayerNorm, density head
+    {
+      float ofc[8];
+      {
+        const float4* src = reinterpret_cast<const float4*>(o_lds + s_local * 16 + 8 * hl);
+        const float4 t0 = src[0], t1 = src[1];
+        ofc[0] = t0.x; ofc[1] = t0.y; ofc[2] = t0.z; ofc[3] = t0.w;
+        ofc[4] = t1.x; ofc[5] = t1.y; ofc[6] = t1.z; ofc[7] = t1.w;
+      }
+      float yv[8];
+      {
+        f32x16 t1 = (f32x16)(0.0f);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) step1(t1, tail + TAIL_FCO, t, lane, ofc[t]);
+        float xs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          yv[r] = t1[r] + av[r];
+          xs += yv[r];
+        }
+        xs += __shfl_xor(xs, 32, 64);
+        const float mean = xs * (1.0f / 16.0f);
+        float var = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float dlt = yv[r] - mean;
+          var += dlt * dlt;
+        }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int o = (r & 3) + 8 * (r >> 2) + 4 * hl;
+          yv[r] = (yv[r] - mean) * rstd * ln_lds[o] + ln_lds[16 + o];
+        }
+      }
+      float sigma;
+      {
+        f32x16 t2 = (f32x16)(0.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) step1(t2, tail + TAIL_OA0, r, lane, yv[r]);
+        step1(t2, tail + TAIL_OA0, 8, lane, hl ? 0.0f : 1.0f);
+        f32x16 t3 = (f32x16)(0.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = t2[r];
+          t = D.raytrans_elu ? (t > 0.0f ? t : (expf(t) - 1.0f)) : fmaxf(t, 0.0f);
+          step1(t3, tail + TAIL_OA2, r, lane, t);
+        }
+        step1(t3, tail + TAIL_OA2, 8, lane, hl ? 0.0f : 1.0f);
+        sigma = fmaxf(t3[0], 0.0f);
+      }
+      if (D.density_maskfill && n_valid < 1.0f) sigma = 0.0f;
+      if (hl == 0) {
+        rs_lds[s_local * 4 + 3] = sigma;
+        if (dbg_sigma && ray_ok && jp < S) dbg_sigma[gs] = sigma;
+      }
+    }
+    // team B requests stage 0 of the next tile (ring slot 0: the views weights were last read four steps ago)
+    if (team == 1 && has_next) stage_dma(0, 2);
+    PP_SYNC();
+    // ============================================================ phase 27 = T4: compositing (one wavefront per ray)
+    for (int rt = tw; rt < rays_per_team; rt += 4) {
+      const int rr = tile * rays_per_tile + team * rays_per_team + rt;
+      if (rr >= R.n_rays || !out_rgb) continue;
+      float rlen = 1.0f;
+      if (!D.wo_render_interval) {
+        const RayGeom gg = make_ray(R, rr);
+        rlen = sqrtf(gg.rx * gg.rx + gg.ry * gg.ry + gg.rz * gg.rz);
+      }
+      float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, ao = 0.f;
+      for (int j0 = 0; j0 < S; j0 += 64) {
+        const int jj = j0 + lane;
+        const bool ok = jj < S;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dd = 0.f;
+        if (ok) {
+          c = reinterpret_cast<const float4*>(rs_lds)[rt * Sp + jj];
+          dd = sample_depth(R, rr, jj);
+          if (!D.wo_render_interval) {
+            const float intv = (jj + 1 < S) ? (sample_depth(R, rr, jj + 1) - dd) : 1e10f;
+            c.w = c.w * (intv * rlen);
+          }
+        }
+        float incl = __shfl_up(c.w, 1, 64);
+        if (lane == 0) incl = 0.0f;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float t = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += t;
+        }
+        const float excl = carry + incl;
+        const float w = ok ? expf(-excl) * (1.0f - expf(-c.w)) : 0.0f;
+        ar += w * c.x;
+        ag += w * c.y;
+        ab += w * c.z;
+        ad += w * dd;
+        ao += w;
+        carry = __shfl(excl + c.w, 63, 64);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        ar += __shfl_xor(ar, off, 64);
+        ag += __shfl_xor(ag, off, 64);
+        ab += __shfl_xor(ab, off, 64);
+        ad += __shfl_xor(ad, off, 64);
+        ao += __shfl_xor(ao, off, 64);
+      }
+      if (lane == 0) {
+        const float bg = D.setbg_opaque ? (1.0f - ao) : 0.0f;
+        out_rgb[(size_t)rr * 3 + 0] = ar + bg;
+        out_rgb[(size_t)rr * 3 + 1] = ag + bg;
+        out_rgb[(size_t)rr * 3 + 2] = ab + bg;
+        out_depth[rr] = ad;
+        out_opacity[rr] = ao;
+      }
+    }
+    rows_in_lds = next_rows;
+    PP_END_M();
+  }
+  if (team == 0) __syncthreads();  // team A's matching last barrier
+#undef PP_END_V
+#undef PP_BEGIN_V
+#undef PP_END_M
+#undef PP_SYNC
+#undef PP_MFMA
+#undef PP_MFMA1
+#undef PP_HDR_LDS
+#undef PP_SEG_SRC
+#undef PP_SLOT_LDS
+}
+#endif  // MNERF_DECODER_PART == 0 (ping-pong form)
+
+
 // ------------------------------------------------------------------ host side
 // Segment schedules shared with the Python packers (matchnerf_amd/cond_nerf.py).
 static void finish_schedule(DecSched* sch, int n, int film_steps, int enc_steps) {
@@ -1800,6 +2508,42 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
                        *dec, sch, *view0, *rays, cond, rgb, depth, opacity, rgb_s, sigma, ext_ndc,   \
                        ext_dir, *scn);                                                               \
   } while (0)
+#if MNERF_DECODER_PART == 0
+  // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream
+  // (S <= 64: at 128 samples per ray the scores of the ray attention take 128 registers per lane and this kernel's
+  // register budget spills more than the staged one: 99 vs 90 ms per 800x800 frame, measured)
+  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= 64 && dec->L_3D == 10 && sch.film_steps == 2 &&
+      sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
+    PPSched pps;
+    const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
+    const int nseg[PP_STAGES] = {1, 1, 2, 2, 2, 2, 1, 2, 1, 2, 2, 1};
+    for (int i = 0; i < PP_STAGES; ++i) {
+      pps.seg_first[i] = first[i], pps.n_seg[i] = nseg[i];
+      // the kernel's compile-time piece counts must be the schedule's
+      MNERF_REQUIRE((sch.seg_floats[first[i]] >> 8) == pp_p0(i) && (nseg[i] == 2 ? (sch.seg_floats[first[i] + 1] >> 8) : 0) == pp_p1(i),
+                    MNERF_E_RANGE, "%s: weight schedule does not match the ping-pong kernel (stage %d)", who, i);
+    }
+    const int rpt = 256 / Sp;
+    const int tiles = (rays->n_rays + rpt - 1) / rpt;
+    const int cus = mnerf_tune().decoder_pp_grid;  // persistent: one 8-wave workgroup per CU
+    const int grid = tiles < cus ? tiles : cus;
+#define MNERF_LAUNCH_PP(SP_)                                                                                          \
+  do {                                                                                                                \
+    const size_t lds = SmemPP<SP_>::TOTAL_FLOATS * sizeof(float);                                                     \
+    static std::atomic<unsigned long long> attr_set{0};                                                               \
+    if (mnerf_once_per_device(attr_set))                                                                              \
+      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((decoder_pp_kernel<SP_>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
+                       opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
+  } while (0)
+    if (Sp == 32)
+      MNERF_LAUNCH_PP(32);
+    else
+      MNERF_LAUNCH_PP(64);
+#undef MNERF_LAUNCH_PP
+    return mnerf_check_launch(who);
+  }
+#endif
 #if MNERF_DECODER_PART == 1
   MNERF_REQUIRE(fused_scene, MNERF_E_NULL, "%s: the one-launch form needs the scene", who);
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_) MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1)

@@ -34,6 +34,23 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr
       : "memory");
 }
 
+// The same copy with a wave-uniform source base in a scalar register pair and the per-lane byte offset (lane * 16) in ONE
+// vector register that never changes: no per-piece vector address arithmetic.  (s_nop 4: a base that came through
+// v_readfirstlane is a VALU-written SGPR read by a memory instruction.)
+__device__ __forceinline__ void glds16_s(const float* uniform_src, unsigned lane_off_bytes, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_off_bytes), "s"(uniform_src), "s"(lds_byte_addr)
+      : "memory");
+}
+
 __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------- split-fp16 matrix path ("f16x3", FMT = 2)
@@ -140,6 +157,7 @@ __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, 
       const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;  // the last unit re-reads itself
       const u32x4 nh = a[nx], nl = a[nx + 64];
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(ch), "+v"(cl));  // ONE wait for both fragments, in front of the three dependent MFMAs (see ksteps_presplit2)
       const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
       acc[m] = mfma16h(ah, b.lo, acc[m]);
       acc[m] = mfma16h(al, b.hi, acc[m]);
@@ -165,6 +183,7 @@ __device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned bas
       const int nx = (i + 1 < NS * NMB) ? (i + 1) * 128 : i * 128;
       const u32x4 nh = a[nx], nl = a[nx + 64];
       __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(ch), "+v"(cl));
       const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
       acc[m] = mfma16h(ah, b[u].lo, acc[m]);
       acc[m] = mfma16h(al, b[u].hi, acc[m]);
@@ -173,6 +192,143 @@ __device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned bas
       ch = nh;
       cl = nl;
     }
+  }
+}
+
+// The same products in the same order with the A fragments requested TWO units ahead of their matrix instructions and
+// across a segment boundary (units [0, NS0 NMB) at base0, the rest at base1): with one unit of look-ahead (96 cycles of
+// matrix work) every unit waited for its ds_read_b128 pair (measured: 4.4-5.3 k cycles for the 96 instructions of a layer
+// against 3.1 k of issue time).
+#ifndef MNERF_PP_DEPTH
+#define MNERF_PP_DEPTH 2  // units of look-ahead of the fragment reads (each unit in flight holds 8 registers)
+#endif
+template <int NMB, int NS0, int NS1>
+__device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
+                                                 const PartsH* b) {
+  constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB, DEP = MNERF_PP_DEPTH, NB = DEP + 1;
+  lds_u32x4_cptr a0 = (lds_u32x4_cptr)(size_t)base0_lds + lane;
+  lds_u32x4_cptr a1 = (lds_u32x4_cptr)(size_t)base1_lds + lane;
+  u32x4 fh[NB], fl[NB];
+  auto fetch = [&](int i, int slot) {
+    if (i < N0) {
+      fh[slot] = a0[i * 128];
+      fl[slot] = a0[i * 128 + 64];
+    } else {
+      fh[slot] = a1[(i - N0) * 128];
+      fl[slot] = a1[(i - N0) * 128 + 64];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < DEP; ++i)
+    if (i < N) fetch(i, i);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + DEP < N) fetch(i + DEP, (i + DEP) % NB);
+    __builtin_amdgcn_sched_barrier(0);
+    const int u = i / NMB, m = i % NMB;
+    // both fragments are waited for BEFORE the first of the three dependent matrix instructions: hipcc otherwise puts
+    // the s_waitcnt of the lo fragment between the first and the second, and an extra issue slot between two MFMAs on the
+    // same accumulator costs ~40 cycles (measured: 3.9 k cycles for the 96 instructions of a layer against 3.1 k)
+    asm volatile("" : "+v"(fh[i % NB]), "+v"(fl[i % NB]));
+    const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % NB]), al = __builtin_bit_cast(f16x8, fl[i % NB]);
+    acc[m] = mfma16h(ah, b[u].lo, acc[m]);
+    acc[m] = mfma16h(al, b[u].hi, acc[m]);
+    acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same again with the two output blocks of a pair (m, m+1) interleaved: a0 a1 a0 a1 a0 a1 instead of a0 a0 a0 a1 a1 a1,
+// so that no matrix instruction has the accumulator of its predecessor (every accumulator still receives its three products
+// in the same order: identical results).  Fragments of a pair are requested one pair (six matrix instructions) ahead.
+template <int NMB, int NS0, int NS1>
+__device__ __forceinline__ void ksteps_presplit2p(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
+                                                  const PartsH* b) {
+  static_assert(NMB % 2 == 0, "pairs of output blocks");
+  constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB, NP = N / 2;
+  lds_u32x4_cptr a0 = (lds_u32x4_cptr)(size_t)base0_lds + lane;
+  lds_u32x4_cptr a1 = (lds_u32x4_cptr)(size_t)base1_lds + lane;
+  u32x4 fh[2][2], fl[2][2];  // [buffer][unit of the pair]
+  auto fetch = [&](int pr, int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * pr + q;
+      if (i < N0) {
+        fh[buf][q] = a0[i * 128];
+        fl[buf][q] = a0[i * 128 + 64];
+      } else {
+        fh[buf][q] = a1[(i - N0) * 128];
+        fl[buf][q] = a1[(i - N0) * 128 + 64];
+      }
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    if (pr + 1 < NP) fetch(pr + 1, (pr + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int u = (2 * pr) / NMB, m = (2 * pr) % NMB;
+    const int bf = pr & 1;
+    const f16x8 ah0 = __builtin_bit_cast(f16x8, fh[bf][0]), al0 = __builtin_bit_cast(f16x8, fl[bf][0]);
+    const f16x8 ah1 = __builtin_bit_cast(f16x8, fh[bf][1]), al1 = __builtin_bit_cast(f16x8, fl[bf][1]);
+    acc[m] = mfma16h(ah0, b[u].lo, acc[m]);
+    acc[m + 1] = mfma16h(ah1, b[u].lo, acc[m + 1]);
+    acc[m] = mfma16h(al0, b[u].hi, acc[m]);
+    acc[m + 1] = mfma16h(al1, b[u].hi, acc[m + 1]);
+    acc[m] = mfma16h(ah0, b[u].hi, acc[m]);
+    acc[m + 1] = mfma16h(ah1, b[u].hi, acc[m + 1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ksteps_presplit2 with the NEXT stage's weight pieces requested between the matrix instructions (the cheapest place to
+// issue an LDS-DMA: ~60 cycles among MFMAs against 150-200 in a VALU phase): this wave takes pieces tw, tw+4, .. of the P0 /
+// P1 one-KiB pieces of the next stage's two segments and spreads them evenly over the units of this stage.
+template <int NMB, int NS0, int NS1, int P0, int P1>
+__device__ __forceinline__ void ksteps_presplit2_dma(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
+                                                     const PartsH* b, bool issue, int tw, const float* src0,
+                                                     const float* src1, unsigned dst0_lds, unsigned dst1_lds) {
+  constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB;
+  constexpr int K0 = (P0 + 3) / 4, K1 = (P1 + 3) / 4, K = K0 + K1;
+  lds_u32x4_cptr a0 = (lds_u32x4_cptr)(size_t)base0_lds + lane;
+  lds_u32x4_cptr a1 = (lds_u32x4_cptr)(size_t)base1_lds + lane;
+  const unsigned voff = (unsigned)lane * 16u;
+  u32x4 fh[3], fl[3];
+  auto fetch = [&](int i, int slot) {
+    if (i < N0) {
+      fh[slot] = a0[i * 128];
+      fl[slot] = a0[i * 128 + 64];
+    } else {
+      fh[slot] = a1[(i - N0) * 128];
+      fl[slot] = a1[(i - N0) * 128 + 64];
+    }
+  };
+  fetch(0, 0);
+  if (N > 1) fetch(1, 1);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i + 2 < N) fetch(i + 2, (i + 2) % 3);
+    __builtin_amdgcn_sched_barrier(0);
+    const int u = i / NMB, m = i % NMB;
+    const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % 3]), al = __builtin_bit_cast(f16x8, fl[i % 3]);
+    acc[m] = mfma16h(ah, b[u].lo, acc[m]);
+    acc[m] = mfma16h(al, b[u].hi, acc[m]);
+    acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    // pieces k with floor(k N / K) == i go out behind unit i
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if ((k * N) / K == i && issue) {
+        if (k < K0) {
+          const int pce = tw + 4 * k;
+          if (pce < P0) glds16_s(src0 + pce * 256, voff, __builtin_amdgcn_readfirstlane(dst0_lds + (unsigned)pce * 1024u));
+        } else {
+          const int pce = tw + 4 * (k - K0);
+          if (pce < P1) glds16_s(src1 + pce * 256, voff, __builtin_amdgcn_readfirstlane(dst1_lds + (unsigned)pce * 1024u));
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -1,6 +1,15 @@
 """End-to-end GPU parity of the drop-in module: MatchNeRF(opts).forward(batch, mode) on the HIP
 path vs the reference goldens (encoder with the K6 kernel + render kernels), for the
 BASELINE config[0] case and the option variants.  Gate: RGB L-inf <= 1e-4 (north_star)."""
+import os
+
+# The training path runs the encoder through the ROCm libraries (MIOpen convolutions).  MIOpen's find mode may pick
+# Winograd / FFT solvers for the fp32 backward convolutions on one box and direct ones on another; the former are only
+# good to ~1e-3 relative, which is the gate of the gradient test below.  Direct / implicit-GEMM solvers only:
+if os.environ.get("MNERF_TEST_NO_WINOGRAD", "1") == "1":
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_FFT", "0")
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +20,10 @@ from matchnerf_amd.edict import EasyDict
 from oracle import matchnerf_oracle as O
 
 pytestmark = pytest.mark.gpu
+if "MNERF_TEST_CUDNN_BENCHMARK" in os.environ:
+    torch.backends.cudnn.benchmark = os.environ["MNERF_TEST_CUDNN_BENCHMARK"] == "1"
+if "MNERF_TEST_CUDNN_DETERMINISTIC" in os.environ:
+    torch.backends.cudnn.deterministic = os.environ["MNERF_TEST_CUDNN_DETERMINISTIC"] == "1"
 
 
 def build_model(meta, device="cuda"):
