@@ -364,7 +364,7 @@ def main():
         issued_launch = samples_launch * (ppm * MLP_FLOPS_PER_SAMPLE + (flops_per_sample(S) - MLP_FLOPS_PER_SAMPLE))
         render_ms = dec["total_ms"] / args.steps + (cv_ms or 0.0)
         render_rate = n_rays / (render_ms * 1e-3)
-        counters = measured_counters("decoder_kernel") if math == decoder_math() else None
+        counters = measured_counters("decoder_") if math == decoder_math() else None
         fresh = bool(counters) and not counters.get("stale")
         mfma_bound = F32_MFMA_PEAK_TFLOPS * 1e12 / (S * flops_per_sample(S))
         gather_bound = HBM_PEAK_BYTES / (S * GATHER_BYTES_PER_SAMPLE)
@@ -401,7 +401,9 @@ def main():
             "roofline": {
                 "bound": "mfma",
                 "kernel": ("decoder_kernel<4,64,2,1> (ONE launch: cost volume + MLP + ray transformer + compositing)" if fused
-                           else "decoder_kernel<4,64> (fused MLP + ray transformer + compositing)"),
+                           else "decoder_pp_kernel<64> (split-fp16 MLP + ray transformer + compositing, ping-pong teams; "
+                                "decoder_kernel<4,64,2,0> with MNERF_DECODER_PP=0)" if math == "f16x3" else
+                                "decoder_kernel<4,64> (fused MLP + ray transformer + compositing)"),
                 "achieved": round(algorithmic, 2), "peak": round(PATH_CEILING_TFLOPS[math], 1), "unit": "TFLOP/s",
                 "frac": round(algorithmic / PATH_CEILING_TFLOPS[math], 4),
                 "what": "ALGORITHMIC FLOPs (SURVEY.md 8d: 258336 + 64 S per sample) / measured launch time vs the ceiling "

@@ -120,6 +120,9 @@ __device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {  /
   return r;
 }
 
+#ifndef CVW_RELOAD_ANY
+#define CVW_RELOAD_ANY 0
+#endif
 #ifndef CVW_PROBE
 #define CVW_PROBE 0  // race probes (tools/exp/race_probe.py): 3 shuffles instead of DPP, 4 unconditional tap reloads,
 #endif               // 5 / 7 hard waits at the slot-local LDS hand-offs, 6 no LDS atomic
@@ -195,6 +198,17 @@ __device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __res
   tap_load<CPL>(q.t[0][1], map, i01, lane_bytes);
   tap_load<CPL>(q.t[1][0], map, i10, lane_bytes);
   tap_load<CPL>(q.t[1][1], map, i11, lane_bytes);
+  return;
+#endif
+#if CVW_RELOAD_ANY
+  // A tap set is reloaded by the WHOLE wave as soon as ANY of its slots has crossed a texel boundary: the texture-address
+  // unit charges a load instruction 16 cycles whatever its lane mask (tools/exp/ta_mask.hip), and the four slots of a wave
+  // cross at different steps, so per-slot reloads are four quarter-full instructions where one full one does (the slots
+  // that had not moved re-read their texel from L1).
+  if (__builtin_amdgcn_ballot_w64(i00 != q.idx[0][0])) { tap_load<CPL>(q.t[0][0], map, i00, lane_bytes); q.idx[0][0] = i00; }
+  if (__builtin_amdgcn_ballot_w64(i01 != q.idx[0][1])) { tap_load<CPL>(q.t[0][1], map, i01, lane_bytes); q.idx[0][1] = i01; }
+  if (__builtin_amdgcn_ballot_w64(i10 != q.idx[1][0])) { tap_load<CPL>(q.t[1][0], map, i10, lane_bytes); q.idx[1][0] = i10; }
+  if (__builtin_amdgcn_ballot_w64(i11 != q.idx[1][1])) { tap_load<CPL>(q.t[1][1], map, i11, lane_bytes); q.idx[1][1] = i11; }
   return;
 #endif
   if (i00 != q.idx[0][0]) { tap_load<CPL>(q.t[0][0], map, i00, lane_bytes); q.idx[0][0] = i00; }

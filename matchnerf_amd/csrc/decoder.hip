@@ -1669,17 +1669,15 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   float* ln_lds = rs_all + SM::RS_FLOATS;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, tw = wave & 3;
-  const int n = lane & 31, hl = lane >> 5;
   const int S = R.n_samples;
   const int rays_per_team = TEAM / Sp, rays_per_tile = 2 * rays_per_team;
   const int n_tiles = (R.n_rays + rays_per_tile - 1) / rays_per_tile;
   const int CS = D.cond_stride;
   const float freq_mul = R.legacy_coord ? 1.0f : 3.14159265358979323846f;
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
-  const unsigned voff = (unsigned)lane * 16u;
   float* rs_lds = rs_all + team * TEAM * 4;
   // a team's ray-attention scratch: ring slot 3 (team A) / 2 (team B), free while that team is in its tail phases
   float* att = smem + (team == 0 ? 3 : 2) * SEG_CAP_FLOATS;
@@ -1698,6 +1696,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   // ---- prologue: LayerNorm parameters, the resident tail segment, the stage headers, stage 0 of the first tile
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
   {
+    const unsigned voff = (unsigned)lane0 * 16u;
     const int seg = sch.n_seg - 1;
     const int pieces = sch.seg_floats[seg] >> 8;
     for (int p = wave; p < pieces; p += 8)
@@ -1722,7 +1721,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   int pp_tl_tile = -1, pp_ph = 0;
 #define PP_SYNC()                                                                                              \
   do {                                                                                                         \
-    unsigned long long* o_ = (sch.tl && lane == 0 && blockIdx.x < 32 && pp_tl_tile >= 0 && pp_tl_tile < 4)     \
+    unsigned long long* o_ = (sch.tl && lane0 == 0 && blockIdx.x < 32 && pp_tl_tile >= 0 && pp_tl_tile < 4)     \
                                  ? sch.tl + ((((size_t)blockIdx.x * 4 + pp_tl_tile) * 8 + wave) * PP_PHASES + pp_ph) * 2 \
                                  : nullptr;                                                                    \
     if (o_) o_[0] = __builtin_amdgcn_s_memtime();                                                              \
@@ -1735,6 +1734,8 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #endif
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
+    unsigned voff = (unsigned)lane0 * 16u;
+    asm volatile("" : "+v"(voff));
     for (int i = 0; i < pps.n_seg[s]; ++i) {
       const float* src = PP_SEG_SRC(s, i);
       const int pieces = sch.seg_floats[pps.seg_first[s] + i] >> 8;
@@ -1787,6 +1788,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     pp_ph = 0;
 #endif
     const bool has_next = tile + tile_step < tile_end;
+    // Everything that depends only on the lane index is re-derived per tile from an OPAQUE copy of it: hoisted out of the
+    // tile loop these values (sample indices, LDS addresses, pointers) stay live across all 28 phases, the register
+    // allocator parks them in scratch, and phase V_0 became a chain of ~20 scratch reloads (7 k cycles, measured).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int n = lane & 31, hl = lane >> 5;
+    const unsigned voff = (unsigned)lane * 16u;
     // ------------------------------------------------------------ per-lane sample identity
     const int s_local = tw * 32 + n;                  // sample within the team
     const int ray_t = s_local / Sp;                   // ray within the team
@@ -1823,27 +1831,20 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
       n_valid = nv;
     }
-    float x, y, z, dx, dy, dz;
+    // (only x, y, z stay in registers across the trunk: the two-float encoding bases are re-derived where the encoding is
+    // evaluated, the view direction where the views stage needs it — kept alive from here they were spilled and reloaded)
+    float x, y, z;
     if (ext_ndc) {
       x = ext_ndc[gs * 3 + 0];
       y = ext_ndc[gs * 3 + 1];
       z = ext_ndc[gs * 3 + 2];
-      dx = ext_dir[gs * 3 + 0];
-      dy = ext_dir[gs * 3 + 1];
-      dz = ext_dir[gs * 3 + 2];
     } else {
       const RayGeom g = make_ray(R, ray);
       const float dpt = sample_depth(R, ray, j);
       float wx_, wy_, wz_;
       ray_point(g, dpt, wx_, wy_, wz_);
       project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
-      const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
-      const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
-      dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
-      dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
-      dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
     }
-    const EncBase encb = enc_base(x, y, z, freq_mul);
     const float enc_max = fmaxf(fmaxf(1.0f, fabsf(x)), fmaxf(fabsf(y), fabsf(z)));
     const bool q_valid = n_valid > 1.0f;
 
@@ -1868,8 +1869,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     f32x16 acc[4];
     int ew_cur = 0, ec, em;
     auto split_enc = [&](float mult) {  // 32 encoding operands -> hs[0..3]
+      // (opaque copies: otherwise the second evaluation, six stages later, is merged with the first one and the 32 values
+      // travel through scratch — 33 stores in V_1, 53 scratch operations with 35 separate waits in V_6: 12 k cycles)
+      float xo = x, yo = y, zo = z;
+      asm volatile("" : "+v"(xo), "+v"(yo), "+v"(zo));
+      const EncBase encb = enc_base(xo, yo, zo, freq_mul);
       {
-        const f32x16 e0 = enc_block16_L10<0>(encb, hl, x, y, z);
+        const f32x16 e0 = enc_block16_L10<0>(encb, hl, xo, yo, zo);
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = e0[r];
@@ -1879,7 +1885,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         hs[1] = split8h(v, mult);
       }
       {
-        const f32x16 e1 = enc_block16_L10<16>(encb, hl, x, y, z);
+        const f32x16 e1 = enc_block16_L10<16>(encb, hl, xo, yo, zo);
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = e1[r];
@@ -1952,7 +1958,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     {
       hmax = film_relu(h5);
       eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
-      split_enc(pow2i(eg));
+      __builtin_amdgcn_sched_barrier(0);  // three separate steps: activations (64 registers), encoding operands, then the
+      split_enc(pow2i(eg));               // accumulators' biases — interleaved by the scheduler they do not fit 256 registers
+      __builtin_amdgcn_sched_barrier(0);
       ew_cur = header_ew(PP_HDR_LDS(6));
       bias_init_h<4>(acc, PP_HDR_LDS(6), hl, pow2i(ew_cur + eg));
     }
@@ -2004,6 +2012,19 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     f32x16 hv[2];
     PP_BEGIN_V(10);
     {  // V_10
+      float dx, dy, dz;  // view direction in the frame of source view 0 (matchnerf.py:129-131)
+      if (ext_ndc) {
+        dx = ext_dir[gs * 3 + 0];
+        dy = ext_dir[gs * 3 + 1];
+        dz = ext_dir[gs * 3 + 2];
+      } else {
+        const RayGeom g = make_ray(R, ray);
+        const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
+        const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
+        dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
+        dy = ux * view0.extr[4] + uy * view0.extr[5] + uz * view0.extr[6];
+        dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
+      }
       egv = gain_exp(fmaxf(1.0f, sample_absmax<4>(acc) * pow2i(ecfeat)));
       split_blocks(acc, pow2i(egv + ecfeat));
       const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};

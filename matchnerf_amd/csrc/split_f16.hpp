@@ -105,6 +105,13 @@ __device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
 __device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// Diagnostic build (-DMNERF_ONE_PRODUCT, tools/exp/one_product.sh; never shipped): the two cross products hi.lo and lo.hi are
+// skipped, i.e. plain fp16 operands with fp32 accumulation — how much of the kernel's time is the 3x split tax?
+#ifdef MNERF_ONE_PRODUCT
+#define MFMA16H_CROSS(a_, b_, c_) (c_)
+#else
+#define MFMA16H_CROSS(a_, b_, c_) mfma16h(a_, b_, c_)
+#endif
 
 // exponent em with 2^em * m in [2^14, 2^15) (m > 0; clamped so that every scale stays a normal fp32 number)
 __device__ __forceinline__ int gain_exp(float m) {
@@ -159,8 +166,8 @@ __device__ __forceinline__ void ksteps_h(f32x16 (&acc)[NMB], unsigned base_lds, 
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+v"(ch), "+v"(cl));  // ONE wait for both fragments, in front of the three dependent MFMAs (see ksteps_presplit2)
       const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
-      acc[m] = mfma16h(ah, b.lo, acc[m]);
-      acc[m] = mfma16h(al, b.hi, acc[m]);
+      acc[m] = MFMA16H_CROSS(ah, b.lo, acc[m]);
+      acc[m] = MFMA16H_CROSS(al, b.hi, acc[m]);
       acc[m] = mfma16h(ah, b.hi, acc[m]);
       __builtin_amdgcn_sched_barrier(0);
       ch = nh;
@@ -185,8 +192,8 @@ __device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned bas
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+v"(ch), "+v"(cl));
       const f16x8 ah = __builtin_bit_cast(f16x8, ch), al = __builtin_bit_cast(f16x8, cl);
-      acc[m] = mfma16h(ah, b[u].lo, acc[m]);
-      acc[m] = mfma16h(al, b[u].hi, acc[m]);
+      acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
+      acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
       acc[m] = mfma16h(ah, b[u].hi, acc[m]);
       __builtin_amdgcn_sched_barrier(0);
       ch = nh;
@@ -231,8 +238,8 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
     // same accumulator costs ~40 cycles (measured: 3.9 k cycles for the 96 instructions of a layer against 3.1 k)
     asm volatile("" : "+v"(fh[i % NB]), "+v"(fl[i % NB]));
     const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % NB]), al = __builtin_bit_cast(f16x8, fl[i % NB]);
-    acc[m] = mfma16h(ah, b[u].lo, acc[m]);
-    acc[m] = mfma16h(al, b[u].hi, acc[m]);
+    acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
+    acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
     acc[m] = mfma16h(ah, b[u].hi, acc[m]);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -311,8 +318,8 @@ __device__ __forceinline__ void ksteps_presplit2_dma(f32x16 (&acc)[NMB], unsigne
     __builtin_amdgcn_sched_barrier(0);
     const int u = i / NMB, m = i % NMB;
     const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % 3]), al = __builtin_bit_cast(f16x8, fl[i % 3]);
-    acc[m] = mfma16h(ah, b[u].lo, acc[m]);
-    acc[m] = mfma16h(al, b[u].hi, acc[m]);
+    acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
+    acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
     acc[m] = mfma16h(ah, b[u].hi, acc[m]);
     __builtin_amdgcn_sched_barrier(0);
     // pieces k with floor(k N / K) == i go out behind unit i

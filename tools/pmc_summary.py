@@ -15,7 +15,7 @@ def main(root):
                 acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 calls[k].add((path, row["Dispatch_Id"]))
     for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("FETCH_SIZE", 0))):
-        if not any(s in k for s in ("decoder_kernel", "cost_volume", "window_attention", "encoder_block", "conv_kernel",
+        if not any(s in k for s in ("decoder_kernel", "decoder_pp_kernel", "cost_volume", "window_attention", "encoder_block", "conv_kernel",
                                     "conv_stem", "qkv_", "instance_norm")):
             continue
         n = max(len(calls[k]), 1)

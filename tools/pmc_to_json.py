@@ -30,9 +30,9 @@ def main(root, frames, out):
                 k = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
                 acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 rows[k][row["Counter_Name"]].add((path, row["Dispatch_Id"]))
-    dec = [k for k in acc if k.startswith("decoder_kernel")]
+    dec = [k for k in acc if k.startswith("decoder_kernel") or k.startswith("decoder_pp_kernel")]
     if not dec:
-        raise SystemExit(f"no decoder_kernel rows under {root}")
+        raise SystemExit(f"no decoder kernel rows under {root}")
     k = max(dec, key=lambda k: acc[k].get("SQ_WAVE_CYCLES", 0) + acc[k].get("FETCH_SIZE", 0))
     c = acc[k]
     launches = {name: len(v) for name, v in rows[k].items()}

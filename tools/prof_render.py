@@ -1,5 +1,7 @@
-"""Small driver for rocprofv3 counter passes: one encoder pass + one full-frame render at
-BASELINE config[1] (5 launches of each render kernel), no CPU baseline, no warm-up loop."""
+"""Small driver for rocprofv3 passes: `frames` full-frame renders (encoder + ray chunks) of one BASELINE configuration,
+no CPU baseline, no warm-up loop.   prof_render.py [frames] [c2 | c3 | c5]
+  c2 (default) BASELINE config[1]: 512x640, 3 views, 64 samples;  c3 config[2]: Blender-like 800x800, 128 samples, white
+  background;  c5 config[4]: 10 source views at 512x640."""
 import os
 import sys
 
@@ -9,10 +11,20 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-opt, model, _ = bench.build_model(torch.device("cuda:0"))
-_, batch = bench.make_batch(torch.device("cuda:0"), 0)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+dev = torch.device("cuda:0")
+if cfg == "c3":
+    opt, model, _ = bench.build_model(dev, 3, 128)
+    model.nerf_setbg_opaque = True
+    _, batch = bench.make_batch(dev, 0, 800, 800, 3, seed=31, wide=True, focal_scale=1.389, near_far=(2.0, 6.0))
+elif cfg == "c5":
+    opt, model, _ = bench.build_model(dev, 10, 64)
+    _, batch = bench.make_batch(dev, 0, 512, 640, 10, seed=32)
+else:
+    opt, model, _ = bench.build_model(dev)
+    _, batch = bench.make_batch(dev, 0)
 with torch.no_grad():
     for _ in range(frames):
         out = model(batch, mode="test")
 torch.cuda.synchronize()
-print("rendered", tuple(out.rgb.shape), float(out.rgb.mean()))
+print("rendered", cfg, tuple(out.rgb.shape), float(out.rgb.mean()))

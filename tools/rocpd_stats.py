@@ -17,7 +17,7 @@ def main(path, top=40, last_frame=0):
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
     rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
     if last_frame:
-        dec = sorted(e for n, s, e in rows if "decoder_kernel" in n)
+        dec = sorted(e for n, s, e in rows if "decoder_kernel" in n or "decoder_pp_kernel" in n)
         if len(dec) > last_frame:
             t0 = dec[-last_frame - 1]
             rows = [r for r in rows if r[1] > t0]
