@@ -2533,7 +2533,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream
   // (S <= 64: at 128 samples per ray the scores of the ray attention take 128 registers per lane and this kernel's
   // register budget spills more than the staged one: 99 vs 90 ms per 800x800 frame, measured)
-  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= 64 && dec->L_3D == 10 && sch.film_steps == 2 &&
+  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= mnerf_tune().decoder_pp_max_s && dec->L_3D == 10 && sch.film_steps == 2 &&
       sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
     PPSched pps;
     const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
@@ -2559,8 +2559,10 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   } while (0)
     if (Sp == 32)
       MNERF_LAUNCH_PP(32);
-    else
+    else if (Sp == 64)
       MNERF_LAUNCH_PP(64);
+    else
+      MNERF_LAUNCH_PP(128);
 #undef MNERF_LAUNCH_PP
     return mnerf_check_launch(who);
   }
