@@ -250,6 +250,222 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
   }
 }
 
+// ============================================================================ texel tiles (MNERF_CV_VARIANT=5; NOT the default)
+// The walk above fetches every tap through the texture path: ~9 load instructions per wave-step, most of them a quarter full
+// (the four slots of a wave cross texel boundaries at different steps), the texture-address unit ~85 % busy.  The 16 adjacent
+// rays x 8 samples of a workgroup step touch only 12-30 distinct texels of a map (tools/exp/cv_torus.py) and read each of them
+// ~20 times, so this kernel has the WORKGROUP stage those texels in LDS once per (pair, scale) and the walk read its taps with
+// ds_read_b128:
+//   B  lane (js, side) of a slot evaluates the walk record of its sample and view (as before) and CLAIMS an LDS place for each of
+//      the record's four texels: place = (x mod 16, y mod 3) of a small torus per map, claimed with one LDS compare-and-swap on a
+//      tag word (EMPTY -> texel index).  A tile whose footprint is at most 16 x 3 texels claims without collisions; a texel that
+//      finds its place taken by a different texel keeps its global index (encoded negative) and is loaded as before.
+//   C  all 256 threads copy the claimed texels into their places (32 lanes x 16 B per texel, 8 texels per pass) and clear the
+//      other tag set for the next (pair, scale);
+//   D  the slots walk: tile_walk (straight-line, taps of step js+1 requested before the arithmetic of step js) when every texel
+//      of the wave's walk is staged, lean_walk<.., TILE> otherwise.  Same arithmetic, same order, same bits as the walk kernel.
+// Two workgroup barriers per (pair, scale): after B (claims complete; every wave has also left the previous walk, so the
+// texel area may be overwritten) and after C.  Wave-local scratch (projections, walk records, cosine sums) as in the walk kernel.
+//
+// MEASURED (MI355X, tools/exp/cvt_check.sh, cvt_stats.py): bit-identical rows, and SLOWER than the walk kernel - 15.8 vs 9.8 ms
+// per frame at 3 views (0.29 % of the references lose their place, 7 % of the wave-walks take the cached walk), 286 vs 182 ms at
+// 10 views (11 % lose their place: wider baselines, 36-72 distinct texels per tile and map).  The staged walk itself runs at
+// 1 380 cycles per wave-step with two waves per SIMD = 690 per SIMD and step, against 750 for the walk kernel (3 000 at four
+// waves): 126 VALU instructions per step (88 of them the interpolation and the three dot products) are ~504 issue cycles, so
+// BOTH kernels sit at 60-73 % of the vector-ALU bound of this formulation and the texture path was never the only wall; what the
+// tiles add - claims 11 %, copy 15 %, barriers 6 %, 247 VGPRs = half the waves - is not paid back.  The packed-fp32 form of the
+// arithmetic would halve the 88 (see cv_walk.hpp for why it is not used).  Kept as an opt-in because it is the measured answer to
+// "stage the texels cooperatively", not because it is useful.
+#define CVT_SEG 8
+#define CVT_TW 16           // torus: 16 texels wide (the 16 rays of a tile are neighbours along x), 3 rows
+#define CVT_TH 3
+#define CVT_PLACES_MAX (CVT_TW * CVT_TH)
+__device__ __forceinline__ int cvt_ymod(int y) { return y - (int)(__umulhi((unsigned)y, 0xAAAAAAABu) >> 1) * 3; }  // y mod 3
+__host__ __device__ inline size_t cvt_lds_bytes(int n_views, int sum_groups) {
+  return (size_t)2 * CVT_PLACES_MAX * FEAT_C * 4 + (size_t)2 * 2 * CVT_PLACES_MAX * 4 +
+         (size_t)16 * cv_slot_lds_floats(CVT_SEG, n_views, sum_groups) * 4;
+}
+
+#ifdef CVT_STATS
+#define CVT_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define CVT_T(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - t_last; t_last = t_; }
+#else
+#define CVT_DBG_PARAM
+#define CVT_T(i)
+#endif
+__global__ __launch_bounds__(256, 2) void cost_volume_tile_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
+                                                                  float* __restrict__ cond CVT_DBG_PARAM) {
+#ifdef CVT_STATS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+  unsigned n_fallback = 0, n_claims = 0, n_slow = 0;
+#endif
+  constexpr int CPL = 8, LPS = 16, NSLOT = 16, SEG = CVT_SEG;
+  static_assert(LPS == 2 * SEG, "a slot's lanes are the (sample, side) pairs of one walk");
+  extern __shared__ __attribute__((aligned(16))) float cvt_smem[];
+  const int V = sc.n_views;
+  const int tid = threadIdx.x;
+  const int sub = tid % LPS, slot = tid / LPS;
+  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
+  const int sumG = G0 + G1;
+  const int cs_stride = (sumG + 3) & ~3;
+  const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
+  const unsigned lane_bytes = (unsigned)sub * CPL * 4;
+  // LDS: staged texels [2 maps][places][512 B] | tags [2 sets][2 maps x places] | per slot: uv | walk records | cosine sums
+  char* tex = reinterpret_cast<char*>(cvt_smem);
+  int* tags = reinterpret_cast<int*>(cvt_smem + 2 * CVT_PLACES_MAX * FEAT_C);
+  float* scratch = cvt_smem + 2 * CVT_PLACES_MAX * FEAT_C + 2 * 2 * CVT_PLACES_MAX;
+  float* uv_lds = scratch + (size_t)slot * SEG * V * 2;
+  float4* wrec_lds = reinterpret_cast<float4*>(scratch + (size_t)NSLOT * SEG * V * 2) + (size_t)slot * SEG * 4;
+  float* cs_lds = scratch + (size_t)NSLOT * SEG * (V * 2 + 16) + slot * SEG * cs_stride;
+  const int S = R.n_samples;
+  const int n_seg = (S + SEG - 1) / SEG;
+
+  // XCD-major contiguous runs of ray blocks (see cost_volume_kernel)
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin;
+  const long long blocks_total = ((long long)R.n_rays + NSLOT - 1) / NSLOT;
+  const long long bpc = (blocks_total + nwg - 1) / nwg;
+  const long long b_begin = (long long)chunk * bpc;
+  long long b_end = b_begin + bpc;
+  if (b_end > blocks_total) b_end = blocks_total;
+
+  for (int i = tid; i < 2 * 2 * CVT_PLACES_MAX; i += 256) tags[i] = -1;
+  __syncthreads();
+  int tag_set = 0;  // the set the next (pair, scale) claims in; the other one is cleared meanwhile
+
+  const int js_mine = sub & (SEG - 1), side_mine = sub >> 3;  // phase B: this lane's (sample, side)
+  for (long long it = b_begin * n_seg; it < b_end * n_seg; ++it) {
+    const long long rb = it / n_seg;
+    const int j0 = (int)(it - rb * n_seg) * SEG;
+    long long ray_ll = rb * NSLOT + slot;
+    const bool ray_live = ray_ll < R.n_rays;
+    if (!ray_live) ray_ll = R.n_rays - 1;
+    const int ray = (int)ray_ll;
+    const int jrow = j0 < S ? j0 : S - 1;
+    float* row0 = cond + ((size_t)ray * S + jrow) * cond_stride;
+
+    CVT_T(7)
+    cv_pass1<CPL, SEG, true>(sc, R, ray, ray_live, j0, row0, cond_stride, uv_lds, sub);
+    for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;
+    cvw_handoff();
+    CVT_T(0)
+
+    int p = 0;
+    for (int a = 0; a < V - 1; ++a) {
+      for (int b = a + 1; b < V; ++b, ++p) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s >= sc.n_scales) break;
+          const int fh = sc.fh[s], fw = sc.fw[s];
+          const size_t map_elems = (size_t)fh * fw * FEAT_C;
+          const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems;
+          const float* m1 = m0 + map_elems;
+          const int G = sc.n_group[s];
+          const int lpg = LPS / G;
+          const int goff = s ? G0 : 0;
+          float* cs_group = cs_lds + goff + sub / lpg;
+          constexpr int places = CVT_PLACES_MAX;
+          int* tg = tags + tag_set * (2 * CVT_PLACES_MAX);
+
+          // ---- B: walk record of (js_mine, side_mine), its four texels claimed in the torus of that map
+          bool wave_all_staged;
+          cvw_handoff();  // this wave's previous walk has read its records
+          {
+            const int vw = side_mine ? b : a;
+            int x0, y0;
+            const TapRec t = tap_setup_xy(uv_lds[(js_mine * V + vw) * 2], uv_lds[(js_mine * V + vw) * 2 + 1], fh, fw, x0, y0);
+            float4 ri, rw;
+            tap_expand(t, fw, ri, rw);
+            int ix[4] = {__float_as_int(ri.x), __float_as_int(ri.y), __float_as_int(ri.z), __float_as_int(ri.w)};
+            const int fl = t.flags;  // bit0/1: x offset of the even/odd column set, bit2/3: row offset of the even/odd row set
+            const int xm[2] = {(x0 + (fl & 1)) & (CVT_TW - 1), (x0 + ((fl >> 1) & 1)) & (CVT_TW - 1)};
+            const int ym[2] = {cvt_ymod(y0 + ((fl >> 2) & 1)), cvt_ymod(y0 + ((fl >> 3) & 1))};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // {EE, EO, OE, OO} = [row set][column set], tap_expand()'s order
+              const int place = side_mine * places + ym[k >> 1] * CVT_TW + xm[k & 1];
+              const int old = atomicCAS(tg + place, -1, ix[k]);
+              ix[k] = (old == -1 || old == ix[k]) ? place * (FEAT_C * 4) : ~ix[k];
+#ifdef CVT_STATS
+              n_claims++;
+              n_fallback += ix[k] < 0;
+#endif
+            }
+            wave_all_staged = __builtin_amdgcn_ballot_w64((ix[0] | ix[1] | ix[2] | ix[3]) < 0) == 0;
+            wrec_lds[(js_mine * 2 + side_mine) * 2] =
+                make_float4(__int_as_float(ix[0]), __int_as_float(ix[1]), __int_as_float(ix[2]), __int_as_float(ix[3]));
+            wrec_lds[(js_mine * 2 + side_mine) * 2 + 1] = rw;
+          }
+          CVT_T(1)
+          __syncthreads();
+          CVT_T(2)
+
+          // ---- C: copy the claimed texels into their places; clear the other tag set
+          {
+            const int l32 = tid & 31;
+            const unsigned dst_lane = (unsigned)((l32 & 1) * 256 + (l32 >> 1) * 16);  // [half][owner lane] (tap_load_tile)
+            constexpr int n_ent = 2 * places;  // 96: whole groups of 32
+            for (int e0 = tid >> 5; e0 < n_ent; e0 += 32) {
+              int tx[4];
+              v4f val[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) tx[q] = tg[e0 + 8 * q];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {  // unclaimed places read texel 0 (one cached line) and store nothing
+                const int e = e0 + 8 * q;
+                val[q] = *reinterpret_cast<const v4f*>((e >= places ? m1 : m0) + (size_t)max(tx[q], 0) * FEAT_C + l32 * 4);
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (tx[q] >= 0) *reinterpret_cast<v4f*>(tex + (unsigned)(e0 + 8 * q) * (FEAT_C * 4) + dst_lane) = val[q];
+            }
+            int* other = tags + (tag_set ^ 1) * (2 * CVT_PLACES_MAX);
+            if (tid < 2 * CVT_PLACES_MAX) other[tid] = -1;
+            tag_set ^= 1;
+          }
+          CVT_T(3)
+          __syncthreads();
+          CVT_T(4)
+
+          // ---- D: walk
+          if (wave_all_staged) {
+            switch (lpg) {
+              case 2: tile_walk<CPL, 2, SEG>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+              case 4: tile_walk<CPL, 4, SEG>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+              default: tile_walk<CPL, 8, SEG>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+            }
+          } else {  // some texel of this wave's walk lost its LDS place: the walk with the register tap cache
+#ifdef CVT_STATS
+            n_slow++;
+#endif
+            switch (lpg) {
+              case 2: lean_walk<CPL, 2, SEG, true>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+              case 4: lean_walk<CPL, 4, SEG, true>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+              default: lean_walk<CPL, 8, SEG, true>(m0, m1, wrec_lds, cs_group, cs_stride, sub, lane_bytes, tex); break;
+            }
+          }
+          CVT_T(5)
+        }
+      }
+    }
+    cvw_handoff();
+    cv_write_cosines<CPL, SEG, true>(R, ray_live, j0, row0, cond_stride, cs_lds, cs_stride, sumG, inv_pairs, sub);
+    __builtin_amdgcn_wave_barrier();
+    CVT_T(6)
+  }
+#ifdef CVT_STATS
+  if (dbg) {
+    if ((tid & 63) == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(dbg + i, st[i]);
+    atomicAdd(dbg + 8, (unsigned long long)n_claims);
+    atomicAdd(dbg + 9, (unsigned long long)n_fallback);
+    if (tid == 0) atomicAdd(dbg + 10, 1ull);
+    if ((tid & 63) == 0) atomicAdd(dbg + 11, (unsigned long long)n_slow);
+  }
+#endif
+}
+
 int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char* who) {
   MNERF_REQUIRE(sc && rays, MNERF_E_NULL, "%s: NULL argument struct", who);
   MNERF_REQUIRE(sc->n_views >= 2 && sc->n_views <= MNERF_MAX_VIEWS, MNERF_E_RANGE,
@@ -290,8 +506,38 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
   if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
   int variant = mnerf_tune().cv_variant;  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = one sample per slot iteration
-  if (variant != 3 && variant != 4) variant = 0;
+  if (variant != 3 && variant != 4 && variant != 5) variant = 0;
   if (sumG > CVW_CS_MAX) variant = 0;
+  if (variant == 5) {  // texel tiles: 8-sample walks need at most 8 lanes per channel group; LDS for two workgroups per CU
+    bool ok = cvt_lds_bytes(scene->n_views, sumG) <= 80 * 1024;
+    for (int s = 0; s < scene->n_scales; ++s) ok = ok && scene->n_group[s] >= 2;
+    if (!ok) variant = 3;
+  }
+  if (variant == 5) {
+    const size_t lds = cvt_lds_bytes(scene->n_views, sumG);
+    static std::atomic<int> tile_lds_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<int>& seen = tile_lds_set[dev & 63];
+    if ((int)lds > seen.load(std::memory_order_relaxed)) {
+      (void)hipFuncSetAttribute((const void*)cost_volume_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      seen.store((int)lds, std::memory_order_relaxed);
+    }
+    long long wgs = ((long long)rays->n_rays + 15) / 16;
+    int cap = 512;  // two resident workgroups per CU, one contiguous run of ray blocks each
+    if (mnerf_tune().cv_grid > 0) cap = mnerf_tune().cv_grid;
+    if (wgs > cap) wgs = cap;
+#ifdef CVT_STATS
+    unsigned long long* dbg = nullptr;
+    if (const char* e = getenv("MNERF_CVDBG_PTR")) dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+    hipLaunchKernelGGL(cost_volume_tile_kernel, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, *scene, *rays,
+                       cond_stride, cond, dbg);
+#else
+    hipLaunchKernelGGL(cost_volume_tile_kernel, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream, *scene, *rays,
+                       cond_stride, cond);
+#endif
+    return mnerf_check_launch("mnerf_cost_volume");
+  }
   if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
     const int nslot = variant == 4 ? 32 : 16;
     const size_t lds = (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + ((sumG + 3) & ~3)) * sizeof(float);

@@ -102,7 +102,7 @@ struct TapRec {
                // row set; bit4: x0 odd; bit5: y0 odd
 };
 
-__device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {  // bilin_setup()'s arithmetic
+__device__ __forceinline__ TapRec tap_setup_xy(float u, float v, int h, int w, int& x0_out, int& y0_out) {  // bilin_setup()'s arithmetic
   float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
   float x = ((gx + 1.0f) * 0.5f) * (float)(w - 1);
   float y = ((gy + 1.0f) * 0.5f) * (float)(h - 1);
@@ -117,7 +117,13 @@ __device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {  /
   r.fx = x - x0f;
   r.fy = y - y0f;
   r.flags = (px & dx) | ((~px & dx) << 1) | ((py & dy) << 2) | ((~py & dy) << 3) | (px << 4) | (py << 5);
+  x0_out = x0;
+  y0_out = y0;
   return r;
+}
+__device__ __forceinline__ TapRec tap_setup(float u, float v, int h, int w) {
+  int x0, y0;
+  return tap_setup_xy(u, v, h, w, x0, y0);
 }
 
 #ifndef CVW_RELOAD_ANY
@@ -170,6 +176,28 @@ __device__ __forceinline__ void tap_load(v2f (&t)[CPL / 2], const float* __restr
 #endif
 }
 
+// Tile form (cost_volume_tile_kernel): the texels a 16-ray x SEG-sample tile touches in the two maps of a (pair, scale) are
+// staged in LDS once by the whole workgroup; a walk record then names a tap set's texel by an ENCODED index:
+//   enc >= 0 : byte offset of the staged texel in the workgroup's texel area.  A staged texel is stored as two 256-byte
+//              halves, [16 lanes][first 16 B of the lane's 32-byte channel run] then [16 lanes][second 16 B], so that the 16
+//              lanes of a slot read 256 contiguous bytes per ds_read_b128 (the global layout would be a 32-byte lane stride);
+//   enc <  0 : ~enc is the texel index in the global map (its LDS place was taken by another texel) - loaded as before.
+template <int CPL>
+__device__ __forceinline__ void tap_load_tile(v2f (&t)[CPL / 2], const float* __restrict__ map, const char* tex, int enc,
+                                              unsigned lane_bytes, unsigned lane_lds) {
+  static_assert(CPL == 8, "the staged texel layout is written for 16 lanes x 8 channels");
+  if (enc >= 0) {
+    const v4f a = *reinterpret_cast<const v4f*>(tex + (unsigned)enc + lane_lds);
+    const v4f b = *reinterpret_cast<const v4f*>(tex + (unsigned)enc + 256u + lane_lds);
+    t[0] = a.lo;
+    t[1] = a.hi;
+    t[2] = b.lo;
+    t[3] = b.hi;
+  } else {
+    tap_load<CPL>(t, map, ~enc, lane_bytes);
+  }
+}
+
 // Expanded walk record of one (sample, view) at the scale being walked: texel held by each parity set
 // {EE, EO, OE, OO} and that set's bilinear weight.  Everything in it is the same for the 16 lanes of a slot, so
 // it is evaluated ONCE per (pair, scale) walk by the lane whose index equals the sample's position in the
@@ -217,6 +245,16 @@ __device__ __forceinline__ void quad_update(PairQuad<CPL>& q, const float* __res
   if (i11 != q.idx[1][1]) { tap_load<CPL>(q.t[1][1], map, i11, lane_bytes); q.idx[1][1] = i11; }
 }
 
+template <int CPL>
+__device__ __forceinline__ void quad_update_tile(PairQuad<CPL>& q, const float* __restrict__ map, const char* tex, const float4 ix,
+                                                 unsigned lane_bytes, unsigned lane_lds) {
+  const int i00 = __float_as_int(ix.x), i01 = __float_as_int(ix.y), i10 = __float_as_int(ix.z), i11 = __float_as_int(ix.w);
+  if (i00 != q.idx[0][0]) { tap_load_tile<CPL>(q.t[0][0], map, tex, i00, lane_bytes, lane_lds); q.idx[0][0] = i00; }
+  if (i01 != q.idx[0][1]) { tap_load_tile<CPL>(q.t[0][1], map, tex, i01, lane_bytes, lane_lds); q.idx[0][1] = i01; }
+  if (i10 != q.idx[1][0]) { tap_load_tile<CPL>(q.t[1][0], map, tex, i10, lane_bytes, lane_lds); q.idx[1][0] = i10; }
+  if (i11 != q.idx[1][1]) { tap_load_tile<CPL>(q.t[1][1], map, tex, i11, lane_bytes, lane_lds); q.idx[1][1] = i11; }
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
   const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
@@ -239,19 +277,26 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
 }
 
 // one (pair, scale): walk the SEG samples of this slot's segment
-template <int CPL, int LPG, int SEG>
+template <int CPL, int LPG, int SEG, bool TILE = false>
 __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const float* __restrict__ m1,
                                           const float4* __restrict__ wrec /* [js][view a|b][idx|weights] */,
-                                          float* __restrict__ cs_group, int cs_stride, int sub, unsigned lane_bytes) {
+                                          float* __restrict__ cs_group, int cs_stride, int sub, unsigned lane_bytes,
+                                          const char* tex = nullptr /* TILE: the workgroup's staged texels */) {
   static_assert(SEG % LPG == 0, "segment length must be a multiple of the lanes per channel group");
   float k_dot = 0.0f, k_na = 1.0f, k_nb = 1.0f;  // the (sample, group) triple this lane will turn into a cosine
   PairQuad<CPL> qa, qb;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) qa.idx[i >> 1][i & 1] = qb.idx[i >> 1][i & 1] = -1;
+  for (int i = 0; i < 4; ++i) qa.idx[i >> 1][i & 1] = qb.idx[i >> 1][i & 1] = TILE ? (int)0x80000000 : -1;  // names no texel
+  const unsigned lane_lds = (unsigned)sub * 16u;
   for (int js = 0; js < SEG; ++js) {
     const float4 wa = wrec[js * 4 + 1], wb = wrec[js * 4 + 3];
-    quad_update<CPL>(qa, m0, wrec[js * 4 + 0], lane_bytes);
-    quad_update<CPL>(qb, m1, wrec[js * 4 + 2], lane_bytes);
+    if constexpr (TILE) {
+      quad_update_tile<CPL>(qa, m0, tex, wrec[js * 4 + 0], lane_bytes, lane_lds);
+      quad_update_tile<CPL>(qb, m1, tex, wrec[js * 4 + 2], lane_bytes, lane_lds);
+    } else {
+      quad_update<CPL>(qa, m0, wrec[js * 4 + 0], lane_bytes);
+      quad_update<CPL>(qb, m1, wrec[js * 4 + 2], lane_bytes);
+    }
     const v2f A00 = {wa.x, wa.x}, A01 = {wa.y, wa.y}, A10 = {wa.z, wa.z}, A11 = {wa.w, wa.w};
     const v2f B00 = {wb.x, wb.x}, B01 = {wb.y, wb.y}, B10 = {wb.z, wb.z}, B11 = {wb.w, wb.w};
     v2f dot2 = {0.f, 0.f}, na2 = {0.f, 0.f}, nb2 = {0.f, 0.f};
@@ -302,6 +347,88 @@ __device__ __forceinline__ void lean_walk(const float* __restrict__ m0, const fl
 }
 
 
+// Walk of the tile form WITHOUT the register tap cache, for a wave whose walk records all name staged texels (enc >= 0; the
+// kernel checks that per wave and walk, and takes lean_walk<.., TILE> otherwise): with the texels in LDS a step simply reads its
+// eight taps (16 ds_read_b128 per lane) - no compares, no divergent reloads, straight-line code - and the reads of step js+1
+// are issued before the arithmetic of step js, so the LDS round trip is hidden even at two waves per SIMD.
+// Arithmetic and its order are lean_walk's.
+template <int CPL>
+struct StepTaps {
+  v2f a[4][CPL / 2], b[4][CPL / 2];  // [EE, EO, OE, OO][channel pair] of map a / map b
+  float4 wa, wb;
+};
+
+template <int CPL>
+__device__ __forceinline__ void step_fetch(StepTaps<CPL>& t, const float4* __restrict__ wrec, int js, const char* tex,
+                                           unsigned lane_lds) {
+  const float4 ia = wrec[js * 4 + 0], ib = wrec[js * 4 + 2];
+  t.wa = wrec[js * 4 + 1];
+  t.wb = wrec[js * 4 + 3];
+  const unsigned ea[4] = {__float_as_uint(ia.x), __float_as_uint(ia.y), __float_as_uint(ia.z), __float_as_uint(ia.w)};
+  const unsigned eb[4] = {__float_as_uint(ib.x), __float_as_uint(ib.y), __float_as_uint(ib.z), __float_as_uint(ib.w)};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const v4f x = *reinterpret_cast<const v4f*>(tex + ea[k] + lane_lds);
+    const v4f y = *reinterpret_cast<const v4f*>(tex + ea[k] + 256u + lane_lds);
+    t.a[k][0] = x.lo, t.a[k][1] = x.hi, t.a[k][2] = y.lo, t.a[k][3] = y.hi;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const v4f x = *reinterpret_cast<const v4f*>(tex + eb[k] + lane_lds);
+    const v4f y = *reinterpret_cast<const v4f*>(tex + eb[k] + 256u + lane_lds);
+    t.b[k][0] = x.lo, t.b[k][1] = x.hi, t.b[k][2] = y.lo, t.b[k][3] = y.hi;
+  }
+}
+
+template <int CPL, int LPG, int SEG>
+__device__ __forceinline__ void tile_walk(const float* __restrict__ m0, const float* __restrict__ m1,
+                                          const float4* __restrict__ wrec, float* __restrict__ cs_group, int cs_stride, int sub,
+                                          unsigned lane_bytes, const char* tex) {
+  static_assert(SEG % LPG == 0, "segment length must be a multiple of the lanes per channel group");
+  float k_dot = 0.0f, k_na = 1.0f, k_nb = 1.0f;
+  const unsigned lane_lds = (unsigned)sub * 16u;
+  StepTaps<CPL> buf[2];
+  step_fetch<CPL>(buf[0], wrec, 0, tex, lane_lds);
+#pragma unroll
+  for (int js = 0; js < SEG; ++js) {
+    StepTaps<CPL>& t = buf[js & 1];
+    if (js + 1 < SEG) step_fetch<CPL>(buf[(js + 1) & 1], wrec, js + 1, tex, lane_lds);
+    const float4 wa = t.wa, wb = t.wb;
+    const v2f A00 = {wa.x, wa.x}, A01 = {wa.y, wa.y}, A10 = {wa.z, wa.z}, A11 = {wa.w, wa.w};
+    const v2f B00 = {wb.x, wb.x}, B01 = {wb.y, wb.y}, B10 = {wb.z, wb.z}, B11 = {wb.w, wb.w};
+    v2f dot2 = {0.f, 0.f}, na2 = {0.f, 0.f}, nb2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CPL / 2; ++k) {
+      v2f fa = pk_mul(t.a[0][k], A00);
+      fa = pk_fma(t.a[1][k], A01, fa);
+      fa = pk_fma(t.a[2][k], A10, fa);
+      fa = pk_fma(t.a[3][k], A11, fa);
+      v2f fb = pk_mul(t.b[0][k], B00);
+      fb = pk_fma(t.b[1][k], B01, fb);
+      fb = pk_fma(t.b[2][k], B10, fb);
+      fb = pk_fma(t.b[3][k], B11, fb);
+      dot2 = pk_fma(fa, fb, dot2);
+      na2 = pk_fma(fa, fa, na2);
+      nb2 = pk_fma(fb, fb, nb2);
+    }
+    const float dot = dpp_group_sum<LPG>(dot2.x + dot2.y);
+    const float na = dpp_group_sum<LPG>(na2.x + na2.y);
+    const float nb = dpp_group_sum<LPG>(nb2.x + nb2.y);
+    const int u = js & (LPG - 1);
+    if (LPG == 1 || (sub & (LPG - 1)) == u) {
+      k_dot = dot;
+      k_na = na;
+      k_nb = nb;
+    }
+    if (u == LPG - 1) {  // see lean_walk: every lane turns one (sample, group) triple into a cosine
+      const float da = fmaxf(sqrtf(k_na), 1e-8f), db = fmaxf(sqrtf(k_nb), 1e-8f);
+      const float c = k_dot / (da * db);
+      const int js_mine = js - (LPG - 1) + (sub & (LPG - 1));
+      __hip_atomic_fetch_add(cs_group + js_mine * cs_stride, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+}
+
 // LDS floats one slot needs for a segment of SEG samples: projections [js][view](u,v) | walk records
 // [js][view a|b][idx|weights] (float4) | cosine sums [js][cs_stride]
 __host__ __device__ inline int cv_slot_lds_floats(int seg, int n_views, int sum_groups) {
@@ -329,22 +456,17 @@ __device__ __forceinline__ void cv_store(float* p, float v) {
   *p = v;
 }
 
-template <int CPL, int SEG, bool NT = false>
-__device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
-                                             float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds,
-                                             float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub) {
+// pass 1 of a walk unit: projections (to uv_lds), colours, masks and the constant column of SEG samples of one ray
+template <int CPL, int SEG, bool NT>
+__device__ __forceinline__ void cv_pass1(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
+                                         float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds, int sub) {
   constexpr int LPS = FEAT_C / CPL;
   constexpr int SPL = SEG / LPS > 0 ? SEG / LPS : 1;  // pass-1 samples per lane
   const int V = sc.n_views;
   const int S = R.n_samples;
-  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
-  const int sumG = G0 + G1;
-  const int cs_stride = (sumG + 3) & ~3;
+  const int sumG = sc.n_group[0] + (sc.n_scales > 1 ? sc.n_group[1] : 0);
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
-  const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
-  const unsigned lane_bytes = (unsigned)sub * CPL * 4;
   const RayGeom g = make_ray(R, ray);
-
   // ---- pass 1: projections, tap records, colours, masks.  Lane `sub` takes samples sub, sub+LPS, ..
 #pragma unroll
   for (int half = 0; half < SPL; ++half) {
@@ -383,6 +505,41 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
       for (int c = dc + 1; c < cond_stride; ++c) cv_store<NT>(out + c, 0.0f);
     }
   }
+}
+
+// the averaged cosines of a unit: lane `sub` writes samples sub, sub+LPS, ..
+template <int CPL, int SEG, bool NT>
+__device__ __forceinline__ void cv_write_cosines(const mnerf_rays& R, bool ray_live, int j0, float* __restrict__ row0,
+                                                 int cond_stride, const float* __restrict__ cs_lds, int cs_stride, int sumG,
+                                                 float inv_pairs, int sub) {
+  constexpr int LPS = FEAT_C / CPL;
+  constexpr int SPL = SEG / LPS > 0 ? SEG / LPS : 1;
+  const int S = R.n_samples;
+#pragma unroll
+  for (int half = 0; half < SPL; ++half) {
+    const int js = sub + LPS * half;
+    if (js < SEG && ray_live && (j0 + js < S)) {
+      float* out = row0 + (size_t)js * cond_stride;
+#pragma clang loop vectorize(disable) interleave(disable)  // (a vectorised multiply is a packed-fp32 instruction)
+      for (int c = 0; c < sumG; ++c) cv_store<NT>(out + c, cs_lds[js * cs_stride + c] * inv_pairs);
+    }
+  }
+}
+
+template <int CPL, int SEG, bool NT = false>
+__device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
+                                             float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds,
+                                             float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub) {
+  constexpr int LPS = FEAT_C / CPL;
+  constexpr int SPL = SEG / LPS > 0 ? SEG / LPS : 1;  // pass-1 samples per lane
+  const int V = sc.n_views;
+  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
+  const int sumG = G0 + G1;
+  const int cs_stride = (sumG + 3) & ~3;
+  const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
+  const unsigned lane_bytes = (unsigned)sub * CPL * 4;
+
+  cv_pass1<CPL, SEG, NT>(sc, R, ray, ray_live, j0, row0, cond_stride, uv_lds, sub);
   for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
   // slot-local LDS hand-off: the lanes of a slot belong to one wave => wave-level ordering
   cvw_handoff();
@@ -432,15 +589,6 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
     }
   }
   cvw_handoff();
-  // ---- write the averaged cosines: lane `sub` writes samples sub, sub+LPS, ..
-#pragma unroll
-  for (int half = 0; half < SPL; ++half) {
-    const int js = sub + LPS * half;
-    if (js < SEG && ray_live && (j0 + js < S)) {
-      float* out = row0 + (size_t)js * cond_stride;
-#pragma clang loop vectorize(disable) interleave(disable)  // (a vectorised multiply is a packed-fp32 instruction)
-      for (int c = 0; c < sumG; ++c) cv_store<NT>(out + c, cs_lds[js * cs_stride + c] * inv_pairs);
-    }
-  }
+  cv_write_cosines<CPL, SEG, NT>(R, ray_live, j0, row0, cond_stride, cs_lds, cs_stride, sumG, inv_pairs, sub);
   __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds / wrec_lds are rewritten by the next unit
 }

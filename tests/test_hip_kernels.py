@@ -465,3 +465,21 @@ def test_render_chunk_is_graph_capturable(hip):
         for a, b in zip(out, eager):
             assert torch.equal(a, b)
     assert linf(out[0], g["rgb"][0, 512:512 + n]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_cost_volume_variants_match_goldens():
+    """The other cost-volume kernels behind MNERF_CV_VARIANT (0: one sample per slot, 4: 8-lane walk, 5: texel tiles staged in LDS;
+    3 is the default) against the same reference goldens.  The knob is read once when the library loads, hence a child process
+    per variant."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for variant in ("0", "4", "5"):
+        env = dict(os.environ, MNERF_CV_VARIANT=variant)
+        # (the tiles run the default walk's arithmetic in its order, so the bit-for-bit comparison with the one-launch form holds too)
+        select = "test_cost_volume_matches_reference" + (" or test_fused_render_chunk_equals_staged" if variant == "5" else "")
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_kernels.py"), "-q", "-x", "-m", "gpu", "-k", select],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, f"MNERF_CV_VARIANT={variant}:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
