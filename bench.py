@@ -189,7 +189,7 @@ def respawn_under_launcher(args):
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
-    if args.shard != "views":
+    if getattr(args, "shard", "views") != "views":
         cmd += ["--shard", args.shard]
     # HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver only supports dmabuf IPC; without it RCCL's buffer exchange
     # between the rank processes fails with `hipIpcGetMemHandle: invalid argument` (environment note of the GPU boxes;

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import torch
 
-from . import checkpoint, metrics, synthetic
+from . import checkpoint, datasets, metrics, synthetic
 from .edict import EasyDict as edict
 from .models import models_dict
 
@@ -60,16 +60,30 @@ class Coach:
 
     def load_dataset(self, splits=("test",), loaders=None):
         """``loaders``: optional list of iterables of batches (objects with get_name()); otherwise
-        every ``data_test`` entry is served by the synthetic generator at that entry's img_wh."""
+        every ``data_test`` entry whose ``root_dir`` exists is read from disk (datasets.py) and the others are served by the
+        synthetic generator at that entry's img_wh."""
         if loaders is not None:
             self.test_loaders = list(loaders)
             return
-        self.test_loaders = [SyntheticScenes(name, cfg, self.n_src_views)
-                             for name, cfg in self.opts.data_test.items() if cfg is not None]
+        self.test_loaders = []
+        for name, cfg in self.opts.data_test.items():
+            if cfg is None:
+                continue
+            root, kind = cfg.get("root_dir"), cfg.get("dataset_name", name)
+            if root and os.path.isdir(root) and kind in datasets.datas_dict:  # coach.py:52-69: the on-disk producer
+                ds = datasets.datas_dict[kind](root, "test", n_views=self.n_src_views, img_wh=cfg.get("img_wh"),
+                                               max_len=cfg.get("max_len", -1),
+                                               test_views_method=cfg.get("test_views_method", "nearest"))
+                loader = torch.utils.data.DataLoader(ds, shuffle=False, num_workers=cfg.get("num_workers", 0),
+                                                     batch_size=self.opts.batch_size, pin_memory=True)
+                loader.get_name = ds.get_name
+                self.test_loaders.append(loader)
+            else:
+                self.test_loaders.append(SyntheticScenes(name, cfg, self.n_src_views))
 
     @torch.no_grad()
     def test_model(self, save_images=False, **kwargs):
-        """coach.py:368-453, PSNR only -> {dataset: {image_id: psnr}}."""
+        """coach.py:368-453 -> {dataset: {image_id: psnr}}; the results file also lists SSIM (LPIPS needs weights we do not have)."""
         self.model.eval()
         out_root = os.path.join(self.opts.output_path, "test")
         os.makedirs(out_root, exist_ok=True)
@@ -77,6 +91,7 @@ class Coach:
         for loader in self.test_loaders:
             name = loader.get_name()
             report[name] = {}
+            ssims = []
             self.model.nerf_setbg_opaque = (name == "blender")  # coach.py:382-383
             for bi, batch in enumerate(loader):
                 var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
@@ -88,6 +103,9 @@ class Coach:
                 for i in range(b):
                     mask = None if gt_depth is None else (gt_depth[i].cpu().numpy() == 0)
                     report[name][f"{name}_{bi:03d}_{i}"] = metrics.psnr(pred[i], gt[i], mask)
+                    tools = metrics.EvalTools()
+                    tools.set_inputs(pred[i], gt[i], mask)
+                    ssims.append(tools.get_metrics(["SSIM"])["SSIM"])
                     if save_images:
                         from PIL import Image
                         vis = np.concatenate([pred[i], gt[i]], 1)
@@ -96,9 +114,9 @@ class Coach:
             self.model.nerf_setbg_opaque = False
             vals = list(report[name].values())
             with open(os.path.join(out_root, f"0results_{name}.txt"), "w") as f:
-                for k, v in report[name].items():
-                    f.write(f"{k}: PSNR {v:.4f}\n")
-                f.write(f"mean PSNR {np.mean(vals):.4f}\n")
+                for (k, v), sv in zip(report[name].items(), ssims):
+                    f.write(f"{k}: PSNR {v:.4f} SSIM {sv:.4f}\n")
+                f.write(f"mean PSNR {np.mean(vals):.4f} SSIM {np.mean(ssims):.4f}\n")
             print(f"[coach] {name}: mean PSNR {np.mean(vals):.2f} over {len(vals)} images")
         return report
 

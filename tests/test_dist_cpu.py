@@ -91,3 +91,5 @@ def test_bench_respawns_itself_under_the_launcher(monkeypatch):
     assert rc == 0 and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    bench.respawn_under_launcher(argparse.Namespace(gpus=2, steps=1, warmup=0, no_cpu_baseline=True, shard="rows"))
+    assert seen["cmd"][-3:] == ["--no-cpu-baseline", "--shard", "rows"]      # the strong-scaling mode reaches the ranks
