@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 4
+#define MNERF_ABI_VERSION 5
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
@@ -218,6 +218,58 @@ int mnerf_composite_backward(int32_t n_rays, int32_t n_samples, const float* rgb
  * The forward interpolation is recomputed from `scene` and `rays` (query_cond_info, matchnerf.py:209-293). */
 int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
                                const float* g_cond, float* g_feat0, float* g_feat1, void* stream);
+
+/* K3+K4 backward — gradients of the conditional MLP + ray transformer (CondNeRF.forward, cond_nerf.py:52-100;
+ * MultiHeadAttention.forward, ray_transformer.py:29-79; what `loss.backward()` does to them in coach.py:215-243).
+ * The parameters are given in torch's own layouts (Linear.weight [out,in], fp32), indexed by MNERF_DT_*; `g[k]` receives the
+ * gradient of `w[k]`, ACCUMULATED (the caller zero-fills or carries over), NULL = not wanted. */
+enum {
+  MNERF_DT_PTS_W0 = 0,   /* pts_linears.i.weight = 2 i, .bias = 2 i + 1, i = 0..5 */
+  MNERF_DT_BIAS_W = 12,  /* pts_bias (the FiLM multiplier) */
+  MNERF_DT_BIAS_B,
+  MNERF_DT_ALPHA_W,      /* alpha_linear.0 */
+  MNERF_DT_ALPHA_B,
+  MNERF_DT_WQ,           /* ray_attention.w_qs / w_ks / w_vs / fc (.weight, no bias) */
+  MNERF_DT_WK,
+  MNERF_DT_WV,
+  MNERF_DT_FC,
+  MNERF_DT_LN_W,         /* ray_attention.layer_norm */
+  MNERF_DT_LN_B,
+  MNERF_DT_OA0_W,        /* out_alpha_linear.0 */
+  MNERF_DT_OA0_B,
+  MNERF_DT_OA2_W,        /* out_alpha_linear.2 */
+  MNERF_DT_OA2_B,
+  MNERF_DT_FEAT_W,       /* feature_linear */
+  MNERF_DT_FEAT_B,
+  MNERF_DT_VIEWS_W,      /* views_linears.0 : [64, 128 + 3] */
+  MNERF_DT_VIEWS_B,
+  MNERF_DT_RGB_W,        /* rgb_linear */
+  MNERF_DT_RGB_B,
+  MNERF_DEC_TENSORS
+};
+typedef struct mnerf_decoder_train {
+  int32_t n_views;          /* source views: the last n_views of the cond_dim conditioning columns are the visibility masks */
+  int32_t cond_dim;         /* conditioning columns the FiLM Linear reads */
+  int32_t n_trunk;          /* opt.decoder.net_depth (6) */
+  int32_t net_width;        /* opt.decoder.net_width (128) */
+  int32_t skip_layer;       /* the trunk layer after which the encoding is concatenated again (opt.decoder.skip[0]); -1: none */
+  int32_t L_3D;             /* octaves of the positional encoding */
+  int32_t legacy_coord;     /* opt.nerf.legacy_coord: frequency 2^l and [l][xyz] order instead of pi 2^l and [xyz][sin|cos][l] */
+  int32_t raytrans_elu;     /* opt.decoder.raytrans_act == 'ELU' (else ReLU) */
+  int32_t raytrans_posenc;  /* add raytrans_table [S,16] to the alpha features */
+  int32_t density_maskfill;
+  const float* raytrans_table;
+  const float* w[MNERF_DEC_TENSORS];
+  float* g[MNERF_DEC_TENSORS];
+} mnerf_decoder_train;
+/* x_ndc [N,3] sample coordinates and dirs [n_rays,3] unit view directions in source view 0's frame (what mnerf_ray_samples and the
+ * host compute for the forward), cond [N, cond_stride] the rows mnerf_cost_volume wrote, g_rgb_s [N,3] / g_sigma [N] from
+ * mnerf_composite_backward (N = n_rays * n_samples, n_samples <= 256).  g_cond [N, cond_stride] (or NULL) receives the gradient
+ * of the first cond_dim columns of the rows (other columns untouched).  workspace: mnerf_decoder_backward_workspace_bytes(). */
+int64_t mnerf_decoder_backward_workspace_bytes(int32_t n_rays, int32_t n_samples);
+int mnerf_decoder_backward(const mnerf_decoder_train* dec, int32_t n_rays, int32_t n_samples, const float* x_ndc,
+                           const float* dirs, const float* cond, int32_t cond_stride, const float* g_rgb_s,
+                           const float* g_sigma, float* g_cond, void* workspace, void* stream);
 
 /* K6 — GMFlow single-head (shifted-)window attention, flash style (no score matrix).
  * Replaces single_head_split_window_attention / single_head_full_attention and the

@@ -3,20 +3,19 @@
 The reference trains by back-propagating through its eager op chain
 (/root/reference/coach.py:215-243).  Here the FORWARD values of ``mode='train'`` come from
 the same HIP kernels as inference (K1-K6); the BACKWARD uses hand-written HIP
-kernels for compositing and the cost volume and, where a backward kernel does not exist yet (window attention,
-the conditional MLP + ray transformer), re-evaluates that op with differentiable PyTorch-ROCm ops on the GPU
-(activation-checkpoint style) and back-propagates through the re-evaluation:
+kernels for the whole ray chunk (compositing, conditional MLP + ray transformer, cost volume) and, where a backward
+kernel does not exist yet (window attention, the encoder), re-evaluates that op with differentiable PyTorch-ROCm ops on the
+GPU (activation-checkpoint style) and back-propagates through the re-evaluation:
 
 * ``window_attention``  — K6 forward, torch roll/split/softmax re-evaluation for grad(q,k,v)
 * ``render_ray_chunk``  — K1..K5 forward in HIP; backward = K5 backward kernel (mnerf_composite_backward) ->
-  torch re-evaluation of the conditional MLP + ray transformer (K3+K4) from the saved conditioning rows, with
-  sample coordinates from mnerf_ray_samples (the forward's bits) -> K1+K2 backward kernel
+  K3+K4 backward (mnerf_decoder_backward: forward re-evaluated from the saved conditioning rows with sample coordinates
+  from mnerf_ray_samples — the forward's bits —, exact-fp32 MFMA products) -> K1+K2 backward kernel
   (mnerf_cost_volume_backward, atomic scatter-add into the feature-map gradients)
 
 This module is only entered when gradients are required; inference never touches it, and it
 is not a fallback: the forward pass still fails loudly without ``libmnerf_hip.so``.
-Training-time ray counts are tiny (``rand_rays_train`` = 1024), so the re-evaluation cost is
-irrelevant next to the encoder.
+Training-time ray counts are small (``rand_rays_train`` = 1024).
 """
 import math
 
@@ -98,49 +97,6 @@ def ray_directions_torch(kinv, c2w, ray_idx, width, legacy):
     return (torch.cat([cam, torch.ones_like(cam[:, :1])], -1) @ c2w.t()) - center
 
 
-def decoder_torch(opt, dec, x, dirs, cond, n_views):
-    """Differentiable CondNeRF.forward (cond_nerf.py:52-100, ray_transformer.py) with torch ops.
-    x [R,S,3] coordinates w.r.t. source view 0, dirs [R,3] unit directions in that view's frame,
-    cond [R,S,Dc] = cat(feat_info, color_info, mask_info) -> rgb_s [R,S,3], sigma [R,S]."""
-    dev = x.device
-    n_r, s_n, _ = x.shape
-    legacy = bool(opt.nerf.legacy_coord)
-    mask = cond[..., -n_views:]
-    L = dec.L_3D
-    freq = 2.0 ** torch.arange(L, device=dev, dtype=torch.float32)
-    if legacy:
-        spec = (x[..., None, :] * freq[:, None]).reshape(n_r, s_n, -1)
-        enc = torch.cat([x, spec.sin(), spec.cos()], -1)
-    else:
-        spec = x[..., None] * (freq * math.pi)
-        enc = torch.cat([x, torch.stack([spec.sin(), spec.cos()], -2).reshape(n_r, s_n, -1)], -1)
-    film = dec.pts_bias(cond)
-    hcur = enc
-    for i, lin in enumerate(dec.pts_linears):
-        hcur = F.relu(lin(hcur) * film)
-        if i in list(opt.decoder.skip):
-            hcur = torch.cat([enc, hcur], -1)
-    act = F.elu if opt.decoder.raytrans_act == "ELU" else F.relu
-    a = act(dec.alpha_linear[0](hcur))
-    if opt.decoder.raytrans_posenc:
-        from .cond_nerf import raytrans_table
-        a = a + torch.from_numpy(raytrans_table(s_n)).to(dev)[None]
-    ra = dec.ray_attention
-    q = ra.w_qs(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
-    k = ra.w_ks(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
-    v_ = ra.w_vs(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
-    n_valid = mask.sum(-1)
-    scores = (q / 2.0) @ k.transpose(-1, -2)
-    scores = torch.where((n_valid > 1)[:, None, :, None], scores, torch.full_like(scores, -1e9))
-    o = (torch.softmax(scores, -1) @ v_).permute(0, 2, 1, 3).reshape(n_r, s_n, 16)
-    o = ra.layer_norm(ra.fc(o) + a)
-    sigma = F.relu(dec.out_alpha_linear[2](act(dec.out_alpha_linear[0](o))))[..., 0]
-    if opt.decoder.density_maskfill:
-        sigma = torch.where(n_valid < 1, torch.zeros_like(sigma), sigma)
-    hv = F.relu(dec.views_linears[0](torch.cat([dec.feature_linear(hcur), dirs[:, None].expand(-1, s_n, -1)], -1)))
-    return torch.sigmoid(dec.rgb_linear(hv)), sigma
-
-
 class RayChunkLaunch:
     """Everything one differentiable ray chunk of one batch element needs to (re)build its C-ABI argument structs:
     the forward launches and the backward kernels must see the same scene, rays and decoder."""
@@ -155,9 +111,9 @@ class RayChunkLaunch:
 
 class _RayChunkFn(torch.autograd.Function):
     """forward : mnerf_cost_volume -> mnerf_decoder_chunk (HIP; per-sample colours / densities kept for the backward)
-    backward: mnerf_composite_backward (HIP) -> torch re-evaluation of the conditional MLP + ray transformer from the
-              saved conditioning rows (gradients of the decoder parameters and of the rows) ->
-              mnerf_cost_volume_backward (HIP) scatters the rows' gradient into the feature maps."""
+    backward: mnerf_composite_backward -> mnerf_decoder_backward (the conditional MLP + ray transformer re-evaluated from the
+              saved conditioning rows and differentiated: gradients of the decoder parameters and of the rows) ->
+              mnerf_cost_volume_backward (scatters the rows' gradient into the feature maps).  All HIP."""
 
     @staticmethod
     def forward(ctx, launch, n_feat, *tensors):
@@ -189,20 +145,21 @@ class _RayChunkFn(torch.autograd.Function):
             rgb_s, sigma, depth_s, g_rgb.contiguous().float(), g_depth.reshape(r).contiguous().float(),
             g_op.reshape(r).contiguous().float(), None if wo else ray.norm(dim=-1).contiguous(),
             wo_render_interval=wo, setbg_opaque=launch.setbg_opaque)
-        dc = dec.cond_dim
-        cond_t = cond.reshape(r, s, dec.cond_stride)[..., :dc].detach().clone().requires_grad_(True)
-        dirs = F.normalize(ray, dim=-1) @ torch.as_tensor(launch.view0_extr, device=ray.device)[:, :3].t()
-        params = [p for p in dec_m.parameters() if p.requires_grad]
-        with torch.enable_grad():
-            rgb_s2, sigma2 = decoder_torch(opt, dec_m, x_ndc.detach(), dirs.detach(), cond_t, launch.n_views)
-        grads = torch.autograd.grad([rgb_s2, sigma2], [cond_t] + params, [g_rgb_s, g_sigma], allow_unused=True)
+        dirs = (F.normalize(ray, dim=-1) @ torch.as_tensor(launch.view0_extr, device=ray.device)[:, :3].t()).contiguous()
+        named = dict(dec_m.named_parameters())
+        table = None
+        if opt.decoder.raytrans_posenc:
+            from .cond_nerf import raytrans_table
+            table = torch.from_numpy(raytrans_table(s))
+        g_cond, g_named = hip.decoder_backward(
+            opt, {k: named[k].detach() for k in hip.DEC_TRAIN_TENSORS}, launch.n_views, x_ndc.reshape(r * s, 3).contiguous(), dirs,
+            cond, dec.cond_stride, g_rgb_s.contiguous(), g_sigma.contiguous(), want_g_cond=any(ctx.needs_input_grad[2:2 + n_feat]),
+            raytrans_table=table, grads={k: None for k in hip.DEC_TRAIN_TENSORS if not named[k].requires_grad})
         g_feats = [None] * n_feat
-        if any(ctx.needs_input_grad[2:2 + n_feat]):
-            g_cond = torch.zeros(r * s, dec.cond_stride, device=cond.device)
-            g_cond[:, :dc] = grads[0].reshape(r * s, dc)
+        if g_cond is not None:
             g_feats = hip.cost_volume_backward(sc, rays, dec.cond_stride, g_cond, [torch.zeros_like(f) for f in feats])
-        it = iter(grads[1:])
-        g_params = [next(it) if p.requires_grad else None for p in dec_m.parameters()]
+        by_param = {id(named[k]): g_named.get(k) for k in hip.DEC_TRAIN_TENSORS}
+        g_params = [by_param.get(id(p)) for p in dec_m.parameters()]
         return (None, None, *g_feats, *g_params)
 
 

@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 4
+MNERF_ABI_VERSION = 5
 MNERF_MAX_VIEWS = 16
 MNERF_COND_STRIDE_MAX, MNERF_COND_STRIDE_MAX_F32 = 96, 64
 SMALL_FIXED = 32  # floats of the `small` parameter block (LayerNorm weight|bias) before the ray-posenc table
@@ -23,7 +23,7 @@ _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
-           "mnerf_composite_backward", "mnerf_cost_volume_backward",
+           "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
@@ -56,6 +56,22 @@ class Decoder(C.Structure):
                 ("L_3D", C.c_int32), ("raytrans_posenc", C.c_int32), ("raytrans_elu", C.c_int32),
                 ("density_maskfill", C.c_int32), ("wo_render_interval", C.c_int32),
                 ("setbg_opaque", C.c_int32), ("wstream_format", C.c_int32)]
+
+
+# parameter tensors of the decoder in mnerf_decoder_train's order (include/mnerf.h, MNERF_DT_*): names relative to the CondNeRF module
+DEC_TRAIN_TENSORS = tuple(f"pts_linears.{i}.{k}" for i in range(6) for k in ("weight", "bias")) + (
+    "pts_bias.weight", "pts_bias.bias", "alpha_linear.0.weight", "alpha_linear.0.bias", "ray_attention.w_qs.weight",
+    "ray_attention.w_ks.weight", "ray_attention.w_vs.weight", "ray_attention.fc.weight", "ray_attention.layer_norm.weight",
+    "ray_attention.layer_norm.bias", "out_alpha_linear.0.weight", "out_alpha_linear.0.bias", "out_alpha_linear.2.weight",
+    "out_alpha_linear.2.bias", "feature_linear.weight", "feature_linear.bias", "views_linears.0.weight", "views_linears.0.bias",
+    "rgb_linear.weight", "rgb_linear.bias")
+
+
+class DecoderTrain(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("cond_dim", C.c_int32), ("n_trunk", C.c_int32), ("net_width", C.c_int32),
+                ("skip_layer", C.c_int32), ("L_3D", C.c_int32), ("legacy_coord", C.c_int32), ("raytrans_elu", C.c_int32),
+                ("raytrans_posenc", C.c_int32), ("density_maskfill", C.c_int32), ("raytrans_table", C.c_void_p),
+                ("w", C.c_void_p * len(DEC_TRAIN_TENSORS)), ("g", C.c_void_p * len(DEC_TRAIN_TENSORS))]
 
 
 class EncoderLayer(C.Structure):
@@ -115,6 +131,10 @@ def load():
     lib.mnerf_cost_volume_backward.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, fp, fp, vp]
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
+    lib.mnerf_decoder_backward_workspace_bytes.restype = i64
+    lib.mnerf_decoder_backward_workspace_bytes.argtypes = [i32, i32]
+    lib.mnerf_decoder_backward.restype = C.c_int
+    lib.mnerf_decoder_backward.argtypes = [C.POINTER(DecoderTrain), i32, i32, fp, fp, fp, i32, fp, fp, fp, vp, vp]
     lib.mnerf_decoder_wstream_floats.restype = i64
     lib.mnerf_decoder_wstream_floats.argtypes = [i32, i32, i32, i32]
     lib.mnerf_decoder_chunk.restype = C.c_int
@@ -162,7 +182,7 @@ def load():
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
-    for which, st in enumerate((View, Rays, Scene, Decoder, EncoderLayer, ConvLayer)):
+    for which, st in enumerate((View, Rays, Scene, Decoder, EncoderLayer, ConvLayer, DecoderTrain)):
         if lib.mnerf_struct_size(which) != C.sizeof(st):
             raise MnerfError(f"struct {st.__name__}: library says {lib.mnerf_struct_size(which)} bytes, "
                              f"ctypes mirror has {C.sizeof(st)}")
@@ -309,6 +329,56 @@ def cost_volume_backward(scene, rays, cond_stride, g_cond, g_feats, stream=None)
                                              _ptr(g_feats[0]), _ptr(g_feats[1]) if len(g_feats) > 1 else None, st),
               "mnerf_cost_volume_backward")
     return g_feats
+
+
+def decoder_backward(opt, params, n_views, x_ndc, dirs, cond, cond_stride, g_rgb_s, g_sigma, want_g_cond=True, raytrans_table=None,
+                     grads=None, stream=None):
+    """K3+K4 backward (cond_nerf.py:52-100 and ray_transformer.py:29-79 under autograd): ``params`` maps DEC_TRAIN_TENSORS names to
+    fp32 CUDA tensors in torch's layouts; returns (g_cond [N, cond_stride] or None, {name: gradient}).  ``grads`` may hold
+    tensors to accumulate into (missing names get fresh zero tensors; a name mapped to None is skipped)."""
+    import torch
+    lib = load()
+    r, s = g_sigma.shape
+    n = r * s
+    dev = g_sigma.device
+    for t, nm in ((x_ndc, "x_ndc"), (dirs, "dirs"), (cond, "cond"), (g_rgb_s, "g_rgb_s"), (g_sigma, "g_sigma")):
+        _f32c(t, nm)
+    d = DecoderTrain()
+    dc = sum(opt.encoder.cos_n_group) + 4 * n_views
+    skip = list(opt.decoder.skip)
+    if len(skip) > 1:
+        raise NotImplementedError("decoder_backward: one skip connection (opt.decoder.skip has %d)" % len(skip))
+    d.n_views, d.cond_dim, d.n_trunk, d.net_width = n_views, dc, int(opt.decoder.net_depth), int(opt.decoder.net_width)
+    d.skip_layer = int(skip[0]) if skip else -1
+    d.L_3D = int(opt.decoder.posenc.L_3D) if opt.decoder.posenc else 0
+    d.legacy_coord = int(bool(opt.nerf.legacy_coord))
+    d.raytrans_elu = int(opt.decoder.raytrans_act == "ELU")
+    d.raytrans_posenc = int(bool(opt.decoder.raytrans_posenc))
+    d.density_maskfill = int(bool(opt.decoder.density_maskfill))
+    keep = []
+    if d.raytrans_posenc:
+        tab = raytrans_table.to(dev).float().contiguous()
+        keep.append(tab)
+        d.raytrans_table = _ptr(tab)
+    out = {}
+    for k, name in enumerate(DEC_TRAIN_TENSORS):
+        w = _f32c(params[name], name)
+        keep.append(w)
+        d.w[k] = _ptr(w)
+        if grads is not None and name in grads:
+            gk = grads[name]
+        else:
+            gk = torch.zeros_like(w)
+        if gk is not None:
+            _f32c(gk, "grad " + name)
+            out[name] = gk
+        d.g[k] = _ptr(gk)
+    g_cond = torch.zeros(n, cond_stride, device=dev) if want_g_cond else None
+    ws = torch.empty(lib.mnerf_decoder_backward_workspace_bytes(r, s) // 4, device=dev)
+    with _on(dev, stream) as st:
+        check(lib.mnerf_decoder_backward(C.byref(d), r, s, _ptr(x_ndc), _ptr(dirs), _ptr(cond), int(cond_stride), _ptr(g_rgb_s),
+                                         _ptr(g_sigma), _ptr(g_cond), _ptr(ws), st), "mnerf_decoder_backward")
+    return g_cond, out
 
 
 def cost_volume(scene, rays, cond_stride, out=None, device=None, stream=None):

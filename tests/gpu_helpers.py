@@ -1,6 +1,9 @@
 """Helpers for the -m gpu parity tests: build C-ABI argument structs from golden cases."""
+import math
+
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from matchnerf_amd import camera, cond_nerf as CN, hip
 from oracle import matchnerf_oracle as O
@@ -76,3 +79,47 @@ def cond_with_stride(cond, stride):
     out[:, :dc] = cond
     out[:, dc] = 1.0
     return out
+
+
+def decoder_torch(opt, dec, x, dirs, cond, n_views):
+    """Plain torch reference of CondNeRF.forward (cond_nerf.py:52-100, ray_transformer.py), differentiable: what
+    mnerf_decoder_backward is compared with.
+    x [R,S,3] coordinates w.r.t. source view 0, dirs [R,3] unit directions in that view's frame,
+    cond [R,S,Dc] = cat(feat_info, color_info, mask_info) -> rgb_s [R,S,3], sigma [R,S]."""
+    dev = x.device
+    n_r, s_n, _ = x.shape
+    legacy = bool(opt.nerf.legacy_coord)
+    mask = cond[..., -n_views:]
+    L = dec.L_3D
+    freq = 2.0 ** torch.arange(L, device=dev, dtype=x.dtype)
+    if legacy:
+        spec = (x[..., None, :] * freq[:, None]).reshape(n_r, s_n, -1)
+        enc = torch.cat([x, spec.sin(), spec.cos()], -1)
+    else:
+        spec = x[..., None] * (freq * math.pi)
+        enc = torch.cat([x, torch.stack([spec.sin(), spec.cos()], -2).reshape(n_r, s_n, -1)], -1)
+    film = dec.pts_bias(cond)
+    hcur = enc
+    for i, lin in enumerate(dec.pts_linears):
+        hcur = F.relu(lin(hcur) * film)
+        if i in list(opt.decoder.skip):
+            hcur = torch.cat([enc, hcur], -1)
+    act = F.elu if opt.decoder.raytrans_act == "ELU" else F.relu
+    a = act(dec.alpha_linear[0](hcur))
+    if opt.decoder.raytrans_posenc:
+        from matchnerf_amd.cond_nerf import raytrans_table
+        a = a + torch.from_numpy(raytrans_table(s_n)).to(dev, x.dtype)[None]
+    ra = dec.ray_attention
+    q = ra.w_qs(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
+    k = ra.w_ks(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
+    v_ = ra.w_vs(a).reshape(n_r, s_n, 4, 4).permute(0, 2, 1, 3)
+    n_valid = mask.sum(-1)
+    scores = (q / 2.0) @ k.transpose(-1, -2)
+    scores = torch.where((n_valid > 1)[:, None, :, None], scores, torch.full_like(scores, -1e9))
+    o = (torch.softmax(scores, -1) @ v_).permute(0, 2, 1, 3).reshape(n_r, s_n, 16)
+    o = ra.layer_norm(ra.fc(o) + a)
+    sigma = F.relu(dec.out_alpha_linear[2](act(dec.out_alpha_linear[0](o))))[..., 0]
+    if opt.decoder.density_maskfill:
+        sigma = torch.where(n_valid < 1, torch.zeros_like(sigma), sigma)
+    hv = F.relu(dec.views_linears[0](torch.cat([dec.feature_linear(hcur), dirs[:, None].expand(-1, s_n, -1)], -1)))
+    return torch.sigmoid(dec.rgb_linear(hv)), sigma
