@@ -178,6 +178,65 @@ def secondary_workload(device, name, n_views, n_samples, height, width, bg, **sc
             "decoder_ms": _per_frame(k, "decoder", 2), "fused_ray_chunk_ms": _per_frame(k, "render_fused", 2), "finite": ok}
 
 
+def train_step_workload(device):
+    """A `Coach.train_iteration`-shaped step (coach.py:215-243) at BASELINE config[1]'s geometry: mode='train' forward on
+    rand_rays_train = 1024 random rays of the 512x640 target, an L2 loss, backward through the HIP ray chunk
+    (mnerf_composite_backward -> mnerf_decoder_backward -> mnerf_cost_volume_backward) and the encoder (torch autograd over the
+    ROCm libraries), no optimizer step.  Outside the timed region; device events around the decoder's backward."""
+    import torch
+    from matchnerf_amd import hip
+    opt, model, _ = build_model(device)
+    model.train()
+    opt.nerf.rand_rays_train = 1024
+    opt.nerf.sample_stratified = True
+    _, batch = make_batch(device, 0)
+    params = [p for p in model.parameters() if p.requires_grad]
+    spans = []
+    inner = hip.decoder_backward
+
+    def timed_backward(*a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = inner(*a, **kw)
+        e1.record()
+        spans.append((e0, e1))
+        return r
+
+    def iteration():
+        for p in params:
+            p.grad = None
+        out = model(batch, mode="train")
+        gt = batch.images[:, -1].reshape(1, 3, -1).permute(0, 2, 1)[:, out.ray_idx]
+        loss = ((out.rgb - gt) ** 2).mean()
+        loss.backward()
+        return loss
+
+    hip.decoder_backward = timed_backward
+    try:
+        torch.manual_seed(0)
+        for _ in range(2):
+            iteration()  # warm-up: MIOpen solver search, weight packing
+        spans.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_it = 3
+        for _ in range(n_it):
+            loss = iteration()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n_it * 1e3
+    finally:
+        hip.decoder_backward = inner
+    dec_ms = sum(a.elapsed_time(b) for a, b in spans) / max(len(spans), 1)
+    grads_ok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
+    del model, batch
+    torch.cuda.empty_cache()
+    return {"workload": "train_iteration-shaped step: 1024 random rays x 64 stratified samples of a 512x640 target, 3 source views, "
+                        "forward + L2 loss + backward of encoder and decoder, no optimizer step",
+            "ms_per_iteration": round(ms, 3), "decoder_backward_ms": round(dec_ms, 3),
+            "decoder_backward": "mnerf_decoder_backward (HIP: exact-fp32 MFMA GEMMs + per-ray attention / LayerNorm kernel)",
+            "loss": float(loss.detach()), "all_gradients_finite": grads_ok}
+
+
 def respawn_under_launcher(args):
     """``python bench.py --gpus N`` without a launcher: start N ranks of this script with torch.distributed.run."""
     s = socket.socket()
@@ -348,6 +407,7 @@ def main():
         secondary.append(secondary_workload(device, "BASELINE config[4]: 10 source views 512x640, 64 samples/ray "
                                             "(45 view pairs, 1.18 GB of feature maps), full frame incl. encoder",
                                             10, 64, 512, 640, False, seed=32))
+        secondary.append(train_step_workload(device))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
