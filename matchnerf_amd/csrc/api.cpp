@@ -46,6 +46,7 @@ static mnerf_tuning read_tuning() {
   t.decoder_stagger = env_int("MNERF_DECODER_STAGGER", 16);     // ~130k cycles ~ half a tile
   t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 5 = texel tiles in LDS (slower, kept: cost_volume.hip); 0 = plain
+  t.cv_uvpair = env_int("MNERF_CV_UVPAIR", -1);
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
   t.wa_xcd = env_int("MNERF_WA_XCD", 1);          // query blocks of a window share an XCD (its L2 holds the K / V images)

@@ -207,14 +207,14 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
 
 // ============================================================================ segment walk (stand-alone kernel)
 // The walk itself lives in cv_walk.hpp (shared with the fused ray-chunk kernel); this kernel maps slots to rays.
-template <int CPL>
+template <int CPL, bool UVPAIR = false>
 __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_lean_kernel(mnerf_scene sc, mnerf_rays R,
                                                                                    int cond_stride,
                                                                                    float* __restrict__ cond) {
   constexpr int LPS = FEAT_C / CPL;     // lanes per sample slot (8 or 16)
   constexpr int NSLOT = 256 / LPS;      // ray slots per workgroup (32 or 16)
   extern __shared__ __attribute__((aligned(16))) float cvw_smem[];
-  const int V = sc.n_views;
+  const int V = UVPAIR ? 2 : sc.n_views;  // views per sample kept in the slot's projection scratch
   const int sub = threadIdx.x % LPS;
   const int slot = threadIdx.x / LPS;                               // NSLOT adjacent rays
   const int sumG = sc.n_group[0] + (sc.n_scales > 1 ? sc.n_group[1] : 0);
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
     if (!ray_live) ray_ll = R.n_rays - 1;
     const int ray = (int)ray_ll;
     const int jrow = j0 < S ? j0 : S - 1;
-    cv_walk_unit<CPL, CVW_SEG, true>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
-                               uv_lds, wrec_lds, cs_lds, sub);
+    cv_walk_unit<CPL, CVW_SEG, true, UVPAIR>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
+                                       uv_lds, wrec_lds, cs_lds, sub);
   }
 }
 
@@ -540,16 +540,25 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   }
   if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
     const int nslot = variant == 4 ? 32 : 16;
-    const size_t lds = (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + ((sumG + 3) & ~3)) * sizeof(float);
+    const int cs_pad = (sumG + 3) & ~3;
+    // A workgroup's LDS is NSLOT x SEG x (2 V + 16 + cs) floats: 38 KiB at 3 views (four workgroups per CU, what 128 VGPRs
+    // allow), 52 KiB at 10 views (three).  From the view count at which the fourth workgroup no longer fits, the 16-lane form
+    // keeps only the current pair's projections (UVPAIR, cv_walk.hpp).
+    bool uvpair = variant == 3 && (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + cs_pad) * sizeof(float) > 40 * 1024;
+    if (variant == 3 && mnerf_tune().cv_uvpair >= 0) uvpair = mnerf_tune().cv_uvpair != 0;
+    const size_t lds = (size_t)nslot * CVW_SEG * ((uvpair ? 2 : scene->n_views) * 2 + 16 + cs_pad) * sizeof(float);
     MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
     // the LDS attribute is per device and only ever raised: largest request seen per (variant, device)
-    static std::atomic<int> lean_lds_set[2][64];
+    static std::atomic<int> lean_lds_set[3][64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::atomic<int>& seen = lean_lds_set[variant - 3][dev & 63];
+    const int which = variant == 4 ? 1 : (uvpair ? 2 : 0);
+    std::atomic<int>& seen = lean_lds_set[which][dev & 63];
     if ((int)lds > seen.load(std::memory_order_relaxed)) {
-      if (variant == 4)
+      if (which == 1)
         (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      else if (which == 2)
+        (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       else
         (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       seen.store((int)lds, std::memory_order_relaxed);
@@ -558,8 +567,11 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
     int cap = variant == 4 ? 2048 : 4096;
     if (mnerf_tune().cv_grid > 0) cap = mnerf_tune().cv_grid;
     if (wgs > cap) wgs = cap;
-    if (variant == 4)
+    if (which == 1)
       hipLaunchKernelGGL(cost_volume_lean_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+                         *scene, *rays, cond_stride, cond);
+    else if (which == 2)
+      hipLaunchKernelGGL((cost_volume_lean_kernel<8, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                          *scene, *rays, cond_stride, cond);
     else
       hipLaunchKernelGGL(cost_volume_lean_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,

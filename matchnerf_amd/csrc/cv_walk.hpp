@@ -481,8 +481,10 @@ __device__ __forceinline__ void cv_pass1(const mnerf_scene& sc, const mnerf_rays
     for (int v = 0; v < V; ++v) {
       float u, w_, z;
       project(sc.views[v], px, py, pz, wm1, hm1, u, w_, z);
-      uv_lds[(js * V + v) * 2 + 0] = u;
-      uv_lds[(js * V + v) * 2 + 1] = w_;
+      if (uv_lds) {
+        uv_lds[(js * V + v) * 2 + 0] = u;
+        uv_lds[(js * V + v) * 2 + 1] = w_;
+      }
       const Bilin b = bilin_setup(u, w_, R.height, R.width);
       const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * R.height * R.width;
       float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
@@ -526,20 +528,24 @@ __device__ __forceinline__ void cv_write_cosines(const mnerf_rays& R, bool ray_l
   }
 }
 
-template <int CPL, int SEG, bool NT = false>
+// UVPAIR: the projections of a segment are not kept for all V views ([js][V] (u,v) in uv_lds) but re-evaluated per view pair
+// for its two views ([js][2]): 2 P instead of V projections per sample (+1 % of a unit's instructions at 10 views) for
+// 2 V - 4 fewer LDS floats per sample — at 10 views that is what lets a fourth workgroup share the CU (cost_volume.hip).
+template <int CPL, int SEG, bool NT = false, bool UVPAIR = false>
 __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
                                              float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds,
                                              float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub) {
   constexpr int LPS = FEAT_C / CPL;
   constexpr int SPL = SEG / LPS > 0 ? SEG / LPS : 1;  // pass-1 samples per lane
   const int V = sc.n_views;
+  const int UVS = UVPAIR ? 2 : V;  // views per sample in uv_lds
   const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
   const int sumG = G0 + G1;
   const int cs_stride = (sumG + 3) & ~3;
   const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
   const unsigned lane_bytes = (unsigned)sub * CPL * 4;
 
-  cv_pass1<CPL, SEG, NT>(sc, R, ray, ray_live, j0, row0, cond_stride, uv_lds, sub);
+  cv_pass1<CPL, SEG, NT>(sc, R, ray, ray_live, j0, row0, cond_stride, UVPAIR ? nullptr : uv_lds, sub);
   for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
   // slot-local LDS hand-off: the lanes of a slot belong to one wave => wave-level ordering
   cvw_handoff();
@@ -548,6 +554,26 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
   int p = 0;
   for (int a = 0; a < V - 1; ++a) {
     for (int b = a + 1; b < V; ++b, ++p) {
+      if constexpr (UVPAIR) {  // this pair's two projections of every sample of the segment (cv_pass1's arithmetic)
+        const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
+        const RayGeom g = make_ray(R, ray);
+        cvw_handoff();  // the previous pair's records have been expanded
+#pragma unroll
+        for (int half = 0; half < SPL; ++half) {
+          const int js = sub + LPS * half;
+          if (js >= SEG) break;
+          const float d = sample_depth(R, ray, min(j0 + js, R.n_samples - 1));
+          float px, py, pz;
+          ray_point(g, d, px, py, pz);
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            float u, w_, z;
+            project(sc.views[side ? b : a], px, py, pz, wm1, hm1, u, w_, z);
+            uv_lds[(js * 2 + side) * 2 + 0] = u;
+            uv_lds[(js * 2 + side) * 2 + 1] = w_;
+          }
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (s >= sc.n_scales) break;
@@ -567,8 +593,8 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
           if (js >= SEG) break;
 #pragma unroll
           for (int side = 0; side < 2; ++side) {
-            const int vw = side ? b : a;
-            const TapRec t = tap_setup(uv_lds[(js * V + vw) * 2], uv_lds[(js * V + vw) * 2 + 1], fh, fw);
+            const int vw = UVPAIR ? side : (side ? b : a);
+            const TapRec t = tap_setup(uv_lds[(js * UVS + vw) * 2], uv_lds[(js * UVS + vw) * 2 + 1], fh, fw);
             float4 ri, rw;
             tap_expand(t, fw, ri, rw);
             wrec_lds[(js * 2 + side) * 2] = ri;

@@ -476,10 +476,12 @@ def test_cost_volume_variants_match_goldens():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    for variant in ("0", "4", "5"):
-        env = dict(os.environ, MNERF_CV_VARIANT=variant)
+    for variant in ("0", "4", "5", "3+uvpair"):
+        env = dict(os.environ, MNERF_CV_VARIANT=variant[0])
+        if variant.endswith("uvpair"):  # the default walk with the projection scratch it takes from 6 views on
+            env["MNERF_CV_UVPAIR"] = "1"
         # (the tiles run the default walk's arithmetic in its order, so the bit-for-bit comparison with the one-launch form holds too)
-        select = "test_cost_volume_matches_reference" + (" or test_fused_render_chunk_equals_staged" if variant == "5" else "")
+        select = "test_cost_volume_matches_reference" + (" or test_fused_render_chunk_equals_staged" if variant[0] in "53" else "")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_kernels.py"), "-q", "-x", "-m", "gpu", "-k", select],
                            env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, f"MNERF_CV_VARIANT={variant}:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
