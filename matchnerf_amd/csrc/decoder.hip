@@ -2090,7 +2090,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       if (next_rows) {
         const float* src = cond + (size_t)first_ray * S * CS;
         const int pieces = (TEAM * CS) >> 8;  // CS is a multiple of 8: 128 rows = CS / 2 KiB
-        for (int p = tw; p < pieces; p += 4) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(rows_lds_addr + (unsigned)p * 1024u));
+        for (int p = tw; p < pieces; p += 4) glds16_s_stream(src + p * 256, voff, __builtin_amdgcn_readfirstlane(rows_lds_addr + (unsigned)p * 1024u));
       }
     }
     f32x16 qkv[2];
