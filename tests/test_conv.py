@@ -87,7 +87,10 @@ def test_conv2d_matches_float64(hip, case):
     if leaky != 1.0:
         ref32 = F.leaky_relu(ref32, leaky)
     err32 = float((ref32.double() - want).abs().max())              # what an fp32 evaluation (CPU) achieves
+    print(f"\nconv {case}: |err| {err:.2e} (fp32 CPU evaluation {err32:.2e}), max|want| {float(want.abs().max()):.2e}")
     assert err < 4 * err32 + 1e-6 * float(want.abs().max()), (case, err, err32)
+    # and an absolute gate that does not move with torch: observed <= 1.0e-6 of the largest output over all cases (MI355X)
+    assert err < 3e-6 * float(want.abs().max()), (case, err)
     assert float(hip.absmax_value(scal[1])) == float(got.abs().max())
 
 

@@ -146,6 +146,7 @@ def test_encoder_block_kernel_matches_reference_chain(ffn, n_tokens):
     print(f"\nencoder block ffn={ffn} N={n_tokens}: message vs float64: kernel {e_kernel:.2e} (incl. the rounding of out - source), "
           f"torch fp32 {e_torch:.2e}")
     assert e_kernel < 3.0 * e_torch + 4e-6
+    assert e_kernel < 1.5e-5   # absolute (messages of magnitude ~10): observed 2.5e-6 ... 4.7e-6 on MI355X
 
 
 @pytest.mark.gpu
