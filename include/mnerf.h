@@ -219,6 +219,10 @@ int mnerf_composite_backward(int32_t n_rays, int32_t n_samples, const float* rgb
 int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
                                const float* g_cond, float* g_feat0, float* g_feat1, void* stream);
 
+/* Test / diagnosis hook: set one tuning knob after load (the lower-case name of its MNERF_* environment variable without the
+ * prefix: "decoder_pp", "cv_variant", ...); returns the previous value, -1 for an unknown name. */
+int mnerf_debug_set_knob(const char* name, int value);
+
 /* K3+K4 backward — gradients of the conditional MLP + ray transformer (CondNeRF.forward, cond_nerf.py:52-100;
  * MultiHeadAttention.forward, ray_transformer.py:29-79; what `loss.backward()` does to them in coach.py:215-243).
  * The parameters are given in torch's own layouts (Linear.weight [out,in], fp32), indexed by MNERF_DT_*; `g[k]` receives the

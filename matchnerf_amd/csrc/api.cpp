@@ -1,4 +1,5 @@
 // libmnerf_hip.so — error channel and ABI version (see include/mnerf.h).
+#include <string.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,7 +34,7 @@ extern "C" int64_t mnerf_struct_size(int32_t which) {
 }
 
 // ---- debug / tuning knobs: the environment is read ONCE, when the library is loaded (a static initialiser), into a
-// table that is read-only from then on.  Nothing in a launch path calls getenv or keeps mutable state; the only
+// table that launches only read (mnerf_debug_set_knob below is the one writer, for tests).  Nothing in a launch path calls getenv or keeps mutable state; the only
 // per-process bookkeeping left is "has this kernel's LDS attribute been set on this device" (mnerf_once_per_device).
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -57,8 +58,26 @@ static mnerf_tuning read_tuning() {
   return t;
 }
 
-static const mnerf_tuning g_tuning = read_tuning();
+static mnerf_tuning g_tuning = read_tuning();
 const mnerf_tuning& mnerf_tune() { return g_tuning; }
+
+// Test / diagnosis hook: change one knob of the table after load (what its environment variable would have set) and get
+// the previous value back; -1 and an error message for an unknown name.  Not synchronised with launches on other threads.
+extern "C" int mnerf_debug_set_knob(const char* name, int value) {
+  struct Knob { const char* name; int* slot; };
+  const Knob knobs[] = {{"decoder_pp", &g_tuning.decoder_pp}, {"decoder_pp_grid", &g_tuning.decoder_pp_grid},
+                        {"decoder_pp_max_s", &g_tuning.decoder_pp_max_s}, {"decoder_grid", &g_tuning.decoder_grid},
+                        {"cv_variant", &g_tuning.cv_variant}, {"cv_uvpair", &g_tuning.cv_uvpair}, {"cv_grid", &g_tuning.cv_grid},
+                        {"render_fused", &g_tuning.render_fused}};
+  for (const Knob& k : knobs)
+    if (name && strcmp(name, k.name) == 0) {
+      const int old = *k.slot;
+      *k.slot = value;
+      return old;
+    }
+  mnerf_set_error("mnerf_debug_set_knob: unknown knob '%s'", name ? name : "(null)");
+  return -1;
+}
 
 bool mnerf_once_per_device(std::atomic<unsigned long long>& mask) {
   int dev = 0;

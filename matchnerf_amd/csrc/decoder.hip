@@ -1642,12 +1642,30 @@ struct SmemPP {
   static_assert(TOTAL_FLOATS * 4 <= 160 * 1024, "LDS budget of one CU");
 };
 // one-KiB pieces of the two weight segments of every stage (the shipped decoder shape; checked against the schedule on the host)
+// MNERF_PP_L5_H_FIRST (default 1): layer 5 = [enc, h] -> 128 takes its ACTIVATION half first (stage 6 = stream segments 11, 12)
+// and its encoding half second (stage 7 = segment 10, whose header carries the layer's biases and scale).  In stream order
+// (0) phase V_6 holds the FiLM multiplier, layer 4's activations AND the new accumulators (3 x 64 registers) while it
+// re-evaluates the encoding: the longest vector phase of the tile (6.6 k cycles against 3.9 k) and the origin of most
+// spills.  Activation half first, the activations are consumed where they are produced and the encoding is evaluated in
+// the short phase V_7.  The layer's sum is then accumulated in the other order, so this kernel's results differ from
+// decoder_kernel's in the last bits (not from one launch to the next: tests/test_stress_gpu.py).
+#ifndef MNERF_PP_L5_H_FIRST
+#define MNERF_PP_L5_H_FIRST 1
+#endif
 __device__ __host__ constexpr int pp_p0(int s) {
+#if MNERF_PP_L5_H_FIRST
+  constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 32, 33, 17, 33, 17, 9};
+#else
   constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 33, 32, 17, 33, 17, 9};
+#endif
   return t[s];
 }
 __device__ __host__ constexpr int pp_p1(int s) {
+#if MNERF_PP_L5_H_FIRST
+  constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 32, 0, 0, 32, 20, 0};
+#else
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 0, 32, 0, 32, 20, 0};
+#endif
   return t[s];
 }
 
@@ -1950,6 +1968,29 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_HIDDEN_LAYER(4);
     PP_HIDDEN_LAYER(5);
 #undef PP_HIDDEN_LAYER
+#if MNERF_PP_L5_H_FIRST
+    // ============================================================ layer 5 = [enc, h] -> 128 (stage 6: activation half, 7: encoding half)
+    // V_6: FiLM + ReLU of layer 4 in place, its operands with the gain BOTH halves share, the layer's biases (they sit in the
+    // header of the encoding half's segment, resident as header 7)
+    int eg;
+    PP_BEGIN_V(6);
+    {
+      hmax = film_relu(acc);
+      eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
+      split_blocks(acc, pow2i(eg + ec));
+      ew_cur = header_ew(PP_HDR_LDS(7));
+      bias_init_h<4>(acc, PP_HDR_LDS(7), hl, pow2i(ew_cur + eg));
+    }
+    PP_END_V(7);
+    PP_MFMA(4, 4, 4, acc, 6, 0u, hs);  // M_6: W5[:, enc:] . h
+    PP_END_M();
+    PP_BEGIN_V(7);
+    split_enc(pow2i(eg));  // V_7: the encoding operands, re-evaluated
+    ec = -eg - ew_cur + ecf;
+    PP_END_V(8);
+    PP_MFMA(4, 4, 0, acc, 7, 1024u, hs);  // M_7: += W5[:, :enc] . enc
+    PP_END_M();
+#else
     // ============================================================ layer 5 = [enc, h] -> 128 (stages 6: enc part, 7: h part)
     // V_6: FiLM + ReLU of layer 4 into h (its operands are split in V_7), encoding operands with the common gain
     int eg;
@@ -1973,6 +2014,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_END_V(8);
     PP_MFMA(4, 4, 4, acc, 7, 0u, hs);  // M_7
     PP_END_M();
+#endif
     // ============================================================ alpha head (stage 8) and feature_linear (stage 9): same operands
     PP_BEGIN_V(8);
     hmax = film_relu(acc);  // V_8
@@ -2536,8 +2578,13 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= mnerf_tune().decoder_pp_max_s && dec->L_3D == 10 && sch.film_steps == 2 &&
       sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
     PPSched pps;
+#if MNERF_PP_L5_H_FIRST
+    const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 11, 10, 13, 14, 16, 18};  // layer 5: activation half, then encoding half
+    const int nseg[PP_STAGES] = {1, 1, 2, 2, 2, 2, 2, 1, 1, 2, 2, 1};
+#else
     const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
     const int nseg[PP_STAGES] = {1, 1, 2, 2, 2, 2, 1, 2, 1, 2, 2, 1};
+#endif
     for (int i = 0; i < PP_STAGES; ++i) {
       pps.seg_first[i] = first[i], pps.n_seg[i] = nseg[i];
       // the kernel's compile-time piece counts must be the schedule's

@@ -23,7 +23,7 @@ _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
-           "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes",
+           "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
@@ -131,6 +131,8 @@ def load():
     lib.mnerf_cost_volume_backward.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, fp, fp, vp]
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
+    lib.mnerf_debug_set_knob.restype = C.c_int
+    lib.mnerf_debug_set_knob.argtypes = [C.c_char_p, C.c_int]
     lib.mnerf_decoder_backward_workspace_bytes.restype = i64
     lib.mnerf_decoder_backward_workspace_bytes.argtypes = [i32, i32]
     lib.mnerf_decoder_backward.restype = C.c_int
@@ -188,6 +190,19 @@ def load():
                              f"ctypes mirror has {C.sizeof(st)}")
     _LIB = lib
     return lib
+
+
+@contextlib.contextmanager
+def knob(name, value):
+    """Tests / diagnosis: run the block with one tuning knob of the library changed (mnerf_debug_set_knob)."""
+    lib = load()
+    old = lib.mnerf_debug_set_knob(name.encode(), int(value))
+    if old == -1 and lib.mnerf_last_error().decode(errors="replace").startswith("mnerf_debug_set_knob"):
+        raise MnerfError(lib.mnerf_last_error().decode(errors="replace"))
+    try:
+        yield
+    finally:
+        lib.mnerf_debug_set_knob(name.encode(), old)
 
 
 def check(rc, what):
