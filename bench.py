@@ -391,8 +391,8 @@ def main():
             if "render_fused" in kf:
                 fused_form = {"ms_per_step": round(msf, 3), "rays_per_s": round(n_rays / (msf * 1e-3), 1),
                               "fused_ray_chunk_ms_per_frame": round(kf["render_fused"]["total_ms"] / 2, 3),
-                              # (bit-identical given the same feature maps: tests/test_hip_kernels.py; here each step
-                              # re-runs the encoder, whose library kernels are not bitwise reproducible)
+                              # (the one-launch form shares decoder_kernel's bits; the default staged decoder, the
+                              # ping-pong kernel, sums layer 5 in the other order: a few ulps, tests/test_hip_kernels.py)
                               "rgb_linf_vs_staged": float((ffull[:, :3] - full[:, :3]).abs().max())}
         finally:
             model.fused_render, model.kernel_timer = False, None
