@@ -121,8 +121,25 @@ extern "C" int mnerf_composite_backward(int32_t n_rays, int32_t n_samples, const
 //   cos = <a,b> / (na nb),  na = max(|a|, eps), nb = max(|b|, eps)
 //   d cos / d a = b / (na nb) - [|a| > eps] cos a / |a|^2        (the clamp branch has no |a| term), same for b
 // and a = sum_t w_t tap_t, so the four taps of each map receive w_t * d a (scatter-add: many samples share texels).
-// Mapping as the forward's plain kernel: a slot of 16 lanes owns one sample, 8 channels per lane; the forward
-// interpolation is recomputed (nothing but the rows' gradient is read).
+// Mapping: a slot of 16 lanes owns one sample; lane `sub` holds channels sub, 16 + sub, .., 112 + sub, so that every load and
+// every float atomic of the slot covers 16 CONSECUTIVE channels = one 64-byte line (with 8 consecutive channels per lane the
+// 16 lanes of an atomic instruction touched 8 lines, two dwords each: 10.9 ms for 1 024 rays x 64 samples, the float-atomic
+// line rate of the L2; this form: see DESIGN.md).  A channel group (128 / G >= 16 channels) is then a set of register indices,
+// the same in every lane, and its sums are 16-lane all-reductions.  The forward interpolation is recomputed (nothing but the
+// rows' gradient is read).
+template <int CTRL>
+__device__ __forceinline__ float bwd_dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float slot16_sum(float v) {  // all-reduce over the 16 lanes of a slot (one DPP row)
+  v = bwd_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = bwd_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = bwd_dpp_add<0x141>(v);  // row_half_mirror
+  v = bwd_dpp_add<0x140>(v);  // row_mirror
+  return v;
+}
+
 __global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
                                                                    const float* __restrict__ g_cond,
                                                                    float* __restrict__ g_feat0,
@@ -135,7 +152,12 @@ __global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene s
   const float inv_pairs = 1.0f / (float)P;
   const long long total = (long long)R.n_rays * S;
   const long long slots = ((long long)gridDim.x * blockDim.x) / LPS;
-  for (long long s_idx = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPS; s_idx < total; s_idx += slots) {
+  const long long rounds = (total + slots - 1) / slots;  // every lane takes part in the DPP reductions of every round
+  const long long slot0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPS;
+  for (long long rnd = 0; rnd < rounds; ++rnd) {
+    const long long s_raw = slot0 + rnd * slots;
+    const bool live = s_raw < total;
+    const long long s_idx = live ? s_raw : total - 1;
     const int ray = (int)(s_idx / S);
     const int j = (int)(s_idx - (long long)ray * S);
     const RayGeom g = make_ray(R, ray);
@@ -155,53 +177,60 @@ __global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene s
           if (s >= sc.n_scales) break;
           const int fh = sc.fh[s], fw = sc.fw[s];
           const size_t map_elems = (size_t)fh * fw * FEAT_C;
-          const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems;
+          const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems + sub;
           const float* m1 = m0 + map_elems;
-          float* gm0 = (s ? g_feat1 : g_feat0) + (size_t)(2 * p) * map_elems;
+          float* gm0 = (s ? g_feat1 : g_feat0) + (size_t)(2 * p) * map_elems + sub;
           float* gm1 = gm0 + map_elems;
           const Bilin ba = bilin_setup(ua, va, fh, fw), bb = bilin_setup(ub, vb, fh, fw);
           float fa[CPL], fb[CPL];
 #pragma unroll
           for (int c = 0; c < CPL; ++c) {
-            const int ch = sub * CPL + c;
+            const int ch = c * LPS;  // (+ sub, folded into the base pointers)
             fa[c] = m0[(size_t)ba.o00 * FEAT_C + ch] * ba.w00 + m0[(size_t)ba.o01 * FEAT_C + ch] * ba.w01 +
                     m0[(size_t)ba.o10 * FEAT_C + ch] * ba.w10 + m0[(size_t)ba.o11 * FEAT_C + ch] * ba.w11;
             fb[c] = m1[(size_t)bb.o00 * FEAT_C + ch] * bb.w00 + m1[(size_t)bb.o01 * FEAT_C + ch] * bb.w01 +
                     m1[(size_t)bb.o10 * FEAT_C + ch] * bb.w10 + m1[(size_t)bb.o11 * FEAT_C + ch] * bb.w11;
           }
           const int G = sc.n_group[s];
-          const int lpg = LPS / G;  // lanes per channel group
-          float dot = 0.f, na2 = 0.f, nb2 = 0.f;
+          const int cpg = CPL / G;  // register indices per channel group (G in {1, 2, 4, 8})
+          const float* gsrc = grow + (s ? sc.n_group[0] : 0);
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            dot += fa[c] * fb[c];
-            na2 += fa[c] * fa[c];
-            nb2 += fb[c] * fb[c];
-          }
-          for (int m = 1; m < lpg; m <<= 1) {
-            dot += __shfl_xor(dot, m, 64);
-            na2 += __shfl_xor(na2, m, 64);
-            nb2 += __shfl_xor(nb2, m, 64);
-          }
-          const float ra = sqrtf(na2), rb = sqrtf(nb2);
-          const float na = fmaxf(ra, 1e-8f), nb = fmaxf(rb, 1e-8f);
-          const float inv = 1.0f / (na * nb);
-          const float cosv = dot * inv;
-          const float gcos = grow[(s ? sc.n_group[0] : 0) + sub / lpg] * inv_pairs;
-          const float ka = ra > 1e-8f ? cosv / na2 : 0.0f, kb = rb > 1e-8f ? cosv / nb2 : 0.0f;
+          for (int gi = 0; gi < CPL; ++gi) {
+            if (gi >= G) break;
+            float dot = 0.f, na2 = 0.f, nb2 = 0.f;
 #pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            const int ch = sub * CPL + c;
-            const float da = gcos * (fb[c] * inv - ka * fa[c]);
-            const float db = gcos * (fa[c] * inv - kb * fb[c]);
-            atomicAdd(gm0 + (size_t)ba.o00 * FEAT_C + ch, da * ba.w00);
-            atomicAdd(gm0 + (size_t)ba.o01 * FEAT_C + ch, da * ba.w01);
-            atomicAdd(gm0 + (size_t)ba.o10 * FEAT_C + ch, da * ba.w10);
-            atomicAdd(gm0 + (size_t)ba.o11 * FEAT_C + ch, da * ba.w11);
-            atomicAdd(gm1 + (size_t)bb.o00 * FEAT_C + ch, db * bb.w00);
-            atomicAdd(gm1 + (size_t)bb.o01 * FEAT_C + ch, db * bb.w01);
-            atomicAdd(gm1 + (size_t)bb.o10 * FEAT_C + ch, db * bb.w10);
-            atomicAdd(gm1 + (size_t)bb.o11 * FEAT_C + ch, db * bb.w11);
+            for (int c = 0; c < CPL; ++c)
+              if (c / cpg == gi) {
+                dot += fa[c] * fb[c];
+                na2 += fa[c] * fa[c];
+                nb2 += fb[c] * fb[c];
+              }
+            dot = slot16_sum(dot);
+            na2 = slot16_sum(na2);
+            nb2 = slot16_sum(nb2);
+            const float ra = sqrtf(na2), rb = sqrtf(nb2);
+            const float na = fmaxf(ra, 1e-8f), nb = fmaxf(rb, 1e-8f);
+            const float inv = 1.0f / (na * nb);
+            const float cosv = dot * inv;
+            const float gcos = gsrc[gi] * inv_pairs;
+            const float ka = ra > 1e-8f ? cosv / na2 : 0.0f, kb = rb > 1e-8f ? cosv / nb2 : 0.0f;
+            if (live) {
+#pragma unroll
+              for (int c = 0; c < CPL; ++c)
+                if (c / cpg == gi) {
+                  const int ch = c * LPS;
+                  const float da = gcos * (fb[c] * inv - ka * fa[c]);
+                  const float db = gcos * (fa[c] * inv - kb * fb[c]);
+                  atomicAdd(gm0 + (size_t)ba.o00 * FEAT_C + ch, da * ba.w00);
+                  atomicAdd(gm0 + (size_t)ba.o01 * FEAT_C + ch, da * ba.w01);
+                  atomicAdd(gm0 + (size_t)ba.o10 * FEAT_C + ch, da * ba.w10);
+                  atomicAdd(gm0 + (size_t)ba.o11 * FEAT_C + ch, da * ba.w11);
+                  atomicAdd(gm1 + (size_t)bb.o00 * FEAT_C + ch, db * bb.w00);
+                  atomicAdd(gm1 + (size_t)bb.o01 * FEAT_C + ch, db * bb.w01);
+                  atomicAdd(gm1 + (size_t)bb.o10 * FEAT_C + ch, db * bb.w10);
+                  atomicAdd(gm1 + (size_t)bb.o11 * FEAT_C + ch, db * bb.w11);
+                }
+            }
           }
         }
       }
