@@ -166,7 +166,36 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors of the by-value structs have the sizes the C side was compiled with."""
     lib = hip.load()
-    for which, st in enumerate((hip.View, hip.Rays, hip.Scene, hip.Decoder, hip.EncoderLayer, hip.ConvLayer)):
+    for which, st in enumerate((hip.View, hip.Rays, hip.Scene, hip.Decoder, hip.EncoderLayer, hip.ConvLayer, hip.DecoderTrain)):
         assert lib.mnerf_struct_size(which) == ctypes.sizeof(st), st.__name__
     assert lib.mnerf_struct_size(99) == -1
     assert ctypes.sizeof(hip.View) == 23 * 4
+
+
+def test_decoder_train_tensor_order_matches_the_header_and_the_module():
+    """mnerf_decoder_train indexes the decoder's parameters by the MNERF_DT_* enum; the binding's name table must list them
+    in that order, name every parameter of the CondNeRF module exactly once, and the knob hook must know its knobs."""
+    header = open(os.path.join(REPO, "include", "mnerf.h")).read()
+    body = header[header.index("MNERF_DT_PTS_W0"):header.index("MNERF_DEC_TENSORS")]
+    enum = re.findall(r"\b(MNERF_DT_[A-Z0-9_]+)", body)
+    expect = {"MNERF_DT_BIAS_W": "pts_bias.weight", "MNERF_DT_BIAS_B": "pts_bias.bias", "MNERF_DT_ALPHA_W": "alpha_linear.0.weight",
+              "MNERF_DT_ALPHA_B": "alpha_linear.0.bias", "MNERF_DT_WQ": "ray_attention.w_qs.weight", "MNERF_DT_WK": "ray_attention.w_ks.weight",
+              "MNERF_DT_WV": "ray_attention.w_vs.weight", "MNERF_DT_FC": "ray_attention.fc.weight",
+              "MNERF_DT_LN_W": "ray_attention.layer_norm.weight", "MNERF_DT_LN_B": "ray_attention.layer_norm.bias",
+              "MNERF_DT_OA0_W": "out_alpha_linear.0.weight", "MNERF_DT_OA0_B": "out_alpha_linear.0.bias",
+              "MNERF_DT_OA2_W": "out_alpha_linear.2.weight", "MNERF_DT_OA2_B": "out_alpha_linear.2.bias",
+              "MNERF_DT_FEAT_W": "feature_linear.weight", "MNERF_DT_FEAT_B": "feature_linear.bias",
+              "MNERF_DT_VIEWS_W": "views_linears.0.weight", "MNERF_DT_VIEWS_B": "views_linears.0.bias",
+              "MNERF_DT_RGB_W": "rgb_linear.weight", "MNERF_DT_RGB_B": "rgb_linear.bias"}
+    assert enum[0] == "MNERF_DT_PTS_W0" and "MNERF_DT_BIAS_W = 12" in header
+    names = [f"pts_linears.{i}.{k}" for i in range(6) for k in ("weight", "bias")] + [expect[e] for e in enum[1:]]
+    assert tuple(names) == hip.DEC_TRAIN_TENSORS and len(names) == 32
+    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt.device = "cpu"
+    from matchnerf_amd.models import models_dict
+    dec = models_dict[opt.model](opt).nerf_dec
+    assert sorted(n for n, _ in dec.named_parameters()) == sorted(hip.DEC_TRAIN_TENSORS)
+    lib = hip.load()
+    old = lib.mnerf_debug_set_knob(b"decoder_pp", 0)
+    assert old in (0, 1) and lib.mnerf_debug_set_knob(b"decoder_pp", old) == 0
+    assert lib.mnerf_debug_set_knob(b"no_such_knob", 1) == -1 and b"unknown knob" in lib.mnerf_last_error()
