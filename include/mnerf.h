@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 5
+#define MNERF_ABI_VERSION 6
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
@@ -220,8 +220,11 @@ int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays,
                                const float* g_cond, float* g_feat0, float* g_feat1, void* stream);
 
 /* Test / diagnosis hook: set one tuning knob after load (the lower-case name of its MNERF_* environment variable without the
- * prefix: "decoder_pp", "cv_variant", ...); returns the previous value, -1 for an unknown name. */
-int mnerf_debug_set_knob(const char* name, int value);
+ * prefix: "decoder_pp", "cv_variant", ...).  Returns MNERF_OK and the previous value through *old_value (may be NULL), or
+ * MNERF_E_RANGE + a message for an unknown name (ABI v6: the status no longer shares the return value with the old value,
+ * whose legitimate range includes -1).  Knobs are plain ints read by later launches; the hook is not a synchronisation
+ * point for launches in flight on other threads. */
+int mnerf_debug_set_knob(const char* name, int value, int* old_value);
 
 /* K3+K4 backward — gradients of the conditional MLP + ray transformer (CondNeRF.forward, cond_nerf.py:52-100;
  * MultiHeadAttention.forward, ray_transformer.py:29-79; what `loss.backward()` does to them in coach.py:215-243).

@@ -61,9 +61,9 @@ static mnerf_tuning read_tuning() {
 static mnerf_tuning g_tuning = read_tuning();
 const mnerf_tuning& mnerf_tune() { return g_tuning; }
 
-// Test / diagnosis hook: change one knob of the table after load (what its environment variable would have set) and get
-// the previous value back; -1 and an error message for an unknown name.  Not synchronised with launches on other threads.
-extern "C" int mnerf_debug_set_knob(const char* name, int value) {
+// Test / diagnosis hook: change one knob of the table after load (what its environment variable would have set); the previous
+// value comes back through *old_value, the return value is only the status.  Not synchronised with launches on other threads.
+extern "C" int mnerf_debug_set_knob(const char* name, int value, int* old_value) {
   struct Knob { const char* name; int* slot; };
   const Knob knobs[] = {{"decoder_pp", &g_tuning.decoder_pp}, {"decoder_pp_grid", &g_tuning.decoder_pp_grid},
                         {"decoder_pp_max_s", &g_tuning.decoder_pp_max_s}, {"decoder_grid", &g_tuning.decoder_grid},
@@ -71,12 +71,12 @@ extern "C" int mnerf_debug_set_knob(const char* name, int value) {
                         {"render_fused", &g_tuning.render_fused}};
   for (const Knob& k : knobs)
     if (name && strcmp(name, k.name) == 0) {
-      const int old = *k.slot;
+      if (old_value) *old_value = *k.slot;
       *k.slot = value;
-      return old;
+      return MNERF_OK;
     }
   mnerf_set_error("mnerf_debug_set_knob: unknown knob '%s'", name ? name : "(null)");
-  return -1;
+  return MNERF_E_RANGE;
 }
 
 bool mnerf_once_per_device(std::atomic<unsigned long long>& mask) {

@@ -42,7 +42,7 @@ struct mnerf_tuning {
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies
   int decoder_pp;       // MNERF_DECODER_PP (default 1): the ping-pong form of the split-fp16 decoder where it applies
   int decoder_pp_grid;  // MNERF_DECODER_PP_GRID (default 256): its persistent grid, one 8-wave workgroup per CU
-  int decoder_pp_max_s; // MNERF_DECODER_PP_MAX_S (default 64): largest padded sample count per ray that takes the ping-pong form
+  int decoder_pp_max_s; // MNERF_DECODER_PP_MAX_S (default 128, values above 128 are clamped): largest padded sample count per ray that takes the ping-pong form
 };
 const mnerf_tuning& mnerf_tune();
 // true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device

@@ -2572,10 +2572,10 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
                        ext_dir, *scn);                                                               \
   } while (0)
 #if MNERF_DECODER_PART == 0
-  // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream
-  // (S <= 64: at 128 samples per ray the scores of the ray attention take 128 registers per lane and this kernel's
-  // register budget spills more than the staged one: 99 vs 90 ms per 800x800 frame, measured)
-  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= mnerf_tune().decoder_pp_max_s && dec->L_3D == 10 && sch.film_steps == 2 &&
+  // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream, S <= 128 (round 3: 82.3 vs
+  // 88.7 ms per 800x800 frame at 128 samples per ray; the knob can only LOWER the limit: there is no 256-sample instance)
+  const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
+  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= pp_max_s && dec->L_3D == 10 && sch.film_steps == 2 &&
       sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
     PPSched pps;
 #if MNERF_PP_L5_H_FIRST
@@ -2593,7 +2593,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     }
     const int rpt = 256 / Sp;
     const int tiles = (rays->n_rays + rpt - 1) / rpt;
-    const int cus = mnerf_tune().decoder_pp_grid;  // persistent: one 8-wave workgroup per CU
+    const int cus = mnerf_tune().decoder_pp_grid > 0 ? mnerf_tune().decoder_pp_grid : 1;  // persistent: one 8-wave workgroup per CU
     const int grid = tiles < cus ? tiles : cus;
 #define MNERF_LAUNCH_PP(SP_)                                                                                          \
   do {                                                                                                                \

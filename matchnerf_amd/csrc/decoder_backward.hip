@@ -7,7 +7,7 @@
 //
 // Training chunks are small (rand_rays_train rays: 65 536 samples) and their activations fit HBM thousands of times over, so this
 // is not one fused tile kernel like the forward: the forward is re-evaluated layer by layer from the saved conditioning rows
-// with every pre-activation kept in a workspace (10.7 KB per sample), then walked backwards.  All matrix products — Y = X W^T,
+// with every pre-activation kept in a workspace (2 604 floats = 10.4 KB per sample), then walked backwards.  All matrix products — Y = X W^T,
 // dX = dY W, dW = dY^T X — run through ONE exact-fp32 MFMA GEMM (`gemm_f32_kernel`, v_mfma_f32_32x32x2_f32, 64x64 tiles staged in
 // LDS, strided operands so that transposes / column slices / the row stride of the conditioning rows cost nothing, split-K with
 // float atomics for the weight gradients whose reduction runs over all samples).  What is not a matrix product is a handful
@@ -465,8 +465,7 @@ enum {
   WS_G = WS_ZA + 16,           // 128 running gradient of the trunk activation
   WS_DZ = WS_G + 128,          // 128
   WS_DFILM = WS_DZ + 128,      // 128
-  WS_DIN = WS_DFILM + 128,     // 192 gradient of a concatenated layer input
-  WS_DHV = WS_DIN + 192,       // 64
+  WS_DHV = WS_DFILM + 128,     // 64
   WS_DZR = WS_DHV + 64,        // 4
   WS_SMALL = WS_DZR + 4,       // 13 x 16: dza a0 dq dk dv o_att du y dy dyx t dt_pre | ds_pre (1, padded to 16)
   WS_FLOATS = WS_SMALL + 13 * 16
@@ -497,7 +496,7 @@ extern "C" int mnerf_decoder_backward(const mnerf_decoder_train* D, int32_t n_ra
   float* ws = (float*)workspace;
   auto at = [&](int off) { return ws + (size_t)off * N; };  // planes: one [N, width] array per entry
   float *enc = at(WS_ENC), *dirs_s = at(WS_DIRS), *film = at(WS_FILM), *feat = at(WS_FEAT), *hv = at(WS_HV), *zr = at(WS_ZR),
-        *za = at(WS_ZA), *g = at(WS_G), *dz = at(WS_DZ), *dfilm = at(WS_DFILM), *din = at(WS_DIN), *dhv = at(WS_DHV), *dzr = at(WS_DZR);
+        *za = at(WS_ZA), *g = at(WS_G), *dz = at(WS_DZ), *dfilm = at(WS_DFILM), *dhv = at(WS_DHV), *dzr = at(WS_DZR);
   auto zl = [&](int i) { return at(WS_Z) + (size_t)i * W * N; };
   auto hl = [&](int i) { return at(WS_H) + (size_t)i * W * N; };  // output of trunk layer i
   float* small = at(WS_SMALL);
@@ -556,6 +555,8 @@ extern "C" int mnerf_decoder_backward(const mnerf_decoder_train* D, int32_t n_ra
   {
     const int threads = (S + 63) & ~63;
     const size_t lds = (size_t)(5 * 256 + 4 * 16 + 16 + S * (4 * 16 + 8 + 4 + 1)) * sizeof(float);
+    // (S = 256: 84 KiB — more than the 64 KiB of earlier CDNA parts; this library is gfx950-only, 160 KiB per workgroup)
+    MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_RANGE, "mnerf_decoder_backward: S=%d needs %zu bytes of LDS per ray (limit 160 KiB)", S, lds);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)ray_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ray_head_kernel, dim3(n_rays), dim3(threads), lds, st, R);
   }
@@ -590,7 +591,6 @@ extern "C" int mnerf_decoder_backward(const mnerf_decoder_train* D, int32_t n_ra
       linear_bwd_data(st, dz, W, wi, W, g, W, N, W, W, false);
     }
   }
-  (void)din;
   linear_bwd_weight(st, dfilm, W, cond, cond_stride, gw[MNERF_DT_BIAS_W], Dc, N, W, Dc);
   colsum(st, dfilm, W, N, W, gw[MNERF_DT_BIAS_B]);
   if (g_cond) linear_bwd_data(st, dfilm, W, w[MNERF_DT_BIAS_W], Dc, g_cond, cond_stride, N, W, Dc, false);

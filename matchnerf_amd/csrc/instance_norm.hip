@@ -84,6 +84,10 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
   }
   const float var = in_block_sum<THREADS>(q, red) * inv_n;
   const float rstd = 1.0f / sqrtf(var + eps);
+  // (an opaque copy of the mean: otherwise the centred values of the variance pass are kept for the output pass — a
+  // second copy of the plane in registers, which without packed arithmetic no longer fits 256 of them)
+  float mean_o = mean;
+  asm volatile("" : "+v"(mean_o));
   const float4* res = residual ? reinterpret_cast<const float4*>(residual + base) : nullptr;
   float4* dst = reinterpret_cast<float4*>(out + base);
   float omax = 0.0f;
@@ -93,10 +97,10 @@ __global__ __launch_bounds__(THREADS) void instance_norm_cached_kernel(const flo
     if (j < n4) {
       const float4 r = res ? res[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 o;
-      o.x = in_finish(v[i].x, mean, rstd, r.x, res != nullptr, relu_inner, relu_outer);
-      o.y = in_finish(v[i].y, mean, rstd, r.y, res != nullptr, relu_inner, relu_outer);
-      o.z = in_finish(v[i].z, mean, rstd, r.z, res != nullptr, relu_inner, relu_outer);
-      o.w = in_finish(v[i].w, mean, rstd, r.w, res != nullptr, relu_inner, relu_outer);
+      o.x = in_finish(v[i].x, mean_o, rstd, r.x, res != nullptr, relu_inner, relu_outer);
+      o.y = in_finish(v[i].y, mean_o, rstd, r.y, res != nullptr, relu_inner, relu_outer);
+      o.z = in_finish(v[i].z, mean_o, rstd, r.z, res != nullptr, relu_inner, relu_outer);
+      o.w = in_finish(v[i].w, mean_o, rstd, r.w, res != nullptr, relu_inner, relu_outer);
       dst[j] = o;
       omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }

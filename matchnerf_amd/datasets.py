@@ -91,6 +91,28 @@ def nearest_resize(a, fx, fy):
     return a[ys][:, xs]
 
 
+def resolve_meta(path, what):
+    """The scene / pair lists (`configs/dtu_meta/*.txt`, `configs/pairs.th`) are DATA the reference keeps in its repository, not
+    part of this package.  A relative path is looked up in the working directory first, then next to this package's configs
+    (matchnerf_amd/configs/..., the same order options.load_options uses for yaml files), then under $MNERF_META_ROOT.  A miss
+    names every place that was tried and the constructor arguments that override the defaults."""
+    if os.path.isabs(path):
+        tried = [path]
+    else:
+        pkg = os.path.dirname(os.path.abspath(__file__))
+        rel = path[len("configs" + os.sep):] if path.startswith("configs" + os.sep) else path
+        tried = [os.path.abspath(path), os.path.join(pkg, "configs", rel)]
+        if os.environ.get("MNERF_META_ROOT"):
+            tried.append(os.path.join(os.environ["MNERF_META_ROOT"], path))
+    for t in tried:
+        if os.path.exists(t):
+            return t
+    raise FileNotFoundError(
+        f"{what} not found (tried: {', '.join(tried)}).  These lists ship with the reference repository "
+        "(configs/dtu_meta/{train_all,val_all,view_pairs}.txt, configs/pairs.th): copy them next to the working directory, "
+        "point MNERF_META_ROOT at a checkout, or pass meta_dir= / pairs_file= (data_test.<name>.meta_dir / .pairs_file in the yaml).")
+
+
 class MVSDatasetDTU(torch.utils.data.Dataset):
     """dtu.py:12-209.  `img_wh` = (640, 512) for the benchmark; a sample is the dict `MatchNeRF.forward` takes
     (images [V+1,3,H,W] with the target LAST, extrinsics world->camera [V+1,4,4], intrinsics [V+1,3,3], near_fars [V+1,2],
@@ -110,15 +132,15 @@ class MVSDatasetDTU(torch.utils.data.Dataset):
         self.n_add_train_views = n_add_train_views
         self.permute_train_src = True
         if split in ("train", "val"):
-            self.metas, id_list = self.build_train_metas(os.path.join(meta_dir, "train_all.txt"),
-                                                         os.path.join(meta_dir, "view_pairs.txt"))
+            self.metas, id_list = self.build_train_metas(resolve_meta(os.path.join(meta_dir, "train_all.txt"), "DTU scan list"),
+                                                         resolve_meta(os.path.join(meta_dir, "view_pairs.txt"), "DTU view-pair list"))
             self.build_camera_info(id_list)
         else:
-            pairs = load_pairs(pairs_file)
+            pairs = load_pairs(resolve_meta(pairs_file, "train/test view split (pairs.th)"))
             train_views, test_views = pairs["dtu_train"], pairs["dtu_test"]
+            val_list = resolve_meta(os.path.join(meta_dir, "val_all.txt"), "DTU test scan list")
             self.build_camera_info([*train_views, *test_views])
-            self.metas = self.build_test_metas(os.path.join(meta_dir, "val_all.txt"), train_views, test_views,
-                                               method=test_views_method)
+            self.metas = self.build_test_metas(val_list, train_views, test_views, method=test_views_method)
 
     def get_name(self):
         return "dtu"

@@ -239,10 +239,10 @@ class MatchNeRF(torch.nn.Module):
 
     def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,
                           n_rays, n_samples, img_h, img_w):
-        """Training path (matchnerf_amd/autograd.py): forward through the HIP kernels; backward = HIP kernels for
-        compositing and the cost volume, torch re-evaluation of the conditional MLP + ray transformer in between.
-        Rays go through in chunks of GRAD_RAYS_PER_CALL so that a full-image call under autograd keeps the
-        re-evaluation's temporaries bounded."""
+        """Training path (matchnerf_amd/autograd.py): forward through the HIP kernels; backward = HIP kernels end to end for the
+        ray chunk (mnerf_composite_backward -> mnerf_decoder_backward -> mnerf_cost_volume_backward).  Rays go through in
+        chunks of GRAD_RAYS_PER_CALL so that a full-image call under autograd keeps the decoder backward's workspace (11.2 KB
+        per sample) bounded."""
         from . import autograd as ag
         device = ref_images.device
         legacy = bool(opt.nerf.legacy_coord)

@@ -164,3 +164,43 @@ def test_eval_tools_mask_and_crop():
     with pytest.raises(ValueError, match="only support"):
         tools.get_metrics(["LPIPS"])
     assert metrics.EvalTools(lpips_fn=lambda a, b: 0.25).get_metrics.__self__.support_metrics[-1] == "LPIPS"
+
+
+def test_missing_list_files_are_named_and_coach_passes_the_overrides(tmp_path, monkeypatch):
+    """with data on disk but without the reference's list files the producer used to die on a bare
+    FileNotFoundError for configs/pairs.th.  Now the error names the files, every place tried and the overrides, the lists are
+    also found under $MNERF_META_ROOT, and Coach.load_dataset hands data_test.<name>.meta_dir / pairs_file through."""
+    import pytest
+    from matchnerf_amd import coach, options
+    root = tmp_path / "dtu"
+    meta, pairs = _make_dtu(root, tmp_path)
+    monkeypatch.chdir(tmp_path)  # no configs/ here
+    monkeypatch.delenv("MNERF_META_ROOT", raising=False)
+    with pytest.raises(FileNotFoundError, match=r"pairs\.th.*meta_dir= / pairs_file="):
+        datasets.MVSDatasetDTU(str(root), "test", n_views=3, img_wh=(64, 32))
+    with pytest.raises(FileNotFoundError, match="DTU scan list"):
+        datasets.MVSDatasetDTU(str(root), "train", n_views=3, img_wh=(64, 32))
+    # the reference's layout under a checkout root
+    ref = tmp_path / "checkout"
+    os.makedirs(ref / "configs" / "dtu_meta")
+    for n in ("val_all.txt", "train_all.txt", "view_pairs.txt"):
+        (ref / "configs" / "dtu_meta" / n).write_text(open(os.path.join(meta, n)).read())
+    torch.save(torch.load(pairs, weights_only=False), str(ref / "configs" / "pairs.th"))
+    monkeypatch.setenv("MNERF_META_ROOT", str(ref))
+    assert len(datasets.MVSDatasetDTU(str(root), "test", n_views=3, img_wh=(64, 32))) == 1
+    monkeypatch.delenv("MNERF_META_ROOT")
+    # Coach.load_dataset with an existing root_dir: the yaml entry carries the locations
+    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt.device = "cpu"
+    for name in list(opt.data_test.keys()):
+        if name != "dtu":
+            opt.data_test[name] = None
+    opt.data_test.dtu.root_dir = str(root)
+    opt.data_test.dtu.img_wh = [64, 32]
+    opt.data_test.dtu.meta_dir, opt.data_test.dtu.pairs_file = meta, pairs
+    c = coach.Coach.__new__(coach.Coach)  # load_dataset only needs the options and the view count
+    c.opts, c.n_src_views = opt, 3
+    c.load_dataset()
+    assert len(c.test_loaders) == 1 and c.test_loaders[0].get_name() == "dtu"
+    batch = next(iter(c.test_loaders[0]))
+    assert batch["images"].shape == (1, 4, 3, 32, 64)

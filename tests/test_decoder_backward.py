@@ -1,11 +1,11 @@
-"""K3+K4 backward (mnerf_decoder_backward) against float64 autograd through a plain torch statement of CondNeRF.forward."""
-import copy
-
+"""K3+K4 backward (mnerf_decoder_backward) against float64 autograd through the ORACLE's decoder (oracle/matchnerf_oracle.py:
+decoder + ray_attention, the restatement of cond_nerf.py:52-100 / ray_transformer.py:29-79 that the goldens pin to the
+reference; it is dtype-generic and differentiable)."""
 import pytest
 import torch
 
-from gpu_helpers import decoder_torch
 from helpers import golden_case
+from oracle import matchnerf_oracle as O
 from test_model_gpu import build_model
 
 pytestmark = pytest.mark.gpu
@@ -44,13 +44,17 @@ def _case(name, n_rays, n_samples, seed, **decoder_opts):
                                          raytrans_table=table)
     torch.cuda.synchronize()
 
-    ref = copy.deepcopy(dec).double().cpu()
+    for k, val in decoder_opts.items():  # the oracle's switches follow the module's options
+        assert hasattr(cfg, k), k
+        setattr(cfg, k, val)
+    sd64 = {"nerf_dec." + k: p.detach().double().cpu().clone().requires_grad_(True) for k, p in dec.named_parameters()}
     cond_ref = cond[:, :dc].double().reshape(n_rays, n_samples, dc).clone().requires_grad_(True)
-    rgb_s, sigma = decoder_torch(opt, ref, x.double().reshape(n_rays, n_samples, 3), dirs.double(), cond_ref, v)
+    rgb_s, sigma = O.decoder(cfg, sd64, x.double().reshape(n_rays, n_samples, 3), dirs.double(), cond_ref, cond_ref[..., -v:])
     (rgb_s * g_rgb.double().reshape(n_rays, n_samples, 3)).sum().add((sigma * g_sig.double()).sum()).backward()
     worst = {}
-    for k, p in ref.named_parameters():
-        assert k in grads, k
+    for k in params:
+        p = sd64["nerf_dec." + k]
+        assert k in grads and p.grad is not None, k
         scale = float(p.grad.abs().max()) + 1e-30
         worst[k] = float((grads[k].cpu().double() - p.grad).abs().max()) / scale
     scale = float(cond_ref.grad.abs().max())

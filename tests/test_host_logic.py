@@ -196,6 +196,11 @@ def test_decoder_train_tensor_order_matches_the_header_and_the_module():
     dec = models_dict[opt.model](opt).nerf_dec
     assert sorted(n for n, _ in dec.named_parameters()) == sorted(hip.DEC_TRAIN_TENSORS)
     lib = hip.load()
-    old = lib.mnerf_debug_set_knob(b"decoder_pp", 0)
-    assert old in (0, 1) and lib.mnerf_debug_set_knob(b"decoder_pp", old) == 0
-    assert lib.mnerf_debug_set_knob(b"no_such_knob", 1) == -1 and b"unknown knob" in lib.mnerf_last_error()
+    old, back = ctypes.c_int(-7), ctypes.c_int(-7)
+    assert lib.mnerf_debug_set_knob(b"decoder_pp", 0, ctypes.byref(old)) == 0 and old.value in (0, 1)
+    assert lib.mnerf_debug_set_knob(b"decoder_pp", old.value, ctypes.byref(back)) == 0 and back.value == 0
+    assert lib.mnerf_debug_set_knob(b"no_such_knob", 1, None) == hip.MNERF_E_RANGE and b"unknown knob" in lib.mnerf_last_error()
+    # a knob whose legitimate value is -1, after a failed call left its message in the error channel: no spurious error
+    with hip.knob("cv_uvpair", 1):
+        pass
+    assert lib.mnerf_debug_set_knob(b"cv_uvpair", -1, ctypes.byref(old)) == 0 and old.value == -1

@@ -113,9 +113,9 @@ def test_random_ray_mode_matches_oracle():
 
 
 def test_train_mode_gradients_match_oracle_autograd():
-    """mode='train' under autograd: forward values from the HIP kernels; backward = HIP kernels for compositing and the
-    cost volume + torch re-evaluation of the MLP on the forward's own sample coordinates (matchnerf_amd/autograd.py)
-    — compared with autograd through the CPU oracle on all nine probe parameters."""
+    """mode='train' under autograd: forward values from the HIP kernels; the ray chunk's backward is HIP end to end
+    (compositing, conditional MLP + ray transformer on the forward's own sample coordinates, cost volume:
+    matchnerf_amd/autograd.py) — compared with autograd through the CPU oracle on all nine probe parameters."""
     g, cfg, sd, batch_cpu = golden_case("c1_default")
     opt, model = build_model(g["meta"])
     model.train()

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../../matchnerf_amd/csrc"
 NAME=$1; EXTRA=$2; shift; shift || true
 SRCS=${@:-"decoder.hip cost_volume.hip"}
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-use-amdgpu-trackers=1 -fno-slp-vectorize $EXTRA"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-use-amdgpu-trackers=1 -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops $EXTRA"
 mkdir -p build/var
 SKIP=""
 NEW=""
