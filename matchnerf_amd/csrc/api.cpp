@@ -48,6 +48,7 @@ static mnerf_tuning read_tuning() {
   t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 5 = texel tiles in LDS (slower, kept: cost_volume.hip); 0 = plain
   t.cv_uvpair = env_int("MNERF_CV_UVPAIR", -1);
+  t.cv_pair_block = env_int("MNERF_CV_PAIR_BLOCK", 8);
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
   t.wa_xcd = env_int("MNERF_WA_XCD", 1);          // query blocks of a window share an XCD (its L2 holds the K / V images)
@@ -67,7 +68,7 @@ extern "C" int mnerf_debug_set_knob(const char* name, int value, int* old_value)
   struct Knob { const char* name; int* slot; };
   const Knob knobs[] = {{"decoder_pp", &g_tuning.decoder_pp}, {"decoder_pp_grid", &g_tuning.decoder_pp_grid},
                         {"decoder_pp_max_s", &g_tuning.decoder_pp_max_s}, {"decoder_grid", &g_tuning.decoder_grid},
-                        {"cv_variant", &g_tuning.cv_variant}, {"cv_uvpair", &g_tuning.cv_uvpair}, {"cv_grid", &g_tuning.cv_grid},
+                        {"cv_variant", &g_tuning.cv_variant}, {"cv_uvpair", &g_tuning.cv_uvpair}, {"cv_pair_block", &g_tuning.cv_pair_block}, {"cv_grid", &g_tuning.cv_grid},
                         {"render_fused", &g_tuning.render_fused}};
   for (const Knob& k : knobs)
     if (name && strcmp(name, k.name) == 0) {

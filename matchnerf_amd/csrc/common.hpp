@@ -36,6 +36,7 @@ static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u
 struct mnerf_tuning {
   int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
+  int cv_pair_block;  // MNERF_CV_PAIR_BLOCK (default 8): view pairs per launch of the many-view cost volume (0: all in one)
   int cv_uvpair;  // MNERF_CV_UVPAIR (default -1 = by LDS footprint): 1 / 0 force the per-pair projection scratch of the walk on / off
   int wa_min4;
   int wa_xcd;  // pre-split window attention: all query blocks of a window on one XCD (1) or launch order (0)

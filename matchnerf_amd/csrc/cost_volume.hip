@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
 template <int CPL, bool UVPAIR = false>
 __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_lean_kernel(mnerf_scene sc, mnerf_rays R,
                                                                                    int cond_stride,
-                                                                                   float* __restrict__ cond) {
+                                                                                   float* __restrict__ cond,
+                                                                                   int pair_begin, int pair_end) {
   constexpr int LPS = FEAT_C / CPL;     // lanes per sample slot (8 or 16)
   constexpr int NSLOT = 256 / LPS;      // ray slots per workgroup (32 or 16)
   extern __shared__ __attribute__((aligned(16))) float cvw_smem[];
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
     const int ray = (int)ray_ll;
     const int jrow = j0 < S ? j0 : S - 1;
     cv_walk_unit<CPL, CVW_SEG, true, UVPAIR>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
-                                       uv_lds, wrec_lds, cs_lds, sub);
+                                       uv_lds, wrec_lds, cs_lds, sub, pair_begin, pair_end);
   }
 }
 
@@ -567,15 +568,22 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
     int cap = variant == 4 ? 2048 : 4096;
     if (mnerf_tune().cv_grid > 0) cap = mnerf_tune().cv_grid;
     if (wgs > cap) wgs = cap;
+    const int n_pairs = scene->n_views * (scene->n_views - 1) / 2;
     if (which == 1)
       hipLaunchKernelGGL(cost_volume_lean_kernel<16>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
-                         *scene, *rays, cond_stride, cond);
-    else if (which == 2)
-      hipLaunchKernelGGL((cost_volume_lean_kernel<8, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
-                         *scene, *rays, cond_stride, cond);
-    else
+                         *scene, *rays, cond_stride, cond, 0, n_pairs);
+    else if (which == 2) {
+      // Many views: one launch per BLOCK of view pairs over all rays, so that the maps a launch gathers from fit the 256 MiB
+      // Infinity Cache (cv_walk.hpp "PAIR BLOCKS"; 8 pairs x 2 sides x 13.1 MB at 512x640 = 210 MB).  Same stream: the blocks
+      // run in order, each continues the cosine sums the previous one left in the rows.  MNERF_CV_PAIR_BLOCK: pairs per
+      // launch (default 8; 0 = all pairs in one launch, the round-3 form).
+      const int blk = mnerf_tune().cv_pair_block > 0 ? mnerf_tune().cv_pair_block : n_pairs;
+      for (int p0 = 0; p0 < n_pairs; p0 += blk)
+        hipLaunchKernelGGL((cost_volume_lean_kernel<8, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+                           *scene, *rays, cond_stride, cond, p0, p0 + blk < n_pairs ? p0 + blk : n_pairs);
+    } else
       hipLaunchKernelGGL(cost_volume_lean_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
-                         *scene, *rays, cond_stride, cond);
+                         *scene, *rays, cond_stride, cond, 0, n_pairs);
   } else {
 #ifdef CV_PROBE_DUP
     unsigned* dbg = nullptr;

@@ -531,10 +531,17 @@ __device__ __forceinline__ void cv_write_cosines(const mnerf_rays& R, bool ray_l
 // UVPAIR: the projections of a segment are not kept for all V views ([js][V] (u,v) in uv_lds) but re-evaluated per view pair
 // for its two views ([js][2]): 2 P instead of V projections per sample (+1 % of a unit's instructions at 10 views) for
 // 2 V - 4 fewer LDS floats per sample — at 10 views that is what lets a fourth workgroup share the CU (cost_volume.hip).
+// PAIR BLOCKS (many views).  At 10 views the 45 pairs' maps are 1.18 GB — 4.6 x the Infinity Cache — and a unit that walks all
+// pairs keeps all of them live: round 3 measured 60 GB fetched per 65,536-ray launch for those 1.18 GB (52 % L2 hits).  The
+// stand-alone kernel can therefore be launched once per BLOCK of pairs [pair_begin, pair_end) over ALL rays of the launch
+// (cost_volume.hip: 8 pairs = 210 MB of maps): the first block also does pass 1, every block continues the per-sample cosine
+// sums where the previous one stopped — they travel through the rows' cosine columns as RAW sums, the last block scales them
+// by 1 / pairs — so every sum is still accumulated pair by pair in the reference's order: same bits as one launch.
 template <int CPL, int SEG, bool NT = false, bool UVPAIR = false>
 __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_rays& R, int ray, bool ray_live, int j0,
                                              float* __restrict__ row0, int cond_stride, float* __restrict__ uv_lds,
-                                             float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub) {
+                                             float4* __restrict__ wrec_lds, float* __restrict__ cs_lds, int sub,
+                                             int pair_begin = 0, int pair_end = 0x7fffffff) {
   constexpr int LPS = FEAT_C / CPL;
   constexpr int SPL = SEG / LPS > 0 ? SEG / LPS : 1;  // pass-1 samples per lane
   const int V = sc.n_views;
@@ -545,8 +552,22 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
   const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
   const unsigned lane_bytes = (unsigned)sub * CPL * 4;
 
-  cv_pass1<CPL, SEG, NT>(sc, R, ray, ray_live, j0, row0, cond_stride, UVPAIR ? nullptr : uv_lds, sub);
-  for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
+  const bool first_block = pair_begin <= 0, last_block = pair_end >= V * (V - 1) / 2;
+  if (first_block) {
+    cv_pass1<CPL, SEG, NT>(sc, R, ray, ray_live, j0, row0, cond_stride, UVPAIR ? nullptr : uv_lds, sub);
+    for (int i = sub; i < SEG * cs_stride; i += LPS) cs_lds[i] = 0.0f;  // this slot's cosine sums
+  } else {
+    static_assert(UVPAIR || SEG > 0, "");
+    // a later pair block: the raw sums of the blocks before it (lane `sub` wrote samples sub, sub + LPS, .. of this segment)
+#pragma unroll
+    for (int half = 0; half < SPL; ++half) {
+      const int js = sub + LPS * half;
+      if (js >= SEG) break;
+      const bool have = ray_live && (j0 + js < R.n_samples);
+      const float* in = row0 + (size_t)js * cond_stride;
+      for (int c = 0; c < sumG; ++c) cs_lds[js * cs_stride + c] = have ? in[c] : 0.0f;
+    }
+  }
   // slot-local LDS hand-off: the lanes of a slot belong to one wave => wave-level ordering
   cvw_handoff();
 
@@ -554,6 +575,7 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
   int p = 0;
   for (int a = 0; a < V - 1; ++a) {
     for (int b = a + 1; b < V; ++b, ++p) {
+      if (p < pair_begin || p >= pair_end) continue;  // not in this launch's pair block
       if constexpr (UVPAIR) {  // this pair's two projections of every sample of the segment (cv_pass1's arithmetic)
         const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
         const RayGeom g = make_ray(R, ray);
@@ -615,6 +637,6 @@ __device__ __forceinline__ void cv_walk_unit(const mnerf_scene& sc, const mnerf_
     }
   }
   cvw_handoff();
-  cv_write_cosines<CPL, SEG, NT>(R, ray_live, j0, row0, cond_stride, cs_lds, cs_stride, sumG, inv_pairs, sub);
+  cv_write_cosines<CPL, SEG, NT>(R, ray_live, j0, row0, cond_stride, cs_lds, cs_stride, sumG, last_block ? inv_pairs : 1.0f, sub);
   __builtin_amdgcn_wave_barrier();  // cs_lds / uv_lds / wrec_lds are rewritten by the next unit
 }

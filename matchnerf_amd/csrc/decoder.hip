@@ -1660,6 +1660,29 @@ __device__ __host__ constexpr int pp_p0(int s) {
 #endif
   return t[s];
 }
+// The ping-pong kernel's schedule is ONE fixed schedule (the host refuses anything else), so the position of every segment in
+// the weight stream is a compile-time constant too: stream order = FiLM | L0 | L1 a b | L2 a b | L3 a b | L4 a b | L5-enc |
+// L5-h a b | alpha | feature a b | views a b | rgb | tail.  Taken from the kernel arguments (sch.seg_off[pps.seg_first[s] + i]:
+// two dependent scalar loads per use) the 20 addresses were hoisted out of the tile loop and parked in VGPR lanes - 280
+// spilled SGPRs, 850 v_readlane per tile (12 % of the kernel's vector instructions).
+__device__ __host__ constexpr int pp_stream_pieces(int k) {  // 1-KiB pieces of stream segment k
+  constexpr int t[20] = {17, 33, 33, 32, 33, 32, 33, 32, 33, 32, 33, 32, 32, 17, 33, 32, 17, 20, 9, 11};
+  return t[k];
+}
+__device__ __host__ constexpr int pp_stream_off_floats(int k) {
+  int o = 0;
+  for (int m = 0; m < k; ++m) o += pp_stream_pieces(m) * 256;
+  return o;
+}
+__device__ __host__ constexpr int pp_seg_first(int s) {
+#if MNERF_PP_L5_H_FIRST
+  constexpr int t[PP_STAGES] = {0, 1, 2, 4, 6, 8, 11, 10, 13, 14, 16, 18};
+#else
+  constexpr int t[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
+#endif
+  return t[s];
+}
+__device__ __host__ constexpr int pp_seg_off_floats(int s, int i) { return pp_stream_off_floats(pp_seg_first(s) + i); }
 __device__ __host__ constexpr int pp_p1(int s) {
 #if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 32, 0, 0, 32, 20, 0};
@@ -1667,6 +1690,147 @@ __device__ __host__ constexpr int pp_p1(int s) {
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 0, 32, 0, 32, 20, 0};
 #endif
   return t[s];
+}
+
+
+// Ray attention of the ping-pong kernel (phase T2): the arithmetic of decoder_kernel's MFMA form, every accumulator fed in the same
+// order (bit-identical), but written so that no matrix instruction waits for its predecessor: the chains of TWO key groups (and,
+// for S <= 64, of the wave's TWO heads) are interleaved — v_mfma_f32_4x4x1 is a 2-pass instruction, and as 4-long dependent
+// chains issued one group after the other (round 3) every instruction paid the full pipeline latency plus a register copy —,
+// and the softmax numerators of a group pair (v_exp_f32: quarter rate, the bound of this phase) are evaluated right in front of
+// that pair's output products, which then run under the next pair's exponentials.
+template <int SP>
+__device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float* k_lds, const float* vt_lds, float* o_lds,
+                                                 int a_ray, int a_hp, int s_q, int lane, int S) {
+  constexpr int G = SP / 4;
+  constexpr int NH = SP >= 128 ? 1 : 2;  // heads side by side (their score sets are live together: SP registers each)
+#pragma unroll 1
+  for (int h0 = 0; h0 < 2; h0 += NH) {
+    f32x4 sc[NH][G];
+    float4 q4[NH];
+    const float* kb[NH];
+    const float* vb[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      const int head = 2 * a_hp + h0 + hh;
+      q4[hh] = *reinterpret_cast<const float4*>(q_lds + s_q * 16 + head * 4);
+      kb[hh] = k_lds + ((a_ray * 4 + head) * SP + (lane & 3)) * 4;
+      vb[hh] = vt_lds + ((a_ray * 4 + head) * 4 + (lane & 3)) * SP;
+    }
+    // ---- scores of 4 keys per group: s4[r] += K[4 g + r][d] * Q[query][d]
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+      float4 ka[NH], kc[NH];
+      f32x4 ta[NH], tc[NH];
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        ka[hh] = *reinterpret_cast<const float4*>(kb[hh] + g * 16);
+        kc[hh] = *reinterpret_cast<const float4*>(kb[hh] + g * 16 + 16);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        ta[hh] = mfma4(ka[hh].x, q4[hh].x, (f32x4){0.f, 0.f, 0.f, 0.f});
+        tc[hh] = mfma4(kc[hh].x, q4[hh].x, (f32x4){0.f, 0.f, 0.f, 0.f});
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        ta[hh] = mfma4(ka[hh].y, q4[hh].y, ta[hh]);
+        tc[hh] = mfma4(kc[hh].y, q4[hh].y, tc[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        ta[hh] = mfma4(ka[hh].z, q4[hh].z, ta[hh]);
+        tc[hh] = mfma4(kc[hh].z, q4[hh].z, tc[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        sc[hh][g] = mfma4(ka[hh].w, q4[hh].w, ta[hh]);
+        sc[hh][g + 1] = mfma4(kc[hh].w, q4[hh].w, tc[hh]);
+      }
+    }
+    // ---- row maxima (four partial maxima per head, as in decoder_kernel)
+    float mx[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+      if (S == SP) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[hh][g][r]);
+      } else {
+        int s_keys = S;  // opaque: see decoder_kernel
+        asm volatile("" : "+s"(s_keys));
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = (4 * g + r < s_keys) ? sc[hh][g][r] : -3.0e38f;
+            sc[hh][g][r] = v;
+            mx4[r] = fmaxf(mx4[r], v);
+          }
+      }
+      mx[hh] = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+    }
+    // ---- numerators of a group pair, then that pair's output products o4[d] += V[key][d] * P[query][key]
+    float ls4[NH][4];
+    f32x4 oa[NH], ob[NH];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ls4[hh][r] = 0.f;
+      oa[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ob[hh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+      float4 va[NH], vc[NH];
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        va[hh] = *reinterpret_cast<const float4*>(vb[hh] + 4 * g);
+        vc[hh] = *reinterpret_cast<const float4*>(vb[hh] + 4 * g + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(sc[hh][g + u][r] - mx[hh]);
+            sc[hh][g + u][r] = pr;
+            ls4[hh][r] += pr;
+          }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        oa[hh] = mfma4(va[hh].x, sc[hh][g][0], oa[hh]);
+        ob[hh] = mfma4(vc[hh].x, sc[hh][g + 1][0], ob[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        oa[hh] = mfma4(va[hh].y, sc[hh][g][1], oa[hh]);
+        ob[hh] = mfma4(vc[hh].y, sc[hh][g + 1][1], ob[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        oa[hh] = mfma4(va[hh].z, sc[hh][g][2], oa[hh]);
+        ob[hh] = mfma4(vc[hh].z, sc[hh][g + 1][2], ob[hh]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < NH; ++hh) {
+        oa[hh] = mfma4(va[hh].w, sc[hh][g][3], oa[hh]);
+        ob[hh] = mfma4(vc[hh].w, sc[hh][g + 1][3], ob[hh]);
+      }
+    }
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+      const int head = 2 * a_hp + h0 + hh;
+      const float lsum = (ls4[hh][0] + ls4[hh][1]) + (ls4[hh][2] + ls4[hh][3]);
+      const float il = 1.0f / lsum;
+      *reinterpret_cast<float4*>(o_lds + s_q * 16 + head * 4) =
+          make_float4((oa[hh][0] + ob[hh][0]) * il, (oa[hh][1] + ob[hh][1]) * il, (oa[hh][2] + ob[hh][2]) * il,
+                      (oa[hh][3] + ob[hh][3]) * il);
+    }
+  }
 }
 
 template <int SP>
@@ -1709,22 +1873,32 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 
 #define PP_SLOT_LDS(s_, i_) (ring_lds + (unsigned)(2 * ((s_)&1) + (i_)) * (SEG_CAP_FLOATS * 4u))
 #define PP_HDR_LDS(s_) (hdr_lds + (unsigned)(s_) * 1024u)
-#define PP_SEG_SRC(s_, i_) (D.wstream + sch.seg_off[pps.seg_first[s_] + (i_)])
+#define PP_SEG_SRC(s_, i_) (D.wstream + pp_seg_off_floats(s_, i_))
 
   // ---- prologue: LayerNorm parameters, the resident tail segment, the stage headers, stage 0 of the first tile
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
+  if (tid < 2) reinterpret_cast<unsigned*>(ln_lds)[48 + tid] = 0u;  // the teams' arrival counters (wave_group_sync)
+  // this wave's team counter: LDS byte address and the number of arrivals it has made (wave-uniform)
+  const unsigned team_ctr_lds = hdr_lds + (unsigned)(SM::HDR_FLOATS + SM::RS_FLOATS + 48 + team) * 4u;
+  int team_epoch = 0;
   {
     const unsigned voff = (unsigned)lane0 * 16u;
-    const int seg = sch.n_seg - 1;
-    const int pieces = sch.seg_floats[seg] >> 8;
-    for (int p = wave; p < pieces; p += 8)
-      glds16_s(D.wstream + sch.seg_off[seg] + p * 256, voff, __builtin_amdgcn_readfirstlane(tail_lds + (unsigned)p * 1024u));
+    for (int p = wave; p < pp_stream_pieces(19); p += 8)
+      glds16_s(D.wstream + pp_stream_off_floats(19) + p * 256, voff, __builtin_amdgcn_readfirstlane(tail_lds + (unsigned)p * 1024u));
     for (int s = wave; s < PP_STAGES; s += 8) glds16_s(PP_SEG_SRC(s, 0), voff, __builtin_amdgcn_readfirstlane(PP_HDR_LDS(s)));
     for (int p = wave; p < pp_p0(0); p += 8)
       glds16_s(PP_SEG_SRC(0, 0) + p * 256, voff, __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(0, 0) + (unsigned)p * 1024u));
   }
   segment_wait();
   __syncthreads();
+  // Static issue priority for team B.  Waves 4-7 are dispatched second, and between two waves of a SIMD at equal priority
+  // the OLDER one wins the vector-issue arbitration: round 4's first timeline had team B's matrix phases at 4.6 k cycles
+  // against team A's 3.85 k, its T2 at 12.6 k against 9.9 k.  One s_setprio for the whole kernel, no per-phase flips
+  // (MI355X_MICROARCH.md "two waves per SIMD", item 4).  MNERF_PP_BPRIO=0 switches it off.
+#ifndef MNERF_PP_BPRIO
+#define MNERF_PP_BPRIO 1
+#endif
+  if (MNERF_PP_BPRIO && team == 1) __builtin_amdgcn_s_setprio(MNERF_PP_BPRIO);
   if (team == 1) __syncthreads();  // team B runs one phase behind team A from here on
 
   int tile_begin = blockIdx.x, tile_end = n_tiles, tile_step = gridDim.x;
@@ -1734,44 +1908,113 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     tile_end = (int)((long long)n_tiles * (xcd + 1) / 8);
     tile_step = ((int)gridDim.x - xcd + 7) >> 3;
   }
+  // Synchronisation of a phase's end.  Trunk phases end at the workgroup barrier (PP_SYNC): that is what keeps the two teams
+  // exactly one phase apart.  The four tail phases only exchange data INSIDE a team (attention scratch, per-sample densities),
+  // so they end at a team-scoped sync (PP_TSYNC: wave_group_sync on the team's LDS counter) and the teams run through their
+  // tails independently: in round 3's lock step the five slots around the tail cost max(A, B) each — T2 (9 k cycles) was paid
+  // twice, 32 k of a tile's 120 k cycles —, now they cost max(sum A, sum B).  PP_NOSYNC: a phase end without any sync.
 #ifdef MNERF_TIMELINE
-  // debug build (tools/exp/pp_timeline.py): per wave and phase, s_memtime at the end of the work and after the barrier
+  // debug build (tools/exp/pp_timeline.py): per wave and phase, s_memtime at the end of the work and after the sync
   int pp_tl_tile = -1, pp_ph = 0;
-#define PP_SYNC()                                                                                              \
+#define PP_STAMPED(sync_)                                                                                      \
   do {                                                                                                         \
     unsigned long long* o_ = (sch.tl && lane0 == 0 && blockIdx.x < 32 && pp_tl_tile >= 0 && pp_tl_tile < 4)     \
                                  ? sch.tl + ((((size_t)blockIdx.x * 4 + pp_tl_tile) * 8 + wave) * PP_PHASES + pp_ph) * 2 \
                                  : nullptr;                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
     if (o_) o_[0] = __builtin_amdgcn_s_memtime();                                                              \
-    __syncthreads();                                                                                           \
+    sync_;                                                                                                     \
     if (o_) o_[1] = __builtin_amdgcn_s_memtime();                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
     ++pp_ph;                                                                                                   \
   } while (0)
 #else
-#define PP_SYNC() __syncthreads()
+  // (a scheduling fence on both sides: the compiler otherwise moves vector work across s_barrier — in round 3's ISA the 64 bias
+  // multiplies and 16 operand conversions of every vector phase sat at the top of the NEXT matrix phase, in front of its first
+  // matrix instruction: ~350 cycles of start-up in the longer phase of the slot)
+#define PP_STAMPED(sync_)                    \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    sync_;                                   \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
 #endif
+#define PP_SYNC() PP_STAMPED(__syncthreads())
+#define PP_TSYNC() PP_STAMPED(wave_group_sync(team_ctr_lds, 4, team_epoch, lane0))
+#define PP_NOSYNC() PP_STAMPED((void)0)
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
     unsigned voff = (unsigned)lane0 * 16u;
     asm volatile("" : "+v"(voff));
-    for (int i = 0; i < pps.n_seg[s]; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const float* src = PP_SEG_SRC(s, i);
-      const int pieces = sch.seg_floats[pps.seg_first[s] + i] >> 8;
+      const int pieces = i == 0 ? pp_p0(s) : pp_p1(s);
       const unsigned base = PP_SLOT_LDS(s, i);
       const int first = half == 2 ? tw : 2 * tw + half, step = half == 2 ? 4 : 8;
       for (int p = first; p < pieces; p += step) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
     }
   };
+  // ---- weight requests of a vector phase.  MNERF_PP_DMA_SPREAD = 0 (round 3): team A asks for its half of stage s (the odd
+  // 1-KiB pieces) in one burst at the START of V_s, team B for its half of stage s+1 (the even ones) in one burst at the END of
+  // its V_s; the LDS-DMA queue drains ~1 piece per 90 cycles, so a wave's burst of 8 stalls it ~1.6 k cycles in which it does
+  // nothing else.  = 1 (default): the requests are SPREAD over the phase, a few behind the FiLM / ReLU pass and one behind every
+  // operand split, so that the queue drains under the wave's own vector work (PP_DMA sites; what is left goes out at the end).
+  // A wave's share of a stage is at most 10 requests: k -> segment k / 5, piece 2 tw + half + 8 (k % 5).
+#ifndef MNERF_PP_DMA_SPREAD
+#define MNERF_PP_DMA_SPREAD 1
+#endif
+  int dma_k = 0;  // requests of the current vector phase already made by this wave (compile-time after unrolling)
+  auto stage_piece = [&](int s, int half, int k) {
+    const int i = k / 5;
+    const int pcs = i == 0 ? pp_p0(s) : pp_p1(s);
+    // (an opaque copy of the wave's index: the ~200 source / destination addresses of a tile's requests are loop-invariant,
+    // and hoisted out of the tile loop they were parked in VGPR lanes — 480 spilled SGPRs, two v_readlane per request; computed
+    // where they are used they are two scalar additions)
+    int twl = tw;
+    asm volatile("" : "+s"(twl));
+    const int pce = 2 * twl + half + 8 * (k % 5);
+    if (pcs > 0 && pce < pcs) {
+      unsigned vo = (unsigned)lane0 * 16u;
+      asm volatile("" : "+v"(vo));
+      glds16_s(PP_SEG_SRC(s, i) + pce * 256, vo, __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(s, i) + (unsigned)pce * 1024u));
+    }
+  };
+  auto dma_some = [&](int sa, int sb, int n) {
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      if (dma_k >= 10) break;
+      __builtin_amdgcn_sched_barrier(0);
+      if (team == 0) {
+        if (sa >= 0) stage_piece(sa, 1, dma_k);
+      } else {
+        if (sb >= 0) stage_piece(sb, 0, dma_k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ++dma_k;
+    }
+  };
+#if MNERF_PP_DMA_SPREAD
+#define PP_BEGIN_V(stage_) do { dma_k = 0; } while (0)
+#define PP_DMA(sa_, sb_, n_) dma_some(sa_, sb_, n_)
+#define PP_END_V(sa_, next_stage_)                                  \
+  do {                                                              \
+    dma_some(sa_, next_stage_, 10);                                 \
+    if (team == 0) segment_wait();                                  \
+    PP_SYNC();                                                      \
+  } while (0)
+#else
 #define PP_BEGIN_V(stage_)                    \
   do {                                        \
     if (team == 0) stage_dma(stage_, 1);      \
   } while (0)
-#define PP_END_V(next_stage_)                                       \
+#define PP_DMA(sa_, sb_, n_) do {} while (0)
+#define PP_END_V(sa_, next_stage_)                                  \
   do {                                                              \
     if (team == 1) { if ((next_stage_) >= 0) stage_dma(next_stage_, 0); } \
     else segment_wait();                                            \
     PP_SYNC();                                                      \
   } while (0)
+#endif
 #define PP_END_M()                   \
   do {                               \
     if (team == 1) segment_wait();   \
@@ -1781,24 +2024,36 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #ifndef MNERF_PP_PAIRS
 #define MNERF_PP_PAIRS 0  // 1: the two blocks of a pair interleaved, no back-to-back dependent MFMAs (measured: no faster, more spills)
 #endif
-#if MNERF_PP_PAIRS
-#define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
-  ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+// MNERF_PP_MPRIO (experiment, default 0): issue priority of a wave while it is in a matrix phase — its MFMAs then win the
+// SIMD's arbitration against the other team's vector instructions.
+#ifndef MNERF_PP_MPRIO
+#define MNERF_PP_MPRIO 0
+#endif
+#if MNERF_PP_MPRIO
+#define PP_PRIO_UP() __builtin_amdgcn_s_setprio(MNERF_PP_MPRIO)
+#define PP_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
 #else
-#define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
-  ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+#define PP_PRIO_UP() do {} while (0)
+#define PP_PRIO_DOWN() do {} while (0)
 #endif
-#define PP_MFMA1(NS0_, acc_, s_, hdr_bytes_, hs_) \
-  ksteps_presplit2<1, NS0_, 0>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_)
+#if MNERF_PP_PAIRS
+#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
+#else
+#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
+#endif
+#define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                   \
+  do {                                                                                                         \
+    PP_PRIO_UP();                                                                                              \
+    PP_MFMA_(NMB_, NS0_, NS1_, acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), hs_);               \
+    PP_PRIO_DOWN();                                                                                            \
+  } while (0)
+#define PP_MFMA1(NS0_, acc_, s_, hdr_bytes_, hs_)                                                              \
+  do {                                                                                                         \
+    PP_PRIO_UP();                                                                                              \
+    ksteps_presplit2<1, NS0_, 0>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_);       \
+    PP_PRIO_DOWN();                                                                                            \
+  } while (0)
 
-#ifdef MNERF_PP_BIDLE
-  // timing experiment: team B only keeps the barriers company (its outputs are garbage): how long are team A's phases alone?
-  if (team == 1) {
-    for (int tile = tile_begin; tile < tile_end; tile += tile_step)
-      for (int ph = 0; ph < PP_PHASES; ++ph) __syncthreads();
-    return;
-  }
-#endif
   bool rows_in_lds = false;  // this tile's conditioning rows were copied to LDS during the previous tile's tail
   for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
 #ifdef MNERF_TIMELINE
@@ -1850,22 +2105,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       n_valid = nv;
     }
     // (only x, y, z stay in registers across the trunk: the two-float encoding bases are re-derived where the encoding is
-    // evaluated, the view direction where the views stage needs it — kept alive from here they were spilled and reloaded)
-    float x, y, z;
-    if (ext_ndc) {
-      x = ext_ndc[gs * 3 + 0];
-      y = ext_ndc[gs * 3 + 1];
-      z = ext_ndc[gs * 3 + 2];
-    } else {
-      const RayGeom g = make_ray(R, ray);
-      const float dpt = sample_depth(R, ray, j);
-      float wx_, wy_, wz_;
-      ray_point(g, dpt, wx_, wy_, wz_);
-      project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
-    }
-    const float enc_max = fmaxf(fmaxf(1.0f, fabsf(x)), fmaxf(fabsf(y), fabsf(z)));
+    // evaluated, the view direction where the views stage needs it — kept alive from here they were spilled and reloaded.
+    // The sample's coordinates themselves are NOT needed before V_1: they are evaluated in phase M_0, behind its 24 matrix
+    // instructions — the shortest matrix phase of the tile, whose slot is as long as the other team's V_0 anyway.)
+    float x, y, z, enc_max;
     const bool q_valid = n_valid > 1.0f;
 
+    dma_k = 0;     // (V_0 has no PP_BEGIN_V: team A requests nothing here, team B its half of stage 1)
     PartsH hs[8];  // operands of the coming matrix stage: 8 K16-steps of fp16 hi | lo fragments (64 registers)
     f32x16 film[4];
     int ecf;
@@ -1878,51 +2124,76 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       ecf = -(ew + (H16_TARGET_EXP - 1));
       bias_init_h<4>(film, PP_HDR_LDS(0), hl, pow2i(ew + (H16_TARGET_EXP - 1)));
     }
-    PP_END_V(1);
+    PP_END_V(-1, 1);
     // ============================================================ phase 1 = M_0: FiLM = pts_bias(cond)
     PP_MFMA(4, 2, 0, film, 0, 1024u, hs);
+    __builtin_amdgcn_sched_barrier(0);  // the geometry stays in this phase (the scheduler moves vector work across s_barrier)
+    if (ext_ndc) {
+      x = ext_ndc[gs * 3 + 0];
+      y = ext_ndc[gs * 3 + 1];
+      z = ext_ndc[gs * 3 + 2];
+    } else {
+      const RayGeom g = make_ray(R, ray);
+      const float dpt = sample_depth(R, ray, j);
+      float wx_, wy_, wz_;
+      ray_point(g, dpt, wx_, wy_, wz_);
+      project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
+    }
+    enc_max = fmaxf(fmaxf(1.0f, fabsf(x)), fmaxf(fabsf(y), fabsf(z)));
+    __builtin_amdgcn_sched_barrier(0);
     PP_END_M();
     // ============================================================ phase 2 = V_1: positional encoding operands (layer 0)
     PP_BEGIN_V(1);
     f32x16 acc[4];
     int ew_cur = 0, ec, em;
-    auto split_enc = [&](float mult) {  // 32 encoding operands -> hs[0..3]
+    // 16 of the 32 encoding operands -> hs[2 half], hs[2 half + 1].  The two halves are evaluated in different phases: the first
+    // in the vector phase in front of the stage, the second INSIDE the matrix phase, between the stage's first and second pair of
+    // K16-steps (48 matrix instructions in all: the phase is short, while a vector phase with the whole encoding was the longest
+    // of the trunk).  Same operands, same K-step order: same bits.
+    auto split_enc_half = [&](int half, float mult) {
       // (opaque copies: otherwise the second evaluation, six stages later, is merged with the first one and the 32 values
       // travel through scratch — 33 stores in V_1, 53 scratch operations with 35 separate waits in V_6: 12 k cycles)
       float xo = x, yo = y, zo = z;
       asm volatile("" : "+v"(xo), "+v"(yo), "+v"(zo));
       const EncBase encb = enc_base(xo, yo, zo, freq_mul);
-      {
-        const f32x16 e0 = enc_block16_L10<0>(encb, hl, xo, yo, zo);
-        float v[8];
+      const f32x16 e = half == 0 ? enc_block16_L10<0>(encb, hl, xo, yo, zo) : enc_block16_L10<16>(encb, hl, xo, yo, zo);
+      float v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = e0[r];
-        hs[0] = split8h(v, mult);
+      for (int r = 0; r < 8; ++r) v[r] = e[r];
+      hs[2 * half] = split8h(v, mult);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = e0[8 + r];
-        hs[1] = split8h(v, mult);
-      }
-      {
-        const f32x16 e1 = enc_block16_L10<16>(encb, hl, xo, yo, zo);
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = e1[r];
-        hs[2] = split8h(v, mult);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = e1[8 + r];
-        hs[3] = split8h(v, mult);
-      }
+      for (int r = 0; r < 8; ++r) v[r] = e[8 + r];
+      hs[2 * half + 1] = split8h(v, mult);
     };
-    auto split_blocks = [&](const f32x16 (&b)[4], float mult) {  // 128 operands held in four 16-register blocks -> hs[0..7]
+    // the matrix phase of an encoding stage (4 K16-steps x 4 blocks in one segment behind a header): steps 0-1, second half of
+    // the operands, steps 2-3
+#define PP_ENC_MFMA(acc_, s_, mult_)                                                                             \
+  do {                                                                                                           \
+    PP_PRIO_UP();                                                                                                \
+    PP_MFMA_(4, 2, 0, acc_, PP_SLOT_LDS(s_, 0) + 1024u, PP_SLOT_LDS(s_, 1), hs);                                 \
+    PP_PRIO_DOWN();                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    split_enc_half(1, mult_);                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    PP_PRIO_UP();                                                                                                \
+    PP_MFMA_(4, 2, 0, acc_, PP_SLOT_LDS(s_, 0) + 1024u + 8 * H16_UNIT_BYTES, PP_SLOT_LDS(s_, 1), hs + 2);         \
+    PP_PRIO_DOWN();                                                                                              \
+  } while (0)
+    // 128 operands held in four 16-register blocks -> hs[0..7]; with MNERF_PP_DMA_SPREAD the wave's weight requests of the phase
+    // (team A: stage sa, team B: stage sb) go out in front of the first split (three of them) and behind every split (one each)
+    auto split_blocks = [&](const f32x16 (&b)[4], float mult, int sa, int sb) {
+      PP_DMA(sa, sb, 3);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         float v[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = b[m][r];
         hs[2 * m] = split8h(v, mult);
+        PP_DMA(sa, sb, 1);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = b[m][8 + r];
         hs[2 * m + 1] = split8h(v, mult);
+        PP_DMA(sa, sb, 1);
       }
     };
     // dst <- max(acc * film, 0) (dst may be acc itself: the accumulators are dead once the activations exist, and a
@@ -1940,13 +2211,16 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       return fmaxf(mx, __shfl_xor(mx, 32, 64));
     };
     em = gain_exp(enc_max);
-    split_enc(pow2i(em));
+    const float mult_l0 = pow2i(em);
+    PP_DMA(1, 2, 4);
+    split_enc_half(0, mult_l0);
+    PP_DMA(1, 2, 4);
     ew_cur = header_ew(PP_HDR_LDS(1));
     bias_init_h<4>(acc, PP_HDR_LDS(1), hl, pow2i(ew_cur + em));
     ec = -em - ew_cur + ecf;
-    PP_END_V(2);
+    PP_END_V(1, 2);
     // ============================================================ phase 3 = M_1: layer 0
-    PP_MFMA(4, 4, 0, acc, 1, 1024u, hs);
+    PP_ENC_MFMA(acc, 1, mult_l0);
     PP_END_M();
     // ============================================================ layers 1..4: V_s (FiLM, ReLU, gain, split, next biases), M_s
     float hmax;
@@ -1955,11 +2229,11 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_BEGIN_V(ST_);                                                        \
     hmax = film_relu(acc);                                                  \
     em = gain_exp(hmax);                                                    \
-    split_blocks(acc, pow2i(em));                                           \
+    split_blocks(acc, pow2i(em), ST_, (ST_) + 1);                           \
     ew_cur = header_ew(PP_HDR_LDS(ST_));                                    \
     bias_init_h<4>(acc, PP_HDR_LDS(ST_), hl, pow2i(ew_cur + (em - ec)));    \
     ec = ec - em - ew_cur + ecf;                                            \
-    PP_END_V((ST_) + 1);                                                    \
+    PP_END_V(ST_, (ST_) + 1);                                               \
     PP_MFMA(4, 4, 4, acc, ST_, 1024u, hs);            \
     PP_END_M();                                                             \
   } while (0)
@@ -1977,18 +2251,20 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     {
       hmax = film_relu(acc);
       eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
-      split_blocks(acc, pow2i(eg + ec));
+      split_blocks(acc, pow2i(eg + ec), 6, 7);
       ew_cur = header_ew(PP_HDR_LDS(7));
       bias_init_h<4>(acc, PP_HDR_LDS(7), hl, pow2i(ew_cur + eg));
     }
-    PP_END_V(7);
+    PP_END_V(6, 7);
     PP_MFMA(4, 4, 4, acc, 6, 0u, hs);  // M_6: W5[:, enc:] . h
     PP_END_M();
     PP_BEGIN_V(7);
-    split_enc(pow2i(eg));  // V_7: the encoding operands, re-evaluated
+    const float mult_l5 = pow2i(eg);
+    PP_DMA(7, 8, 4);
+    split_enc_half(0, mult_l5);  // V_7: the encoding operands, re-evaluated (first half; the second one inside M_7)
     ec = -eg - ew_cur + ecf;
-    PP_END_V(8);
-    PP_MFMA(4, 4, 0, acc, 7, 1024u, hs);  // M_7: += W5[:, :enc] . enc
+    PP_END_V(7, 8);
+    PP_ENC_MFMA(acc, 7, mult_l5);  // M_7: += W5[:, :enc] . enc
     PP_END_M();
 #else
     // ============================================================ layer 5 = [enc, h] -> 128 (stages 6: enc part, 7: h part)
@@ -2000,18 +2276,19 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       hmax = film_relu(h5);
       eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
       __builtin_amdgcn_sched_barrier(0);  // three separate steps: activations (64 registers), encoding operands, then the
-      split_enc(pow2i(eg));               // accumulators' biases — interleaved by the scheduler they do not fit 256 registers
+      split_enc_half(0, pow2i(eg));       // accumulators' biases — interleaved by the scheduler they do not fit 256 registers
+      split_enc_half(1, pow2i(eg));
       __builtin_amdgcn_sched_barrier(0);
       ew_cur = header_ew(PP_HDR_LDS(6));
       bias_init_h<4>(acc, PP_HDR_LDS(6), hl, pow2i(ew_cur + eg));
     }
-    PP_END_V(7);
+    PP_END_V(6, 7);
     PP_MFMA(4, 4, 0, acc, 6, 1024u, hs);  // M_6
     PP_END_M();
     PP_BEGIN_V(7);
-    split_blocks(h5, pow2i(eg + ec));  // V_7
+    split_blocks(h5, pow2i(eg + ec), 7, 8);  // V_7
     ec = -eg - ew_cur + ecf;
-    PP_END_V(8);
+    PP_END_V(7, 8);
     PP_MFMA(4, 4, 4, acc, 7, 0u, hs);  // M_7
     PP_END_M();
 #endif
@@ -2019,11 +2296,11 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_BEGIN_V(8);
     hmax = film_relu(acc);  // V_8
     const int em5 = gain_exp(hmax);
-    split_blocks(acc, pow2i(em5));
+    split_blocks(acc, pow2i(em5), 8, 9);
     f32x16 al[1];
     const int ew_a = header_ew(PP_HDR_LDS(8));
     bias_init_h<1>(al, PP_HDR_LDS(8), hl, pow2i(ew_a + em5 - ec));
-    PP_END_V(9);
+    PP_END_V(8, 9);
     PP_MFMA1(8, al, 8, 1024u, hs);  // M_8: alpha head 128 -> 16
     PP_END_M();
     float av[8];
@@ -2045,7 +2322,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       bias_init_h<4>(acc, PP_HDR_LDS(9), hl, pow2i(ew_cur + (em5 - ec)));
     }
     const int ecfeat = ec - em5 - ew_cur;
-    PP_END_V(10);
+    PP_END_V(9, 10);
     PP_MFMA(4, 4, 4, acc, 9, 1024u, hs);  // M_9: feature_linear 128 -> 128, no activation
     PP_END_M();
     // ============================================================ views_linear (stage 10): [feat, dir] -> 64
@@ -2068,14 +2345,14 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         dz = ux * view0.extr[8] + uy * view0.extr[9] + uz * view0.extr[10];
       }
       egv = gain_exp(fmaxf(1.0f, sample_absmax<4>(acc) * pow2i(ecfeat)));
-      split_blocks(acc, pow2i(egv + ecfeat));
+      split_blocks(acc, pow2i(egv + ecfeat), 10, 11);
       const float v[8] = {hl ? 0.0f : dx, hl ? 0.0f : dy, hl ? 0.0f : dz, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       hsd = split8h(v, pow2i(egv));
       const int ew = header_ew(PP_HDR_LDS(10));
       bias_init_h<2>(hv, PP_HDR_LDS(10), hl, pow2i(ew + egv));
       ecv = -egv - ew;
     }
-    PP_END_V(11);
+    PP_END_V(10, 11);
     PP_MFMA(2, 4, 4, hv, 10, 1024u, hs);  // M_10
     ksteps_presplit<2, 1>(hv, PP_SLOT_LDS(10, 1) + 8 * H16_UNIT_BYTES, lane, &hsd);
     PP_END_M();
@@ -2104,7 +2381,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       bias_init_h<1>(c3, PP_HDR_LDS(11), hl, pow2i(ew + emr - ecv));
       cc = pow2i(ecv - emr - ew);
     }
-    PP_END_V(-1);
+    PP_END_V(11, -1);
     {  // M_11
       PP_MFMA1(4, c3, 11, 1024u, hs);
       if (hl == 0) {
@@ -2121,7 +2398,15 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         }
       }
     }
-    PP_END_M();
+    // From here to the end of T4 a team only exchanges data with itself.  Team A leaves M_11 through the workgroup barrier
+    // that team B leaves V_11 through (the last lock-step hand-over of the tile); team B's M_11 ends at its own team sync
+    // (its attention scratch is ring slot 2: the rgb weights every wave of the team has just finished reading).
+    if (team == 1) {
+      segment_wait();
+      PP_TSYNC();
+    } else {
+      PP_SYNC();
+    }
     // ============================================================ phase 24 = T1: q | k | v of the ray transformer -> team scratch
     // The team's conditioning rows of the next tile travel to LDS meanwhile (its half of ring slot 1, free between the views
     // stage and layer 1 of the next tile): phase V_0 then starts from LDS instead of waiting ~8 k cycles for global loads.
@@ -2154,7 +2439,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       *reinterpret_cast<float4*>(q_lds + s_local * 16 + head * 4) =
           make_float4(qkv[0][4 * hh] * qs, qkv[0][4 * hh + 1] * qs, qkv[0][4 * hh + 2] * qs, qkv[0][4 * hh + 3] * qs);
     }
-    PP_SYNC();
+    PP_TSYNC();
     // ============================================================ phase 25 = T2: ray attention on the matrix pipe (lane = query)
     {
       int a_ray, a_hp, a_jq;
@@ -2171,75 +2456,10 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         a_hp = lane >> 5;
         a_jq = lane & 31;
       }
-      const int s_q = a_ray * Sp + a_jq;
-      constexpr int HEAD_UNROLL = SP >= 128 ? 1 : 2;
-#pragma unroll HEAD_UNROLL
-      for (int hh = 0; hh < 2; ++hh) {
-        const int head = 2 * a_hp + hh;
-        const float4 q4 = *reinterpret_cast<const float4*>(q_lds + s_q * 16 + head * 4);
-        const float* kb = k_lds + ((a_ray * 4 + head) * Sp + (lane & 3)) * 4;
-        f32x4 sc[SP / 4];
-#pragma unroll
-        for (int g = 0; g < SP / 4; ++g) {
-          const float4 kk = *reinterpret_cast<const float4*>(kb + g * 16);
-          f32x4 t = {0.f, 0.f, 0.f, 0.f};
-          t = mfma4(kk.x, q4.x, t);
-          t = mfma4(kk.y, q4.y, t);
-          t = mfma4(kk.z, q4.z, t);
-          t = mfma4(kk.w, q4.w, t);
-          sc[g] = t;
-        }
-        float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-        if (S == Sp) {
-#pragma unroll
-          for (int g = 0; g < SP / 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[g][r]);
-        } else {
-          int s_keys = S;
-          asm volatile("" : "+s"(s_keys));
-#pragma unroll
-          for (int g = 0; g < SP / 4; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float v = (4 * g + r < s_keys) ? sc[g][r] : -3.0e38f;
-              sc[g][r] = v;
-              mx4[r] = fmaxf(mx4[r], v);
-            }
-        }
-        const float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
-        float ls4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < SP / 4; ++g)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(sc[g][r] - mx);
-            sc[g][r] = pr;
-            ls4[r] += pr;
-          }
-        const float lsum = (ls4[0] + ls4[1]) + (ls4[2] + ls4[3]);
-        const float* vb = vt_lds + ((a_ray * 4 + head) * 4 + (lane & 3)) * Sp;
-        f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < SP / 4; g += 2) {
-          const float4 va = *reinterpret_cast<const float4*>(vb + 4 * g);
-          const float4 vc = *reinterpret_cast<const float4*>(vb + 4 * g + 4);
-          oa = mfma4(va.x, sc[g][0], oa);
-          ob = mfma4(vc.x, sc[g + 1][0], ob);
-          oa = mfma4(va.y, sc[g][1], oa);
-          ob = mfma4(vc.y, sc[g + 1][1], ob);
-          oa = mfma4(va.z, sc[g][2], oa);
-          ob = mfma4(vc.z, sc[g + 1][2], ob);
-          oa = mfma4(va.w, sc[g][3], oa);
-          ob = mfma4(vc.w, sc[g + 1][3], ob);
-        }
-        const float il = 1.0f / lsum;
-        *reinterpret_cast<float4*>(o_lds + s_q * 16 + head * 4) =
-            make_float4((oa[0] + ob[0]) * il, (oa[1] + ob[1]) * il, (oa[2] + ob[2]) * il, (oa[3] + ob[3]) * il);
-      }
+      ray_attention_pp<SP>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
     }
     segment_wait();  // the team's rows of the next tile
-    PP_SYNC();
+    PP_TSYNC();
     // ============================================================ phase 26 = T3: fc + residual + LayerNorm, density head
     {
       float ofc[8];
@@ -2300,7 +2520,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     }
     // team B requests stage 0 of the next tile (ring slot 0: the views weights were last read four steps ago)
     if (team == 1 && has_next) stage_dma(0, 2);
-    PP_SYNC();
+    PP_TSYNC();
     // ============================================================ phase 27 = T4: compositing (one wavefront per ray)
     for (int rt = tw; rt < rays_per_team; rt += 4) {
       const int rr = tile * rays_per_tile + team * rays_per_team + rt;
@@ -2358,13 +2578,28 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       }
     }
     rows_in_lds = next_rows;
-    PP_END_M();
+    // Team A goes straight on to V_0 of its next tile (inputs from its own rows in LDS, no weights) and meets team B at the
+    // end of that phase; team B's T4 ends at that same workgroup barrier, behind its wait for stage 0 of the next tile.
+    if (team == 1) {
+      segment_wait();
+      PP_SYNC();
+    } else {
+      PP_NOSYNC();
+    }
   }
   if (team == 0) __syncthreads();  // team A's matching last barrier
 #undef PP_END_V
+#undef PP_DMA
 #undef PP_BEGIN_V
 #undef PP_END_M
 #undef PP_SYNC
+#undef PP_TSYNC
+#undef PP_NOSYNC
+#undef PP_STAMPED
+#undef PP_ENC_MFMA
+#undef PP_MFMA_
+#undef PP_PRIO_UP
+#undef PP_PRIO_DOWN
 #undef PP_MFMA
 #undef PP_MFMA1
 #undef PP_HDR_LDS
@@ -2590,7 +2825,11 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
       // the kernel's compile-time piece counts must be the schedule's
       MNERF_REQUIRE((sch.seg_floats[first[i]] >> 8) == pp_p0(i) && (nseg[i] == 2 ? (sch.seg_floats[first[i] + 1] >> 8) : 0) == pp_p1(i),
                     MNERF_E_RANGE, "%s: weight schedule does not match the ping-pong kernel (stage %d)", who, i);
+      MNERF_REQUIRE(first[i] == pp_seg_first(i), MNERF_E_RANGE, "%s: stage table of the ping-pong kernel (stage %d)", who, i);
     }
+    for (int k = 0; k < 20; ++k)  // the kernel addresses the stream with compile-time offsets
+      MNERF_REQUIRE(sch.seg_off[k] == pp_stream_off_floats(k) && (sch.seg_floats[k] >> 8) == pp_stream_pieces(k), MNERF_E_RANGE,
+                    "%s: weight stream layout does not match the ping-pong kernel (segment %d)", who, k);
     const int rpt = 256 / Sp;
     const int tiles = (rays->n_rays + rpt - 1) / rpt;
     const int cus = mnerf_tune().decoder_pp_grid > 0 ? mnerf_tune().decoder_pp_grid : 1;  // persistent: one 8-wave workgroup per CU

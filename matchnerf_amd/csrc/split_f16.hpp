@@ -74,6 +74,31 @@ __device__ __forceinline__ void glds16_s_stream(const float* uniform_src, unsign
 
 __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ---- a barrier for a SUBSET of the workgroup's waves (gfx950 has one hardware barrier per workgroup and no named barriers):
+// a monotonic counter in LDS.  Every wave of the group (n_waves of them) calls it the same number of times; `epoch` is the
+// wave's own count of arrivals so far (kept in a scalar register by the caller, starts at 0, counter zeroed before first use).
+//   arrive: all LDS traffic of this wave has completed (lgkmcnt(0): LDS executes a wave's operations in order, so its writes are
+//           visible and its reads have their data), then lane 0 adds 1;
+//   wait:   poll the counter (one ds_read_b32 + s_sleep per round: the SIMD's other wave keeps the issue slots) until it has
+//           reached n_waves x calls.
+// Outstanding VMEM / LDS-DMA traffic is NOT waited for (the ping-pong decoder keeps weight and row DMAs in flight across these
+// syncs; data that arrives by DMA is published by the issuing wave's own segment_wait() before it arrives here).
+// Everything is asm volatile with a memory clobber: the compiler moves no LDS access across it.
+__device__ __forceinline__ void wave_group_sync(unsigned ctr_lds_byte_addr, int n_waves, int& epoch, int lane) {
+  epoch += n_waves;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) {
+    const unsigned one = 1u;
+    asm volatile("ds_add_u32 %0, %1" ::"v"(ctr_lds_byte_addr), "v"(one) : "memory");
+  }
+  for (;;) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ctr_lds_byte_addr) : "memory");
+    if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)epoch) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // ---------------------------------------------------------------- split-fp16 matrix path ("f16x3", FMT = 2)
 // Same chain on v_mfma_f32_32x32x16_f16 with TWO fp16 terms per operand and THREE products per MAC
 // (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is < 2^-22 of the product): half the matrix instructions of
@@ -105,17 +130,34 @@ __device__ __forceinline__ float resid_hi(float v, float mult, unsigned hpk) {
   return r;
 }
 
-// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: 5 VALU ops per pair of values
-// (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32)
+// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: FOUR vector instructions per pair of
+// values, all of them "mix" FMAs that take fp32 / fp16 sources and write one fp16 half of the destination:
+//   hi.lo16 = f16(v0 * mult + 0)      v_fma_mixlo_f16   (the product with a power of two is exact: one rounding, to fp16)
+//   hi.hi16 = f16(v1 * mult + 0)      v_fma_mixhi_f16
+//   lo.lo16 = f16(v0 * mult - hi.lo)  v_fma_mixlo_f16   (the residual is exact in fp32: again one effective rounding)
+//   lo.hi16 = f16(v1 * mult - hi.hi)  v_fma_mixhi_f16
+// Rounds 1-3 spent 5 (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32), and 6 once packed fp32 was banned
+// from the library (build.py: NO_PACKED_F32); same values bit for bit (tests/test_pack_decoder.py emulates exactly these
+// roundings).  -DMNERF_SPLIT_CVT restores the conversion form.
 __device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
   u32x4 H, L;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+#ifdef MNERF_SPLIT_CVT
     const f32x2 ab = {v[2 * i] * mult, v[2 * i + 1] * mult};
     const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2));  // v_cvt_pk_f16_f32
     const f32x2 r = {resid_lo(v[2 * i], mult, h), resid_hi(v[2 * i + 1], mult, h)};
     H[i] = h;
     L[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+#else
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(v[2 * i]), "v"(mult));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(v[2 * i + 1]), "v"(mult));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(v[2 * i]), "v"(mult), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(v[2 * i + 1]), "v"(mult), "v"(h));
+    H[i] = h;
+    L[i] = l;
+#endif
   }
   PartsH p;
   p.hi = __builtin_bit_cast(f16x8, H);

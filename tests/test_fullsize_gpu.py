@@ -54,6 +54,26 @@ def test_ten_source_views_match_oracle():
     assert linf(out.depth, ref["depth"]) < 3e-4
 
 
+@pytest.mark.parametrize("n_views", [10, 7])
+def test_pair_blocked_cost_volume_is_bit_identical_to_one_launch(n_views):
+    """From 6 views on the cost volume runs one launch per block of view pairs (cv_walk.hpp "PAIR BLOCKS"); the per-sample
+    cosine sums travel through the rows between the blocks as raw sums and are accumulated pair by pair in the same order:
+    the rendered frame and the conditioning rows are bit-identical for every block size, including ragged last blocks."""
+    from matchnerf_amd import hip
+    opt, model, sd = build(n_views=n_views, S=40)
+    scene = syn.make_scene(32, 48, n_views, seed=23)
+    batch = gpu_batch(scene)
+    frames = {}
+    with torch.no_grad():
+        for blk in (0, 8, 4, 7, 1):  # 0: all pairs in one launch (the round-3 form)
+            with hip.knob("cv_pair_block", blk):
+                out = model(batch, mode="test")
+                frames[blk] = (out.rgb.clone(), out.depth.clone(), out.opacity.clone())
+    for blk, fr in frames.items():
+        for a, b in zip(fr, frames[0]):
+            assert torch.equal(a, b), f"pair block {blk}"
+
+
 def test_blender_like_128_samples_match_oracle():
     opt, model, sd = build(n_views=3, S=128)
     model.nerf_setbg_opaque = True

@@ -35,5 +35,6 @@ with torch.no_grad():
     ms = (time.perf_counter() - t0) / frames * 1e3
 k = timer.summary()
 knobs = {n: os.environ[n] for n in os.environ if n.startswith("MNERF_")}
+bits = int(out.rgb.contiguous().view(torch.int32).to(torch.int64).sum()) & 0xffffffffffff  # equal bits <=> (almost surely) equal frames
 print(f"{cfg} {knobs}: frame {ms:.2f} ms, decoder {k['decoder']['total_ms'] / frames:.2f}, cost volume {k['cost_volume']['total_ms'] / frames:.2f}, "
-      f"rgb mean {float(out.rgb.mean()):.6f}")
+      f"rgb mean {float(out.rgb.mean()):.6f} bits {bits:012x}")
