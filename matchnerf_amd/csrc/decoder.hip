@@ -1891,12 +1891,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   }
   segment_wait();
   __syncthreads();
-  // Static issue priority for team B.  Waves 4-7 are dispatched second, and between two waves of a SIMD at equal priority
-  // the OLDER one wins the vector-issue arbitration: round 4's first timeline had team B's matrix phases at 4.6 k cycles
-  // against team A's 3.85 k, its T2 at 12.6 k against 9.9 k.  One s_setprio for the whole kernel, no per-phase flips
-  // (MI355X_MICROARCH.md "two waves per SIMD", item 4).  MNERF_PP_BPRIO=0 switches it off.
+  // Static issue priority for team B (experiment, MNERF_PP_BPRIO=1; default off).  Waves 4-7 are dispatched second, and between
+  // two waves of a SIMD at equal priority the OLDER one wins the vector-issue arbitration: round 4's first timeline had team
+  // B's matrix phases at 4.6 k cycles against team A's 3.85 k, its T2 at 12.6 k against 9.9 k.  One s_setprio for the whole
+  // kernel, no per-phase flips (MI355X_MICROARCH.md "two waves per SIMD", item 4).  MEASURED: priority only moves the loss to the
+  // other team (B's matrix phases 3.75 k, A's T2 16.9 k against B's 8.5 k): 18.99 vs 18.82 ms per frame, no gain.
 #ifndef MNERF_PP_BPRIO
-#define MNERF_PP_BPRIO 1
+#define MNERF_PP_BPRIO 0
 #endif
   if (MNERF_PP_BPRIO && team == 1) __builtin_amdgcn_s_setprio(MNERF_PP_BPRIO);
   if (team == 1) __syncthreads();  // team B runs one phase behind team A from here on
@@ -1957,11 +1958,14 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   // ---- weight requests of a vector phase.  MNERF_PP_DMA_SPREAD = 0 (round 3): team A asks for its half of stage s (the odd
   // 1-KiB pieces) in one burst at the START of V_s, team B for its half of stage s+1 (the even ones) in one burst at the END of
   // its V_s; the LDS-DMA queue drains ~1 piece per 90 cycles, so a wave's burst of 8 stalls it ~1.6 k cycles in which it does
-  // nothing else.  = 1 (default): the requests are SPREAD over the phase, a few behind the FiLM / ReLU pass and one behind every
+  // nothing else.  = 1 (experiment): the requests are SPREAD over the phase, a few behind the FiLM / ReLU pass and one behind every
   // operand split, so that the queue drains under the wave's own vector work (PP_DMA sites; what is left goes out at the end).
   // A wave's share of a stage is at most 10 requests: k -> segment k / 5, piece 2 tw + half + 8 (k % 5).
+  // MEASURED (gpurun_out r4b, profiles/r4_variants.md): slower. Every request still stalls its wave (the queue is full whenever
+  // eight waves feed it), now ten times per phase behind a scheduling fence each: vector phases 3.9 k -> 4.7 k cycles, decoder
+  // 18.2 -> 19.0 ms per frame.  The bursts stay.
 #ifndef MNERF_PP_DMA_SPREAD
-#define MNERF_PP_DMA_SPREAD 1
+#define MNERF_PP_DMA_SPREAD 0  // measured (round 4, same box): spread 18.99 ms per frame, bursts 18.20 - see below
 #endif
   int dma_k = 0;  // requests of the current vector phase already made by this wave (compile-time after unrolling)
   auto stage_piece = [&](int s, int half, int k) {
@@ -2007,6 +2011,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   do {                                        \
     if (team == 0) stage_dma(stage_, 1);      \
   } while (0)
+  (void)dma_some;
 #define PP_DMA(sa_, sb_, n_) do {} while (0)
 #define PP_END_V(sa_, next_stage_)                                  \
   do {                                                              \

@@ -130,20 +130,19 @@ __device__ __forceinline__ float resid_hi(float v, float mult, unsigned hpk) {
   return r;
 }
 
-// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: FOUR vector instructions per pair of
-// values, all of them "mix" FMAs that take fp32 / fp16 sources and write one fp16 half of the destination:
-//   hi.lo16 = f16(v0 * mult + 0)      v_fma_mixlo_f16   (the product with a power of two is exact: one rounding, to fp16)
-//   hi.hi16 = f16(v1 * mult + 0)      v_fma_mixhi_f16
-//   lo.lo16 = f16(v0 * mult - hi.lo)  v_fma_mixlo_f16   (the residual is exact in fp32: again one effective rounding)
-//   lo.hi16 = f16(v1 * mult - hi.hi)  v_fma_mixhi_f16
-// Rounds 1-3 spent 5 (v_pk_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32), and 6 once packed fp32 was banned
-// from the library (build.py: NO_PACKED_F32); same values bit for bit (tests/test_pack_decoder.py emulates exactly these
-// roundings).  -DMNERF_SPLIT_CVT restores the conversion form.
+// v * mult (mult a power of two) -> fp16 hi (RNE) + fp16 lo of the exact fp32 residual: 6 VALU ops per pair of values
+// (2 x v_mul_f32, v_cvt_pk_f16_f32, 2 x v_fma_mix_f32, v_cvt_pk_f16_f32; 5 with v_pk_mul_f32 before packed fp32 was banned from
+// the library, build.py: NO_PACKED_F32).
+// -DMNERF_SPLIT_MIX: the same values (bit for bit, measured) from FOUR "mix" FMAs per pair that write one fp16 half each,
+//   hi.lo16 = f16(v0 * mult + 0)  v_fma_mixlo_f16      lo.lo16 = f16(v0 * mult - hi.lo)  v_fma_mixlo_f16
+//   hi.hi16 = f16(v1 * mult + 0)  v_fma_mixhi_f16      lo.hi16 = f16(v1 * mult - hi.hi)  v_fma_mixhi_f16
+// 1 000 fewer vector instructions per decoder tile - and SLOWER on MI355X: 18.99 vs 18.51 ms per frame (the half-writing forms
+// are read-modify-write on their destination and evidently cost more than one issue slot).  Kept as a build-time experiment.
 __device__ __forceinline__ PartsH split8h(const float (&v)[8], float mult) {
   u32x4 H, L;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-#ifdef MNERF_SPLIT_CVT
+#ifndef MNERF_SPLIT_MIX
     const f32x2 ab = {v[2 * i] * mult, v[2 * i + 1] * mult};
     const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, f16x2));  // v_cvt_pk_f16_f32
     const f32x2 r = {resid_lo(v[2 * i], mult, h), resid_hi(v[2 * i + 1], mult, h)};
