@@ -1693,13 +1693,40 @@ __device__ __host__ constexpr int pp_p1(int s) {
 }
 
 
+// ---- wave-level reductions / scan of the compositing phase WITHOUT LDS round trips (MNERF_PP_T4_DPP).  __shfl_xor / __shfl_up
+// are ds_bpermute_b32: every one of the ~40 exchanges of a ray's compositing (exclusive transmittance scan + five sums) is an
+// LDS access of ~100 cycles that the next one depends on.  DPP row operations exchange inside a row of 16 lanes in the vector
+// ALU itself; rows are joined by row_bcast (scan) or four v_readlane (sums).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get0(float v) {  // the source lane's value, 0 where the row is masked / the source is outside
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {  // total over the 64 lanes (wave-uniform)
+  v = dpp_group_sum<16>(v);  // every lane: the sum of its row
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ float wave_exclusive_sum_dpp(float v) {  // lane l: v[0] + .. + v[l-1]
+  float x = dpp_get0<0x138>(v);           // wave_shr:1, lane 0 <- 0
+  x += dpp_get0<0x111>(x);                // row_shr:1
+  x += dpp_get0<0x112>(x);                // row_shr:2
+  x += dpp_get0<0x114>(x);                // row_shr:4
+  x += dpp_get0<0x118>(x);                // row_shr:8     -> inclusive scan inside every row
+  x += dpp_get0<0x142, 0xA>(x);           // row_bcast:15 into rows 1, 3
+  x += dpp_get0<0x143, 0xC>(x);           // row_bcast:31 into rows 2, 3
+  return x;
+}
+
 // Ray attention of the ping-pong kernel (phase T2): the arithmetic of decoder_kernel's MFMA form, every accumulator fed in the same
 // order (bit-identical), but written so that no matrix instruction waits for its predecessor: the chains of TWO key groups (and,
 // for S <= 64, of the wave's TWO heads) are interleaved — v_mfma_f32_4x4x1 is a 2-pass instruction, and as 4-long dependent
 // chains issued one group after the other (round 3) every instruction paid the full pipeline latency plus a register copy —,
 // and the softmax numerators of a group pair (v_exp_f32: quarter rate, the bound of this phase) are evaluated right in front of
 // that pair's output products, which then run under the next pair's exponentials.
-template <int SP>
+// PADDED = false: S == SP, no masked key slots.  A template parameter, not a run-time test inside: with `if (S == SP)` around the
+// maxima the compiler if-converted the two cases into ONE stream that evaluated the padded-key selects always — 128 v_cndmask +
+// 128 v_mov + 256 scalar compare / select instructions per wave next to 128 exponentials, in the unpadded case too.
+template <int SP, bool PADDED>
 __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float* k_lds, const float* vt_lds, float* o_lds,
                                                  int a_ray, int a_hp, int s_q, int lane, int S) {
   constexpr int G = SP / 4;
@@ -1753,7 +1780,7 @@ __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
       float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-      if (S == SP) {
+      if constexpr (!PADDED) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -2026,6 +2053,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_SYNC();                       \
   } while (0)
   // M_s: stage s's matrix instructions (+ team A: the requests for stage NXT_)
+#ifndef MNERF_PP_T4_DPP
+#define MNERF_PP_T4_DPP 0  // 1: compositing scan / sums through DPP row operations instead of ds_bpermute shuffles (see wave_sum_dpp)
+#endif
 #ifndef MNERF_PP_PAIRS
 #define MNERF_PP_PAIRS 0  // 1: the two blocks of a pair interleaved, no back-to-back dependent MFMAs (measured: no faster, more spills)
 #endif
@@ -2461,7 +2491,10 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         a_hp = lane >> 5;
         a_jq = lane & 31;
       }
-      ray_attention_pp<SP>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
+      if (S == Sp)
+        ray_attention_pp<SP, false>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
+      else
+        ray_attention_pp<SP, true>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
     }
     segment_wait();  // the team's rows of the next tile
     PP_TSYNC();
@@ -2549,6 +2582,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
             c.w = c.w * (intv * rlen);
           }
         }
+#if MNERF_PP_T4_DPP
+        const float excl = carry + wave_exclusive_sum_dpp(c.w);
+#else
         float incl = __shfl_up(c.w, 1, 64);
         if (lane == 0) incl = 0.0f;
 #pragma unroll
@@ -2557,14 +2593,26 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
           if (lane >= off) incl += t;
         }
         const float excl = carry + incl;
+#endif
         const float w = ok ? expf(-excl) * (1.0f - expf(-c.w)) : 0.0f;
         ar += w * c.x;
         ag += w * c.y;
         ab += w * c.z;
         ad += w * dd;
         ao += w;
+#if MNERF_PP_T4_DPP
+        carry = __builtin_amdgcn_readlane(excl + c.w, 63);
+#else
         carry = __shfl(excl + c.w, 63, 64);
+#endif
       }
+#if MNERF_PP_T4_DPP
+      ar = wave_sum_dpp(ar);
+      ag = wave_sum_dpp(ag);
+      ab = wave_sum_dpp(ab);
+      ad = wave_sum_dpp(ad);
+      ao = wave_sum_dpp(ao);
+#else
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         ar += __shfl_xor(ar, off, 64);
@@ -2573,6 +2621,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         ad += __shfl_xor(ad, off, 64);
         ao += __shfl_xor(ao, off, 64);
       }
+#endif
       if (lane == 0) {
         const float bg = D.setbg_opaque ? (1.0f - ao) : 0.0f;
         out_rgb[(size_t)rr * 3 + 0] = ar + bg;

@@ -271,6 +271,52 @@ __device__ __forceinline__ void ksteps_presplit(f32x16 (&acc)[NMB], unsigned bas
 #ifndef MNERF_PP_DEPTH
 #define MNERF_PP_DEPTH 2  // units of look-ahead of the fragment reads (each unit in flight holds 8 registers)
 #endif
+#ifndef MNERF_PP_GROUP2
+#define MNERF_PP_GROUP2 0  // experiment: the fragments of TWO units requested together (4 ds_read_b128 every second unit): half as
+#endif                     // many interruptions of the matrix-instruction stream, each twice as long
+#if MNERF_PP_GROUP2
+template <int NMB, int NS0, int NS1>
+__device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
+                                                 const PartsH* b) {
+  constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB, NP = (N + 1) / 2;
+  lds_u32x4_cptr a0 = (lds_u32x4_cptr)(size_t)base0_lds + lane;
+  lds_u32x4_cptr a1 = (lds_u32x4_cptr)(size_t)base1_lds + lane;
+  u32x4 fh[2][2], fl[2][2];  // [pair buffer][unit of the pair]
+  auto fetch = [&](int pr, int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * pr + q;
+      if (i >= N) break;
+      if (i < N0) {
+        fh[buf][q] = a0[i * 128];
+        fl[buf][q] = a0[i * 128 + 64];
+      } else {
+        fh[buf][q] = a1[(i - N0) * 128];
+        fl[buf][q] = a1[(i - N0) * 128 + 64];
+      }
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    if (pr + 1 < NP) fetch(pr + 1, (pr + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int bf = pr & 1;
+    asm volatile("" : "+v"(fh[bf][0]), "+v"(fl[bf][0]), "+v"(fh[bf][1]), "+v"(fl[bf][1]));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = 2 * pr + q;
+      if (i >= N) break;
+      const int u = i / NMB, m = i % NMB;
+      const f16x8 ah = __builtin_bit_cast(f16x8, fh[bf][q]), al = __builtin_bit_cast(f16x8, fl[bf][q]);
+      acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
+      acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
+      acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+#else
 template <int NMB, int NS0, int NS1>
 __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
                                                  const PartsH* b) {
@@ -306,6 +352,7 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+#endif  // MNERF_PP_GROUP2
 
 // The same again with the two output blocks of a pair (m, m+1) interleaved: a0 a1 a0 a1 a0 a1 instead of a0 a0 a0 a1 a1 a1,
 // so that no matrix instruction has the accumulator of its predecessor (every accumulator still receives its three products

@@ -384,6 +384,18 @@ class UpSampler(nn.Module):
 
 
 _SINE_CACHE = {}
+_PAIR_INDEX_CACHE = {}
+
+
+def _pair_index_tensors(v, device):
+    """view indices (a | b) of the V (V - 1) / 2 pairs as device tensors, built once per (V, device): a host list -> device
+    copy per forward is a pageable-memory transfer, which a stream capture (the encoder graph, matchnerf.py) does not allow"""
+    key = (int(v), str(device))
+    if key not in _PAIR_INDEX_CACHE:
+        pairs = pair_list(v)
+        _PAIR_INDEX_CACHE[key] = (torch.tensor([a for a, _ in pairs], device=device),
+                                  torch.tensor([bb for _, bb in pairs], device=device))
+    return _PAIR_INDEX_CACHE[key]
 
 
 def sine_position_tokens(h, w, channels, device):
@@ -448,8 +460,7 @@ class GMFlow(nn.Module):
             raise ValueError(f"backbone output {tuple(tok.shape[1:])} != expected {(h, w, ch)} for a {hh}x{ww} input")
         tok = tok.reshape(b, v, h * w, ch)
         pairs = pair_list(v)
-        ia = torch.tensor([a for a, _ in pairs], device=tok.device)
-        ib = torch.tensor([bb for _, bb in pairs], device=tok.device)
+        ia, ib = _pair_index_tensors(v, tok.device)
         p_n = len(pairs)
         outs0, outs1 = [], []
         for bi in range(b):

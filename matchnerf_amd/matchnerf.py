@@ -16,6 +16,8 @@ fed by pair-major channel-last feature maps that stay resident in HBM for the wh
 The HIP path is the ONLY path: there is no eager fallback.  Without the shared library or
 without a GPU, rendering raises ``hip.MnerfError`` / ``RuntimeError``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -50,6 +52,8 @@ class MatchNeRF(torch.nn.Module):
             raise NotImplementedError("encoder.feature_sample_local_radius > 0 (gmflow/utils.py:136-162) is not "
                                       "built; every shipped config uses 0 (base.yaml:27)")
         self._ws = None
+        self._enc_graphs = {}     # captured encoder passes (get_img_feat), keyed by input shape and weight versions
+        self.encoder_graph = os.environ.get("MNERF_ENCODER_GRAPH", "1") != "0"
         self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
         self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
@@ -125,8 +129,46 @@ class MatchNeRF(torch.nn.Module):
         (``gmflow.pair_major_to_view_chunks`` converts to the reference's [B,V,(V-1)*128,h,w])."""
         if attn_splits_list is None:
             attn_splits_list = self.opts.encoder.attn_splits_list
-        return self.feat_enc(imgs=imgs[:, :cur_n_src_views], attn_splits_list=attn_splits_list,
-                             wo_self_attn=self.opts.encoder.wo_self_attn)
+        imgs = imgs[:, :cur_n_src_views]
+        if self.encoder_graph and imgs.is_cuda and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+            return self._encoder_graph_replay(imgs, attn_splits_list)
+        return self.feat_enc(imgs=imgs, attn_splits_list=attn_splits_list, wo_self_attn=self.opts.encoder.wo_self_attn)
+
+    def _encoder_graph_replay(self, imgs, attn_splits_list):
+        """The inference encoder as ONE HIP graph launch.  An encoder pass is ~100 short kernels (15 convolutions, 15 norms,
+        12 x (q|k|v, window attention, K7), layout glue): 3.9 ms at 3 x 512 x 640, of which the kernels themselves are ~3.2 —
+        the rest is launch gaps.  Every kernel of the pass is enqueue-only on the current stream (include/mnerf.h), so the
+        pass is captured once per (input shape, attention splits, encoder weights) and replayed: the input is copied into the
+        graph's static buffer, the outputs are CLONED out of it (78 MB at 3 views: ~40 us), so results never alias a later call.
+        A weight update (load_state_dict, an optimizer step) changes the parameters' version counters and thereby the key.
+        MNERF_ENCODER_GRAPH=0 (or .encoder_graph = False) keeps the eager pass; a failed capture falls back to it once and
+        for all with a warning (the kernels are the same either way)."""
+        enc = self.feat_enc
+        splits = tuple(attn_splits_list) if isinstance(attn_splits_list, (list, tuple)) else (attn_splits_list,)
+        wkey = tuple((int(p._version), int(p.data_ptr())) for p in enc.parameters())
+        key = (tuple(imgs.shape), str(imgs.device), splits, bool(self.opts.encoder.wo_self_attn), hash(wkey))
+        entry = self._enc_graphs.get(key)
+        if entry is None:
+            run = lambda x: enc(imgs=x, attn_splits_list=attn_splits_list, wo_self_attn=self.opts.encoder.wo_self_attn)
+            static_in = imgs.clone()
+            run(static_in)  # eager warm-up: weight packing, LDS attributes, cached index / position tensors
+            torch.cuda.synchronize(imgs.device)
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = run(static_in)
+            except Exception as e:  # noqa: BLE001
+                import warnings
+                warnings.warn(f"encoder graph capture failed ({type(e).__name__}: {e}); using the eager encoder pass")
+                self.encoder_graph = False
+                return run(imgs)
+            if len(self._enc_graphs) >= 4:  # a handful of live shapes at most (each graph owns its activations)
+                self._enc_graphs.pop(next(iter(self._enc_graphs)))
+            entry = self._enc_graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = entry
+        static_in.copy_(imgs)
+        graph.replay()
+        return [o.clone() for o in static_out]
 
     # ------------------------------------------------------------------ C-ABI argument structs
     def _scene(self, b, ref_poses_host, ref_feats_list, images_cl, feats_b=None):

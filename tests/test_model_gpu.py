@@ -274,3 +274,32 @@ def test_two_same_shaped_batches_do_not_share_launch_context():
     with torch.no_grad():
         again = model(batch_b, mode="test")
     assert torch.equal(again.rgb, ref_b.rgb)
+
+
+def test_encoder_graph_replay_equals_the_eager_pass_and_follows_weight_updates():
+    """get_img_feat replays a captured HIP graph of the encoder pass at inference (matchnerf.py: _encoder_graph_replay): same
+    kernels, same bits as the eager pass; the outputs are clones (a second call does not overwrite the first result); a
+    parameter update changes the key, so the next call re-captures and again equals the eager pass."""
+    g, cfg, sd, _ = golden_case("c1_default")
+    opt, model = build_model(g["meta"])
+    batch = to_batch(g)
+    imgs = batch.images[:, :3]
+    with torch.no_grad():
+        model.encoder_graph = False
+        eager = [f.clone() for f in model.get_img_feat(imgs, cur_n_src_views=3)]
+        model.encoder_graph = True
+        first = model.get_img_feat(imgs, cur_n_src_views=3)      # warm-up + capture + replay
+        assert model.encoder_graph and len(model._enc_graphs) == 1, "capture failed"
+        second = model.get_img_feat(imgs.flip(-1).contiguous(), cur_n_src_views=3)  # another input through the same graph
+        third = model.get_img_feat(imgs, cur_n_src_views=3)
+        for a, b, c in zip(eager, first, third):
+            assert torch.equal(a, b) and torch.equal(a, c)
+        assert not torch.equal(first[0], second[0])
+        # a weight update: new key, new capture, still the eager pass's bits
+        model.feat_enc.transformer.layers[0].self_attn.q_proj.weight.mul_(1.01)
+        upd = model.get_img_feat(imgs, cur_n_src_views=3)
+        assert len(model._enc_graphs) == 2 and not torch.equal(upd[0], eager[0])
+        model.encoder_graph = False
+        eager2 = model.get_img_feat(imgs, cur_n_src_views=3)
+        for a, b in zip(upd, eager2):
+            assert torch.equal(a, b)
