@@ -325,6 +325,18 @@ int mnerf_qkv_window_images(const float* wstream, const int32_t* ew, const float
 int mnerf_window_attention_images(const float* q, float* out, int32_t batch, int32_t h, int32_t w, int32_t num_splits,
                                   int32_t shifted, const void* workspace, size_t workspace_bytes, void* stream);
 
+/* K6 backward — gradients of the (shifted-)window attention (what `loss.backward()` does to
+ * models/gmflow/transformer.py:46-105 in coach.py:215-243), flash style: the [windows, L_w, L_w] score tensor is never
+ * materialised.  q, k, v, out (the forward's result), g_out (gradient of `out`): [batch, h*w, 128] fp32; g_q, g_k, g_v
+ * (same shape) are OVERWRITTEN.  Exact-fp32 matrix products, no atomics (deterministic).  `workspace`: at least
+ * mnerf_window_attention_backward_workspace_bytes(batch, h, w) bytes (three floats per token: row maximum, row sum of
+ * exponentials, <g_out, out>). */
+int64_t mnerf_window_attention_backward_workspace_bytes(int32_t batch, int32_t h, int32_t w);
+int mnerf_window_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* g_out,
+                                    float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,
+                                    int32_t num_splits, int32_t shifted, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* InstanceNorm2d (no affine, biased variance, as torch.nn.functional.instance_norm) of an NCHW tensor fused with what
  * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):
  *   v = (x - mean_plane) / sqrt(var_plane + eps);  if relu_inner: v = max(v, 0);

@@ -3,11 +3,11 @@
 The reference trains by back-propagating through its eager op chain
 (/root/reference/coach.py:215-243).  Here the FORWARD values of ``mode='train'`` come from
 the same HIP kernels as inference (K1-K6); the BACKWARD uses hand-written HIP
-kernels for the whole ray chunk (compositing, conditional MLP + ray transformer, cost volume) and, where a backward
-kernel does not exist yet (window attention, the encoder), re-evaluates that op with differentiable PyTorch-ROCm ops on the
-GPU (activation-checkpoint style) and back-propagates through the re-evaluation:
+kernels for the whole ray chunk (compositing, conditional MLP + ray transformer, cost volume) and for the window attention;
+where a backward kernel does not exist yet (the rest of the encoder: projections, K7 chain, convolutions) that op runs as
+differentiable PyTorch-ROCm ops on the GPU and back-propagates through them:
 
-* ``window_attention``  — K6 forward, torch roll/split/softmax re-evaluation for grad(q,k,v)
+* ``window_attention``  — K6 forward; backward = mnerf_window_attention_backward (flash style, no score tensor)
 * ``render_ray_chunk``  — K1..K5 forward in HIP; backward = K5 backward kernel (mnerf_composite_backward) ->
   K3+K4 backward (mnerf_decoder_backward: forward re-evaluated from the saved conditioning rows with sample coordinates
   from mnerf_ray_samples — the forward's bits —, exact-fp32 MFMA products) -> K1+K2 backward kernel
@@ -18,6 +18,7 @@ is not a fallback: the forward pass still fails loudly without ``libmnerf_hip.so
 Training-time ray counts are small (``rand_rays_train`` = 1024).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -59,18 +60,28 @@ def _window_attention_torch(q, k, v, h, w, splits, shifted):
 
 
 class _WindowAttentionFn(torch.autograd.Function):
+    """HIP forward (the inference kernel) and HIP backward (mnerf_window_attention_backward: flash style, the
+    [windows, L_w, L_w] score tensor is never built; exact fp32, deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
+    form for comparison: re-evaluation of the op chain with torch ops under autograd (``_window_attention_torch``)."""
+
     @staticmethod
     def forward(ctx, q, k, v, h, w, splits, shifted):
-        ctx.save_for_backward(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = hip.window_attention(q, k, v, h, w, splits, shifted)
+        ctx.save_for_backward(q, k, v, out)
         ctx.geom = (h, w, splits, shifted)
-        return hip.window_attention(q.contiguous(), k.contiguous(), v.contiguous(), h, w, splits, shifted)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        q, k, v = (t.detach().requires_grad_(True) for t in ctx.saved_tensors)
-        with torch.enable_grad():
-            out = _window_attention_torch(q, k, v, *ctx.geom)
-        gq, gk, gv = torch.autograd.grad(out, (q, k, v), grad_out)
+        q, k, v, out = ctx.saved_tensors
+        if os.environ.get("MNERF_WA_BACKWARD", "hip") == "torch":
+            q, k, v = (t.detach().requires_grad_(True) for t in (q, k, v))
+            with torch.enable_grad():
+                re = _window_attention_torch(q, k, v, *ctx.geom)
+            gq, gk, gv = torch.autograd.grad(re, (q, k, v), grad_out)
+        else:
+            gq, gk, gv = hip.window_attention_backward(q, k, v, out, grad_out.contiguous(), *ctx.geom)
         return gq, gk, gv, None, None, None, None
 
 

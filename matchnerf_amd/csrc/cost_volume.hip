@@ -205,6 +205,19 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
   }
 }
 
+// padding of a slot's LDS areas (floats): the stride becomes = 8 (projections) / 4 (cosine sums) mod 32
+#ifndef CVW_NO_PAD
+#define CVW_PAD_UV(n) ((40 - ((n) & 31)) & 31)
+#define CVW_PAD_CS(n) ((36 - ((n) & 31)) & 31)
+#else
+#define CVW_PAD_UV(n) 0
+#define CVW_PAD_CS(n) 0
+#endif
+__host__ __device__ inline size_t cvw_lean_lds_floats(int nslot, int seg, int views_kept, int cs_pad) {
+  const int uv = seg * views_kept * 2, cs = seg * cs_pad;
+  return (size_t)nslot * ((uv + CVW_PAD_UV(uv)) + (seg * 4 + 1) * 4 + (cs + CVW_PAD_CS(cs)));
+}
+
 // ============================================================================ segment walk (stand-alone kernel)
 // The walk itself lives in cv_walk.hpp (shared with the fused ray-chunk kernel); this kernel maps slots to rays.
 template <int CPL, bool UVPAIR = false>
@@ -221,9 +234,14 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
   const int sumG = sc.n_group[0] + (sc.n_scales > 1 ? sc.n_group[1] : 0);
   const int cs_stride = (sumG + 3) & ~3;                            // cosine sums per segment sample in LDS
   // LDS per slot: projections [js][view](u,v) | walk records [js][view a|b][idx|weights] (float4) | cosine sums [js][cs]
-  float* uv_lds = cvw_smem + (size_t)slot * CVW_SEG * V * 2;
-  float4* wrec_lds = reinterpret_cast<float4*>(cvw_smem + (size_t)NSLOT * CVW_SEG * V * 2) + (size_t)slot * CVW_SEG * 4;
-  float* cs_lds = cvw_smem + (size_t)NSLOT * CVW_SEG * (V * 2 + 16) + slot * CVW_SEG * cs_stride;
+  // Every slot's three areas are padded so that the SAME offset in different slots falls into different LDS banks: the four
+  // (eight) slots of a wave read their walk records / projections / cosine sums at the same offsets in the same instruction,
+  // and with slot strides of 96, 256 and 192 floats (all = 0 mod 32) every such access was a 4-way bank conflict
+  // (round-3 PMC: 4.6 conflict cycles per LDS instruction).  CVW_PAD_* floats per slot: strides = 8, 4, 4 mod 32.
+  const int uv_str = CVW_SEG * V * 2 + CVW_PAD_UV(CVW_SEG * V * 2), cs_str = CVW_SEG * cs_stride + CVW_PAD_CS(CVW_SEG * cs_stride);
+  float* uv_lds = cvw_smem + (size_t)slot * uv_str;
+  float4* wrec_lds = reinterpret_cast<float4*>(cvw_smem + (size_t)NSLOT * uv_str) + (size_t)slot * (CVW_SEG * 4 + 1);
+  float* cs_lds = cvw_smem + (size_t)NSLOT * (uv_str + (CVW_SEG * 4 + 1) * 4) + slot * cs_str;
   const int S = R.n_samples;
   const int n_seg = (S + CVW_SEG - 1) / CVW_SEG;
 
@@ -545,9 +563,9 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
     // A workgroup's LDS is NSLOT x SEG x (2 V + 16 + cs) floats: 38 KiB at 3 views (four workgroups per CU, what 128 VGPRs
     // allow), 52 KiB at 10 views (three).  From the view count at which the fourth workgroup no longer fits, the 16-lane form
     // keeps only the current pair's projections (UVPAIR, cv_walk.hpp).
-    bool uvpair = variant == 3 && (size_t)nslot * CVW_SEG * (scene->n_views * 2 + 16 + cs_pad) * sizeof(float) > 40 * 1024;
+    bool uvpair = variant == 3 && cvw_lean_lds_floats(nslot, CVW_SEG, scene->n_views, cs_pad) * sizeof(float) > 40 * 1024;
     if (variant == 3 && mnerf_tune().cv_uvpair >= 0) uvpair = mnerf_tune().cv_uvpair != 0;
-    const size_t lds = (size_t)nslot * CVW_SEG * ((uvpair ? 2 : scene->n_views) * 2 + 16 + cs_pad) * sizeof(float);
+    const size_t lds = cvw_lean_lds_floats(nslot, CVW_SEG, uvpair ? 2 : scene->n_views, cs_pad) * sizeof(float);
     MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
     // the LDS attribute is per device and only ever raised: largest request seen per (variant, device)
     static std::atomic<int> lean_lds_set[3][64];

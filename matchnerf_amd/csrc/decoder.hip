@@ -1706,15 +1706,20 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {  // total over the 64 l
   return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
          (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
-__device__ __forceinline__ float wave_exclusive_sum_dpp(float v) {  // lane l: v[0] + .. + v[l-1]
-  float x = dpp_get0<0x138>(v);           // wave_shr:1, lane 0 <- 0
+// lane l: v[0] + .. + v[l-1].  Only ROW operations (row_shr) and v_readlane: the wave-wide DPP forms of earlier GCN parts
+// (wave_shr:1, row_bcast:15 / :31) assemble for gfx950 but do not work there — the first version of this function, written
+// with them, rendered an all-zero frame (gpurun_out r4d).
+__device__ __forceinline__ float wave_exclusive_sum_dpp(float v, int lane) {
+  float x = dpp_get0<0x111>(v);           // row_shr:1: v[l-1] inside a row, 0 at a row's first lane ..
+  const float c15 = __builtin_amdgcn_readlane(v, 15), c31 = __builtin_amdgcn_readlane(v, 31), c47 = __builtin_amdgcn_readlane(v, 47);
+  x = lane == 16 ? c15 : (lane == 32 ? c31 : (lane == 48 ? c47 : x));  // .. which takes the last lane of the row before
   x += dpp_get0<0x111>(x);                // row_shr:1
   x += dpp_get0<0x112>(x);                // row_shr:2
   x += dpp_get0<0x114>(x);                // row_shr:4
   x += dpp_get0<0x118>(x);                // row_shr:8     -> inclusive scan inside every row
-  x += dpp_get0<0x142, 0xA>(x);           // row_bcast:15 into rows 1, 3
-  x += dpp_get0<0x143, 0xC>(x);           // row_bcast:31 into rows 2, 3
-  return x;
+  const float t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const float t01 = t0 + t1;
+  return x + (lane >= 48 ? t01 + t2 : (lane >= 32 ? t01 : (lane >= 16 ? t0 : 0.0f)));
 }
 
 // Ray attention of the ping-pong kernel (phase T2): the arithmetic of decoder_kernel's MFMA form, every accumulator fed in the same
@@ -2583,7 +2588,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
           }
         }
 #if MNERF_PP_T4_DPP
-        const float excl = carry + wave_exclusive_sum_dpp(c.w);
+        const float excl = carry + wave_exclusive_sum_dpp(c.w, lane);
 #else
         float incl = __shfl_up(c.w, 1, 64);
         if (lane == 0) incl = 0.0f;

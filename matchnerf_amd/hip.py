@@ -27,7 +27,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
 
 
 class MnerfError(RuntimeError):
@@ -158,6 +158,10 @@ def load():
     lib.mnerf_window_attention_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.mnerf_window_attention_presplit.restype = C.c_int
     lib.mnerf_window_attention_presplit.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
+    lib.mnerf_window_attention_backward_workspace_bytes.restype = i64
+    lib.mnerf_window_attention_backward_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.mnerf_window_attention_backward.restype = C.c_int
+    lib.mnerf_window_attention_backward.argtypes = [fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_qkv_wstream_floats.restype = i64
     lib.mnerf_qkv_wstream_floats.argtypes = []
     lib.mnerf_qkv_projection.restype = C.c_int
@@ -575,6 +579,28 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
             check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                              int(bool(shifted)), math, st), "mnerf_window_attention")
     return out
+
+
+def window_attention_backward(q, k, v, out, g_out, h, w, num_splits, shifted, stream=None):
+    """K6 backward (mnerf_window_attention_backward): gradients of q, k, v [B,h*w,128] given the forward's ``out`` and its
+    gradient ``g_out``; flash style (no score tensor), exact fp32, deterministic."""
+    import torch
+    lib = load()
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (g_out, "g_out")):
+        _f32c(t, name)
+    b, n, c = q.shape
+    if c != 128 or n != h * w or any(tuple(t.shape) != (b, n, c) for t in (k, v, out, g_out)):
+        raise MnerfError(f"window_attention_backward: expected five [B,{h * w},128] tensors, got {tuple(q.shape)} ...")
+    g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    nbytes = int(lib.mnerf_window_attention_backward_workspace_bytes(b, h, w))
+    ws = torch.empty(max(nbytes // 4, 4), device=q.device)
+    if stream is not None:
+        ws.record_stream(stream)
+    with _on(q.device, stream) as st:
+        check(lib.mnerf_window_attention_backward(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(g_out), _ptr(g_q), _ptr(g_k), _ptr(g_v),
+                                                  b, h, w, int(num_splits), int(bool(shifted)), C.c_void_p(ws.data_ptr()),
+                                                  ws.numel() * 4, st), "mnerf_window_attention_backward")
+    return g_q, g_k, g_v
 
 
 def qkv_projection(wstream, ews, x_q, x_kv=None, kv_swap=False, stream=None):

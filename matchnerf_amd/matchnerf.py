@@ -53,7 +53,7 @@ class MatchNeRF(torch.nn.Module):
                                       "built; every shipped config uses 0 (base.yaml:27)")
         self._ws = None
         self._enc_graphs = {}     # captured encoder passes (get_img_feat), keyed by input shape and weight versions
-        self.encoder_graph = os.environ.get("MNERF_ENCODER_GRAPH", "1") != "0"
+        self.encoder_graph = os.environ.get("MNERF_ENCODER_GRAPH", "0") == "1"  # opt-in: measured no gain (see _encoder_graph_replay)
         self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
         self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
@@ -135,9 +135,12 @@ class MatchNeRF(torch.nn.Module):
         return self.feat_enc(imgs=imgs, attn_splits_list=attn_splits_list, wo_self_attn=self.opts.encoder.wo_self_attn)
 
     def _encoder_graph_replay(self, imgs, attn_splits_list):
-        """The inference encoder as ONE HIP graph launch.  An encoder pass is ~100 short kernels (15 convolutions, 15 norms,
-        12 x (q|k|v, window attention, K7), layout glue): 3.9 ms at 3 x 512 x 640, of which the kernels themselves are ~3.2 —
-        the rest is launch gaps.  Every kernel of the pass is enqueue-only on the current stream (include/mnerf.h), so the
+        """The inference encoder as ONE HIP graph launch (opt-in: MNERF_ENCODER_GRAPH=1 or .encoder_graph = True).  An encoder
+        pass is ~100 short kernels (15 convolutions, 15 norms, 12 x (q|k|v, window attention, K7), layout glue); the idea was
+        that launch gaps are a sizeable part of its 3.9 ms.  MEASURED (round 4, same box): frame 30.27-30.50 ms with the graph,
+        30.32 without, encoder 3.85 vs 3.89 ms — the host enqueues far enough ahead that the kernels already run back to back;
+        what is left of the 3.9 ms is the kernels themselves.  Kept because it is correct and tested, not because it pays.
+        Every kernel of the pass is enqueue-only on the current stream (include/mnerf.h), so the
         pass is captured once per (input shape, attention splits, encoder weights) and replayed: the input is copied into the
         graph's static buffer, the outputs are CLONED out of it (78 MB at 3 views: ~40 us), so results never alias a later call.
         A weight update (load_state_dict, an optimizer step) changes the parameters' version counters and thereby the key.

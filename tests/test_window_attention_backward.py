@@ -1,0 +1,62 @@
+"""K6 backward (mnerf_window_attention_backward) against float64 autograd through the ORACLE's window attention
+(oracle/matchnerf_oracle.py: window_attention, the per-token restatement of gmflow/transformer.py:46-105 that the goldens pin to
+the reference)."""
+import pytest
+import torch
+
+from oracle import matchnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("b,h,w,splits,shifted", [
+    (2, 16, 24, 2, False),   # 96-token windows: one and a half 64-row tiles
+    (2, 16, 24, 2, True),    # wrap-region mask
+    (1, 12, 20, 1, False),   # one window = the whole map (global attention), 240 tokens
+    (3, 24, 24, 2, True),    # 144-token windows, odd tile remainder
+    (2, 32, 40, 4, True),    # attn_splits 4 (rect_wide / IBRNet-style)
+    (6, 64, 80, 2, True),    # the DTU shape: 3 pairs x 2 directions, 1280-token windows
+])
+def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shifted):
+    from matchnerf_amd import hip
+    gen = torch.Generator().manual_seed(h * 1000 + w * 10 + splits + int(shifted))
+    n, c = h * w, 128
+    q = torch.randn(b, n, c, generator=gen) * 0.6       # scores ~ N(0, 0.36 * 0.8^2 * 128 / 11.3^2): a peaked but not one-hot softmax
+    k = torch.randn(b, n, c, generator=gen) * 0.8
+    v = torch.randn(b, n, c, generator=gen)
+    g = torch.randn(b, n, c, generator=gen)
+    qg, kg, vg, gg = q.cuda(), k.cuda(), v.cuda(), g.cuda()
+    out = hip.window_attention(qg, kg, vg, h, w, splits, shifted)
+    gq, gk, gv = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
+    again = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
+    for a, bb in zip((gq, gk, gv), again):
+        assert torch.equal(a, bb)                       # no atomics: bit-reproducible
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    o64 = O.window_attention(q64, k64, v64, h, w, splits, shifted)
+    assert float((out.cpu().double() - o64.detach()).abs().max()) < 2e-5
+    (o64 * g.double()).sum().backward()
+    worst = {}
+    for name, got, ref in (("q", gq, q64.grad), ("k", gk, k64.grad), ("v", gv, v64.grad)):
+        assert torch.isfinite(got).all()
+        worst[name] = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    print({kk: f"{vv:.1e}" for kk, vv in worst.items()})
+    assert all(vv < 2e-5 for vv in worst.values()), worst
+
+
+def test_autograd_bridge_uses_the_hip_backward(monkeypatch):
+    """autograd.window_attention: HIP forward + HIP backward; the torch re-evaluation (MNERF_WA_BACKWARD=torch) agrees."""
+    from matchnerf_amd import autograd as ag
+    gen = torch.Generator().manual_seed(9)
+    b, h, w = 2, 16, 24
+    mk = lambda s: (torch.randn(b, h * w, 128, generator=gen) * s).cuda()
+    grads = {}
+    g = mk(1.0)
+    base = [mk(0.6), mk(0.8), mk(1.0)]
+    for mode in ("hip", "torch"):
+        monkeypatch.setenv("MNERF_WA_BACKWARD", mode)
+        q, k, v = (t.clone().requires_grad_(True) for t in base)
+        out = ag.window_attention(q, k, v, h, w, 2, True)
+        (out * g).sum().backward()
+        grads[mode] = (q.grad, k.grad, v.grad)
+    for a, bb in zip(grads["hip"], grads["torch"]):
+        assert float((a - bb).abs().max() / bb.abs().max()) < 2e-5
