@@ -206,16 +206,20 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
 }
 
 // padding of a slot's LDS areas (floats): the stride becomes = 8 (projections) / 4 (cosine sums) mod 32
-#ifndef CVW_NO_PAD
+// MEASURED (round 4, same box, two runs each): padded 9.78-9.91 ms per frame, unpadded 9.57-9.59 - the conflicts the counters
+// show are not on the kernel's critical path, and the padding costs more than it buys.  Off by default (-DCVW_PAD=1 to try).
+#if defined(CVW_PAD) && CVW_PAD
 #define CVW_PAD_UV(n) ((40 - ((n) & 31)) & 31)
 #define CVW_PAD_CS(n) ((36 - ((n) & 31)) & 31)
+#define CVW_PAD_REC 1
 #else
 #define CVW_PAD_UV(n) 0
 #define CVW_PAD_CS(n) 0
+#define CVW_PAD_REC 0
 #endif
 __host__ __device__ inline size_t cvw_lean_lds_floats(int nslot, int seg, int views_kept, int cs_pad) {
   const int uv = seg * views_kept * 2, cs = seg * cs_pad;
-  return (size_t)nslot * ((uv + CVW_PAD_UV(uv)) + (seg * 4 + 1) * 4 + (cs + CVW_PAD_CS(cs)));
+  return (size_t)nslot * ((uv + CVW_PAD_UV(uv)) + (seg * 4 + CVW_PAD_REC) * 4 + (cs + CVW_PAD_CS(cs)));
 }
 
 // ============================================================================ segment walk (stand-alone kernel)
@@ -234,14 +238,14 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
   const int sumG = sc.n_group[0] + (sc.n_scales > 1 ? sc.n_group[1] : 0);
   const int cs_stride = (sumG + 3) & ~3;                            // cosine sums per segment sample in LDS
   // LDS per slot: projections [js][view](u,v) | walk records [js][view a|b][idx|weights] (float4) | cosine sums [js][cs]
-  // Every slot's three areas are padded so that the SAME offset in different slots falls into different LDS banks: the four
-  // (eight) slots of a wave read their walk records / projections / cosine sums at the same offsets in the same instruction,
-  // and with slot strides of 96, 256 and 192 floats (all = 0 mod 32) every such access was a 4-way bank conflict
-  // (round-3 PMC: 4.6 conflict cycles per LDS instruction).  CVW_PAD_* floats per slot: strides = 8, 4, 4 mod 32.
+  // (experiment, CVW_PAD=1: every slot's three areas padded so that the SAME offset in different slots falls into different
+  // LDS banks - the slots of a wave read their walk records / projections / cosine sums at the same offsets in one instruction,
+  // and slot strides of 96, 256 and 192 floats are all = 0 mod 32: the 4.6 conflict cycles per LDS instruction of round 3's
+  // PMC.  Measured slower, see CVW_PAD_* above.)
   const int uv_str = CVW_SEG * V * 2 + CVW_PAD_UV(CVW_SEG * V * 2), cs_str = CVW_SEG * cs_stride + CVW_PAD_CS(CVW_SEG * cs_stride);
   float* uv_lds = cvw_smem + (size_t)slot * uv_str;
-  float4* wrec_lds = reinterpret_cast<float4*>(cvw_smem + (size_t)NSLOT * uv_str) + (size_t)slot * (CVW_SEG * 4 + 1);
-  float* cs_lds = cvw_smem + (size_t)NSLOT * (uv_str + (CVW_SEG * 4 + 1) * 4) + slot * cs_str;
+  float4* wrec_lds = reinterpret_cast<float4*>(cvw_smem + (size_t)NSLOT * uv_str) + (size_t)slot * (CVW_SEG * 4 + CVW_PAD_REC);
+  float* cs_lds = cvw_smem + (size_t)NSLOT * (uv_str + (CVW_SEG * 4 + CVW_PAD_REC) * 4) + slot * cs_str;
   const int S = R.n_samples;
   const int n_seg = (S + CVW_SEG - 1) / CVW_SEG;
 

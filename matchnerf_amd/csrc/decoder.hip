@@ -1652,7 +1652,8 @@ struct SmemPP {
 #ifndef MNERF_PP_L5_H_FIRST
 #define MNERF_PP_L5_H_FIRST 1
 #endif
-__device__ __host__ constexpr int pp_p0(int s) {
+__device__ __host__ constexpr int pp_p0(int s, int fs = 2) {
+  if (s == 0) return 1 + 8 * fs;  // FiLM: header + fs K16-steps x 4 blocks x (hi | lo)
 #if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 32, 33, 17, 33, 17, 9};
 #else
@@ -1665,13 +1666,14 @@ __device__ __host__ constexpr int pp_p0(int s) {
 // L5-h a b | alpha | feature a b | views a b | rgb | tail.  Taken from the kernel arguments (sch.seg_off[pps.seg_first[s] + i]:
 // two dependent scalar loads per use) the 20 addresses were hoisted out of the tile loop and parked in VGPR lanes - 280
 // spilled SGPRs, 850 v_readlane per tile (12 % of the kernel's vector instructions).
-__device__ __host__ constexpr int pp_stream_pieces(int k) {  // 1-KiB pieces of stream segment k
+__device__ __host__ constexpr int pp_stream_pieces(int k, int fs = 2) {  // 1-KiB pieces of stream segment k
+  if (k == 0) return 1 + 8 * fs;
   constexpr int t[20] = {17, 33, 33, 32, 33, 32, 33, 32, 33, 32, 33, 32, 32, 17, 33, 32, 17, 20, 9, 11};
   return t[k];
 }
-__device__ __host__ constexpr int pp_stream_off_floats(int k) {
+__device__ __host__ constexpr int pp_stream_off_floats(int k, int fs = 2) {
   int o = 0;
-  for (int m = 0; m < k; ++m) o += pp_stream_pieces(m) * 256;
+  for (int m = 0; m < k; ++m) o += pp_stream_pieces(m, fs) * 256;
   return o;
 }
 __device__ __host__ constexpr int pp_seg_first(int s) {
@@ -1682,7 +1684,7 @@ __device__ __host__ constexpr int pp_seg_first(int s) {
 #endif
   return t[s];
 }
-__device__ __host__ constexpr int pp_seg_off_floats(int s, int i) { return pp_stream_off_floats(pp_seg_first(s) + i); }
+__device__ __host__ constexpr int pp_seg_off_floats(int s, int i, int fs = 2) { return pp_stream_off_floats(pp_seg_first(s) + i, fs); }
 __device__ __host__ constexpr int pp_p1(int s) {
 #if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 32, 0, 0, 32, 20, 0};
@@ -1701,23 +1703,24 @@ template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get0(float v) {  // the source lane's value, 0 where the row is masked / the source is outside
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
 }
+__device__ __forceinline__ float readlane_f(float v, int l) {  // (the builtin is an INTEGER operation: a float argument would be
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));  //  converted by value - 0.37f -> 0 - not by bits)
+}
 __device__ __forceinline__ float wave_sum_dpp(float v) {  // total over the 64 lanes (wave-uniform)
   v = dpp_group_sum<16>(v);  // every lane: the sum of its row
-  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
-         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
 }
-// lane l: v[0] + .. + v[l-1].  Only ROW operations (row_shr) and v_readlane: the wave-wide DPP forms of earlier GCN parts
-// (wave_shr:1, row_bcast:15 / :31) assemble for gfx950 but do not work there — the first version of this function, written
-// with them, rendered an all-zero frame (gpurun_out r4d).
+// lane l: v[0] + .. + v[l-1].  Row operations (row_shr) and v_readlane only (the wave-wide DPP forms wave_shr / row_bcast of
+// earlier GCN parts assemble for gfx950; not relied upon here).
 __device__ __forceinline__ float wave_exclusive_sum_dpp(float v, int lane) {
   float x = dpp_get0<0x111>(v);           // row_shr:1: v[l-1] inside a row, 0 at a row's first lane ..
-  const float c15 = __builtin_amdgcn_readlane(v, 15), c31 = __builtin_amdgcn_readlane(v, 31), c47 = __builtin_amdgcn_readlane(v, 47);
+  const float c15 = readlane_f(v, 15), c31 = readlane_f(v, 31), c47 = readlane_f(v, 47);
   x = lane == 16 ? c15 : (lane == 32 ? c31 : (lane == 48 ? c47 : x));  // .. which takes the last lane of the row before
   x += dpp_get0<0x111>(x);                // row_shr:1
   x += dpp_get0<0x112>(x);                // row_shr:2
   x += dpp_get0<0x114>(x);                // row_shr:4
   x += dpp_get0<0x118>(x);                // row_shr:8     -> inclusive scan inside every row
-  const float t0 = __builtin_amdgcn_readlane(x, 15), t1 = __builtin_amdgcn_readlane(x, 31), t2 = __builtin_amdgcn_readlane(x, 47);
+  const float t0 = readlane_f(x, 15), t1 = readlane_f(x, 31), t2 = readlane_f(x, 47);
   const float t01 = t0 + t1;
   return x + (lane >= 48 ? t01 + t2 : (lane >= 32 ? t01 : (lane >= 16 ? t0 : 0.0f)));
 }
@@ -1865,7 +1868,11 @@ __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float
   }
 }
 
-template <int SP>
+// FS: K16-steps of the FiLM stage = ceil(conditioning inputs / 16): 2 up to 5 source views (the shipped 3-view case), 3 for
+// 6-7, 4 for 8-11 (BASELINE config[4]: 10 views, 50 inputs).  Only the first stage, its operands and its place in the weight
+// stream depend on it; with FS > 2 a team's rows of the next tile (128 x cond_stride floats) no longer fit its half of ring
+// slot 1, so V_0 reads them from global memory.
+template <int SP, int FS = 2>
 __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     mnerf_decoder D, DecSched sch, PPSched pps, mnerf_view view0, mnerf_rays R, const float* __restrict__ cond,
     float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_opacity,
@@ -1905,7 +1912,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 
 #define PP_SLOT_LDS(s_, i_) (ring_lds + (unsigned)(2 * ((s_)&1) + (i_)) * (SEG_CAP_FLOATS * 4u))
 #define PP_HDR_LDS(s_) (hdr_lds + (unsigned)(s_) * 1024u)
-#define PP_SEG_SRC(s_, i_) (D.wstream + pp_seg_off_floats(s_, i_))
+#define PP_SEG_SRC(s_, i_) (D.wstream + pp_seg_off_floats(s_, i_, FS))
 
   // ---- prologue: LayerNorm parameters, the resident tail segment, the stage headers, stage 0 of the first tile
   if (tid < SMALL_FIXED) ln_lds[tid] = D.small_[tid];
@@ -1916,9 +1923,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   {
     const unsigned voff = (unsigned)lane0 * 16u;
     for (int p = wave; p < pp_stream_pieces(19); p += 8)
-      glds16_s(D.wstream + pp_stream_off_floats(19) + p * 256, voff, __builtin_amdgcn_readfirstlane(tail_lds + (unsigned)p * 1024u));
+      glds16_s(D.wstream + pp_stream_off_floats(19, FS) + p * 256, voff, __builtin_amdgcn_readfirstlane(tail_lds + (unsigned)p * 1024u));
     for (int s = wave; s < PP_STAGES; s += 8) glds16_s(PP_SEG_SRC(s, 0), voff, __builtin_amdgcn_readfirstlane(PP_HDR_LDS(s)));
-    for (int p = wave; p < pp_p0(0); p += 8)
+    for (int p = wave; p < pp_p0(0, FS); p += 8)
       glds16_s(PP_SEG_SRC(0, 0) + p * 256, voff, __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(0, 0) + (unsigned)p * 1024u));
   }
   segment_wait();
@@ -1981,7 +1988,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     asm volatile("" : "+v"(voff));
     for (int i = 0; i < 2; ++i) {
       const float* src = PP_SEG_SRC(s, i);
-      const int pieces = i == 0 ? pp_p0(s) : pp_p1(s);
+      const int pieces = i == 0 ? pp_p0(s, FS) : pp_p1(s);
       const unsigned base = PP_SLOT_LDS(s, i);
       const int first = half == 2 ? tw : 2 * tw + half, step = half == 2 ? 4 : 8;
       for (int p = first; p < pieces; p += step) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
@@ -2002,7 +2009,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   int dma_k = 0;  // requests of the current vector phase already made by this wave (compile-time after unrolling)
   auto stage_piece = [&](int s, int half, int k) {
     const int i = k / 5;
-    const int pcs = i == 0 ? pp_p0(s) : pp_p1(s);
+    const int pcs = i == 0 ? pp_p0(s, FS) : pp_p1(s);
     // (an opaque copy of the wave's index: the ~200 source / destination addresses of a tile's requests are loop-invariant,
     // and hoisted out of the tile loop they were parked in VGPR lanes — 480 spilled SGPRs, two v_readlane per request; computed
     // where they are used they are two scalar additions)
@@ -2118,24 +2125,14 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     const int j = jp < S ? jp : (S - 1);
     const size_t gs = (size_t)ray * S + j;
 
-    // ============================================================ phase 0 = V_0: inputs, geometry, FiLM operands
-    float4 cpre[4];
+    // ============================================================ phase 0 = V_0: inputs, FiLM operands
+    float4 cpre[2 * FS];
     float n_valid;
-    if (rows_in_lds) {
-      const float* crow = rows_lds + s_local * CS;
+    {
+      // the sample's row: in LDS when the previous tile's tail copied it there (FS == 2 only), else in global memory
+      const float* crow = (FS == 2 && rows_in_lds) ? rows_lds + s_local * CS : cond + gs * CS;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
-        cpre[i] = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      const float* mrow = crow + (D.cond_dim - D.n_views);
-      float nv = 0.0f;
-      for (int v = 0; v < D.n_views; ++v) nv += mrow[v];
-      n_valid = nv;
-    } else {
-      const float* crow = cond + gs * CS;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 2 * FS; ++i) {
         const int o = 16 * (i >> 1) + 8 * hl + 4 * (i & 1);
         cpre[i] = (o + 4 <= CS) ? *reinterpret_cast<const float4*>(crow + o) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -2156,17 +2153,19 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     f32x16 film[4];
     int ecf;
     {
-      const float v0[8] = {cpre[0].x, cpre[0].y, cpre[0].z, cpre[0].w, cpre[1].x, cpre[1].y, cpre[1].z, cpre[1].w};
-      const float v1[8] = {cpre[2].x, cpre[2].y, cpre[2].z, cpre[2].w, cpre[3].x, cpre[3].y, cpre[3].z, cpre[3].w};
-      hs[0] = split8h(v0, (float)(1 << (H16_TARGET_EXP - 1)));
-      hs[1] = split8h(v1, (float)(1 << (H16_TARGET_EXP - 1)));
+#pragma unroll
+      for (int t = 0; t < FS; ++t) {
+        const float vt[8] = {cpre[2 * t].x, cpre[2 * t].y, cpre[2 * t].z, cpre[2 * t].w,
+                             cpre[2 * t + 1].x, cpre[2 * t + 1].y, cpre[2 * t + 1].z, cpre[2 * t + 1].w};
+        hs[t] = split8h(vt, (float)(1 << (H16_TARGET_EXP - 1)));
+      }
       const int ew = header_ew(PP_HDR_LDS(0));
       ecf = -(ew + (H16_TARGET_EXP - 1));
       bias_init_h<4>(film, PP_HDR_LDS(0), hl, pow2i(ew + (H16_TARGET_EXP - 1)));
     }
     PP_END_V(-1, 1);
     // ============================================================ phase 1 = M_0: FiLM = pts_bias(cond)
-    PP_MFMA(4, 2, 0, film, 0, 1024u, hs);
+    PP_MFMA(4, FS, 0, film, 0, 1024u, hs);
     __builtin_amdgcn_sched_barrier(0);  // the geometry stays in this phase (the scheduler moves vector work across s_barrier)
     if (ext_ndc) {
       x = ext_ndc[gs * 3 + 0];
@@ -2451,7 +2450,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     // The team's conditioning rows of the next tile travel to LDS meanwhile (its half of ring slot 1, free between the views
     // stage and layer 1 of the next tile): phase V_0 then starts from LDS instead of waiting ~8 k cycles for global loads.
     bool next_rows = false;
-    if (S == Sp && has_next) {
+    if (FS == 2 && S == Sp && has_next) {
       const int first_ray = (tile + tile_step) * rays_per_tile + team * rays_per_team;
       next_rows = first_ray + rays_per_team <= R.n_rays;
       if (next_rows) {
@@ -2606,7 +2605,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         ad += w * dd;
         ao += w;
 #if MNERF_PP_T4_DPP
-        carry = __builtin_amdgcn_readlane(excl + c.w, 63);
+        carry = readlane_f(excl + c.w, 63);
 #else
         carry = __shfl(excl + c.w, 63, 64);
 #endif
@@ -2869,7 +2868,10 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream, S <= 128 (round 3: 82.3 vs
   // 88.7 ms per 800x800 frame at 128 samples per ray; the knob can only LOWER the limit: there is no 256-sample instance)
   const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
-  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= pp_max_s && dec->L_3D == 10 && sch.film_steps == 2 &&
+  // FiLM stages of 2 K16-steps (<= 5 views) at every S; of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
+  const int fs = sch.film_steps;
+  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= pp_max_s && dec->L_3D == 10 &&
+      (fs == 2 || ((fs == 3 || fs == 4) && Sp == 64)) && dec->cond_stride <= 16 * fs &&
       sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
     PPSched pps;
 #if MNERF_PP_L5_H_FIRST
@@ -2882,32 +2884,36 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     for (int i = 0; i < PP_STAGES; ++i) {
       pps.seg_first[i] = first[i], pps.n_seg[i] = nseg[i];
       // the kernel's compile-time piece counts must be the schedule's
-      MNERF_REQUIRE((sch.seg_floats[first[i]] >> 8) == pp_p0(i) && (nseg[i] == 2 ? (sch.seg_floats[first[i] + 1] >> 8) : 0) == pp_p1(i),
+      MNERF_REQUIRE((sch.seg_floats[first[i]] >> 8) == pp_p0(i, fs) && (nseg[i] == 2 ? (sch.seg_floats[first[i] + 1] >> 8) : 0) == pp_p1(i),
                     MNERF_E_RANGE, "%s: weight schedule does not match the ping-pong kernel (stage %d)", who, i);
       MNERF_REQUIRE(first[i] == pp_seg_first(i), MNERF_E_RANGE, "%s: stage table of the ping-pong kernel (stage %d)", who, i);
     }
     for (int k = 0; k < 20; ++k)  // the kernel addresses the stream with compile-time offsets
-      MNERF_REQUIRE(sch.seg_off[k] == pp_stream_off_floats(k) && (sch.seg_floats[k] >> 8) == pp_stream_pieces(k), MNERF_E_RANGE,
+      MNERF_REQUIRE(sch.seg_off[k] == pp_stream_off_floats(k, fs) && (sch.seg_floats[k] >> 8) == pp_stream_pieces(k, fs), MNERF_E_RANGE,
                     "%s: weight stream layout does not match the ping-pong kernel (segment %d)", who, k);
     const int rpt = 256 / Sp;
     const int tiles = (rays->n_rays + rpt - 1) / rpt;
     const int cus = mnerf_tune().decoder_pp_grid > 0 ? mnerf_tune().decoder_pp_grid : 1;  // persistent: one 8-wave workgroup per CU
     const int grid = tiles < cus ? tiles : cus;
-#define MNERF_LAUNCH_PP(SP_)                                                                                          \
+#define MNERF_LAUNCH_PP(SP_, FS_)                                                                                     \
   do {                                                                                                                \
     const size_t lds = SmemPP<SP_>::TOTAL_FLOATS * sizeof(float);                                                     \
     static std::atomic<unsigned long long> attr_set{0};                                                               \
     if (mnerf_once_per_device(attr_set))                                                                              \
-      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((decoder_pp_kernel<SP_>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
+      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_, FS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((decoder_pp_kernel<SP_, FS_>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
                        opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
   } while (0)
-    if (Sp == 32)
-      MNERF_LAUNCH_PP(32);
+    if (fs == 3)
+      MNERF_LAUNCH_PP(64, 3);
+    else if (fs == 4)
+      MNERF_LAUNCH_PP(64, 4);
+    else if (Sp == 32)
+      MNERF_LAUNCH_PP(32, 2);
     else if (Sp == 64)
-      MNERF_LAUNCH_PP(64);
+      MNERF_LAUNCH_PP(64, 2);
     else
-      MNERF_LAUNCH_PP(128);
+      MNERF_LAUNCH_PP(128, 2);
 #undef MNERF_LAUNCH_PP
     return mnerf_check_launch(who);
   }

@@ -48,33 +48,56 @@ __global__ __launch_bounds__(256) void wa_bwd_rowdot_kernel(const float* __restr
   if (c4 == 0) d[tok] = s;
 }
 
-// 64 rows (window-local indices i0 .. i0+63 of window (wy, wx) of sequence `seq`) x 128 channels -> LDS [channel][row];
-// rows beyond the window are zero-filled.  `tok_lds[row]` / `reg_lds[row]`: token id (-1 beyond the window) and wrap region.
-__device__ __forceinline__ void wb_load_tile(float* __restrict__ dst, const float* __restrict__ src_seq, const WinGeom& G, int wy,
-                                             int wx, int i0, int tid, int* tok_lds, int* reg_lds) {
-  if (tok_lds && tid < WB_T) {
-    int region = 0;
-    const int li = i0 + tid;
-    const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
-    tok_lds[tid] = tok;
-    reg_lds[tid] = region;
-  }
-  // a half-wave (32 lanes x 16 B) reads one row: 512 contiguous bytes
+// A tile = 64 rows (window-local indices i0 .. i0+63 of window (wy, wx)) x 128 channels, staged in LDS as [channel][row]; rows
+// beyond the window are zero.  Loading is split in two so that the global loads of the NEXT tile are in flight while the
+// current one is multiplied (one wave per SIMD, 512 registers: the 8 float4 per tile are free):
+//   wb_fetch   global -> registers: a half-wave (32 lanes x 16 B) reads one row, 512 contiguous bytes
+//   wb_store   registers -> LDS (transposing), after the barrier that retires the previous tile
+//   wb_tokens  token id (-1 beyond the window) and wrap region of the tile's rows
+struct WbTileRegs {
+  float4 v[WB_T / 8];
+};
+__device__ __forceinline__ void wb_fetch(WbTileRegs& r, const float* __restrict__ src_seq, const WinGeom& G, int wy, int wx, int i0,
+                                         int tid) {
   const int c4 = tid & 31;
-#pragma unroll 4
-  for (int row = tid >> 5; row < WB_T; row += 8) {
-    const int li = i0 + row;
+#pragma unroll
+  for (int k = 0; k < WB_T / 8; ++k) {
+    const int li = i0 + (tid >> 5) + 8 * k;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (li < G.Lw) {
       int region;
       const int tok = win_token(G, wy, wx, li, region);
       v = reinterpret_cast<const float4*>(src_seq + (size_t)tok * WA_C)[c4];
     }
-    dst[(4 * c4 + 0) * WB_LD + row] = v.x;
-    dst[(4 * c4 + 1) * WB_LD + row] = v.y;
-    dst[(4 * c4 + 2) * WB_LD + row] = v.z;
-    dst[(4 * c4 + 3) * WB_LD + row] = v.w;
+    r.v[k] = v;
   }
+}
+__device__ __forceinline__ void wb_store(float* __restrict__ dst, const WbTileRegs& r, int tid) {
+  const int c4 = tid & 31;
+#pragma unroll
+  for (int k = 0; k < WB_T / 8; ++k) {
+    const int row = (tid >> 5) + 8 * k;
+    dst[(4 * c4 + 0) * WB_LD + row] = r.v[k].x;
+    dst[(4 * c4 + 1) * WB_LD + row] = r.v[k].y;
+    dst[(4 * c4 + 2) * WB_LD + row] = r.v[k].z;
+    dst[(4 * c4 + 3) * WB_LD + row] = r.v[k].w;
+  }
+}
+__device__ __forceinline__ void wb_tokens(const WinGeom& G, int wy, int wx, int i0, int tid, int* tok_lds, int* reg_lds) {
+  if (tid < WB_T) {
+    int region = 0;
+    const int li = i0 + tid;
+    const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
+    tok_lds[tid] = tok;
+    reg_lds[tid] = region;
+  }
+}
+__device__ __forceinline__ void wb_load_tile(float* __restrict__ dst, const float* __restrict__ src_seq, const WinGeom& G, int wy,
+                                             int wx, int i0, int tid, int* tok_lds, int* reg_lds) {
+  WbTileRegs r;
+  wb_fetch(r, src_seq, G, wy, wx, i0, tid);
+  wb_store(dst, r, tid);
+  if (tok_lds) wb_tokens(G, wy, wx, i0, tid, tok_lds, reg_lds);
 }
 
 // acc[rows of A-block ra] [cols of B-block cb] = sum_ch A[ch][ra*32 + m] * B[ch][cb*32 + n]   (both tiles [channel][row])
@@ -155,10 +178,14 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_kernel(WaBwdArgs A) {
 
   // ---- pass 1: row statistics over this wave's share of the keys (online softmax), merged across the waves afterwards
   float run_m = -INFINITY, run_l = 0.0f;
+  WbTileRegs nk, nv;  // the next key / value tile, in flight
+  wb_fetch(nk, ks, G, wy, wx, 0, tid);
   for (int kt = 0; kt < n_tiles; ++kt) {
     __syncthreads();  // the previous tile has been consumed
-    wb_load_tile(k_t, ks, G, wy, wx, kt * WB_T, tid, k_tok, k_reg);
+    wb_store(k_t, nk, tid);
+    wb_tokens(G, wy, wx, kt * WB_T, tid, k_tok, k_reg);
     __syncthreads();
+    if (kt + 1 < n_tiles) wb_fetch(nk, ks, G, wy, wx, (kt + 1) * WB_T, tid);
     const f32x16 st = wb_tile_product(k_t, wk, q_t, wq, lane);  // S^T block: rows = keys, columns = queries
     float sc[16], mx = -INFINITY;
 #pragma unroll
@@ -201,11 +228,18 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_kernel(WaBwdArgs A) {
   f32x16 dq[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) dq[mb] = (f32x16)(0.0f);
+  wb_fetch(nk, ks, G, wy, wx, 0, tid);
+  wb_fetch(nv, vs, G, wy, wx, 0, tid);
   for (int kt = 0; kt < n_tiles; ++kt) {
     __syncthreads();
-    wb_load_tile(k_t, ks, G, wy, wx, kt * WB_T, tid, k_tok, k_reg);
-    wb_load_tile(v_t, vs, G, wy, wx, kt * WB_T, tid, nullptr, nullptr);
+    wb_store(k_t, nk, tid);
+    wb_store(v_t, nv, tid);
+    wb_tokens(G, wy, wx, kt * WB_T, tid, k_tok, k_reg);
     __syncthreads();
+    if (kt + 1 < n_tiles) {
+      wb_fetch(nk, ks, G, wy, wx, (kt + 1) * WB_T, tid);
+      wb_fetch(nv, vs, G, wy, wx, (kt + 1) * WB_T, tid);
+    }
     const f32x16 st = wb_tile_product(k_t, wk, q_t, wq, lane);
     const f32x16 dpt = wb_tile_product(v_t, wk, do_t, wq, lane);  // dP^T block
     f32x16 ds;
@@ -283,11 +317,19 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_kernel(WaBwdArgs A) {
   f32x16 dk[4], dv[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) dk[mb] = dv[mb] = (f32x16)(0.0f);
+  WbTileRegs nq, ndo;  // the next query / dO tile, in flight
+  wb_fetch(nq, qs, G, wy, wx, 0, tid);
+  wb_fetch(ndo, gos, G, wy, wx, 0, tid);
   for (int qt = 0; qt < n_tiles; ++qt) {
     __syncthreads();
-    wb_load_tile(q_t, qs, G, wy, wx, qt * WB_T, tid, q_tok, q_reg);
-    wb_load_tile(do_t, gos, G, wy, wx, qt * WB_T, tid, nullptr, nullptr);
+    wb_store(q_t, nq, tid);
+    wb_store(do_t, ndo, tid);
+    wb_tokens(G, wy, wx, qt * WB_T, tid, q_tok, q_reg);
     __syncthreads();
+    if (qt + 1 < n_tiles) {
+      wb_fetch(nq, qs, G, wy, wx, (qt + 1) * WB_T, tid);
+      wb_fetch(ndo, gos, G, wy, wx, (qt + 1) * WB_T, tid);
+    }
     if (tid < WB_T) {
       const int tok = q_tok[tid];
       st_m[tid] = tok >= 0 ? A.row_m[seq_off + tok] : 0.0f;

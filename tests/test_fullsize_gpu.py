@@ -74,6 +74,25 @@ def test_pair_blocked_cost_volume_is_bit_identical_to_one_launch(n_views):
             assert torch.equal(a, b), f"pair block {blk}"
 
 
+@pytest.mark.parametrize("n_views", [7, 10])
+def test_ping_pong_decoder_with_wider_film_stage_equals_the_staged_kernel_and_the_oracle(n_views):
+    """6-11 source views: 34-54 conditioning inputs = a FiLM stage of 3 / 4 K16-steps.  decoder_pp_kernel<64, 3|4> (round 4)
+    against decoder_kernel<4,64,2,0> (the two sum layer 5 in different orders: 3e-6) and against the CPU oracle."""
+    from matchnerf_amd import hip
+    opt, model, sd = build(n_views=n_views, S=64)
+    scene = syn.make_scene(32, 40, n_views, seed=24)
+    batch = gpu_batch(scene)
+    with torch.no_grad():
+        pp = model(batch, mode="test")
+        pp = (pp.rgb.clone(), pp.depth.clone(), pp.opacity.clone())
+        with hip.knob("decoder_pp", 0):
+            st = model(batch, mode="test")
+        cfg = O.OracleConfig(n_src_views=n_views, sample_intvs=64)
+        ref = O.forward_test(cfg, sd, {k: torch.from_numpy(v) for k, v in scene.items()})
+    assert linf(pp[0], st.rgb) < 3e-6 and linf(pp[2], st.opacity) < 3e-6 and linf(pp[1], st.depth) < 3e-5
+    assert linf(pp[0], ref["rgb"]) < 1e-4 and linf(pp[2], ref["opacity"]) < 1e-4 and linf(pp[1], ref["depth"]) < 3e-4
+
+
 def test_blender_like_128_samples_match_oracle():
     opt, model, sd = build(n_views=3, S=128)
     model.nerf_setbg_opaque = True
