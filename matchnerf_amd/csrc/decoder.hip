@@ -2066,8 +2066,8 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   } while (0)
   // M_s: stage s's matrix instructions (+ team A: the requests for stage NXT_)
 #ifndef MNERF_PP_T4_DPP
-#define MNERF_PP_T4_DPP 0  // 1: compositing scan / sums through DPP row operations instead of ds_bpermute shuffles (see wave_sum_dpp)
-#endif
+#define MNERF_PP_T4_DPP 1  // compositing scan / sums through DPP row operations instead of ds_bpermute shuffles (wave_sum_dpp):
+#endif                     // measured 16.77 -> 16.42 ms per frame (same box, two runs each); 0 restores the shuffles
 #ifndef MNERF_PP_PAIRS
 #define MNERF_PP_PAIRS 0  // 1: the two blocks of a pair interleaved, no back-to-back dependent MFMAs (measured: no faster, more spills)
 #endif
@@ -2247,7 +2247,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
           dst[m][r] = t;
           mx = fmaxf(mx, t);
         }
-      return fmaxf(mx, __shfl_xor(mx, 32, 64));
+      return pair_max(mx);
     };
     em = gain_exp(enc_max);
     const float mult_l0 = pow2i(em);
@@ -2522,7 +2522,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
           yv[r] = t1[r] + av[r];
           xs += yv[r];
         }
-        xs += __shfl_xor(xs, 32, 64);
+        xs = pair_sum(xs);
         const float mean = xs * (1.0f / 16.0f);
         float var = 0.f;
 #pragma unroll
@@ -2530,7 +2530,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
           const float dlt = yv[r] - mean;
           var += dlt * dlt;
         }
-        var += __shfl_xor(var, 32, 64);
+        var = pair_sum(var);
         const float rstd = 1.0f / sqrtf(var * (1.0f / 16.0f) + 1e-6f);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {

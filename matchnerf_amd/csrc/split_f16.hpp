@@ -456,6 +456,27 @@ __device__ __forceinline__ void kblock_h(f32x16 (&acc)[NMB], unsigned base_lds, 
   ksteps_h<NMB, 2>(acc, base_lds, lane, v, mult);
 }
 
+// x of lane (n, 0) and of lane (n, 1) in every lane of the pair: v_permlane32_swap (gfx950) exchanges the upper half of its
+// first operand with the lower half of its second - one VALU instruction instead of a ds_bpermute round trip through LDS
+// (~100 cycles on the critical path of every per-sample gain).  (inline asm: hipcc 7.2 folds the two results of
+// __builtin_amdgcn_permlane32_swap into one.)  max / sum of the pair from (lo, hi) are the same bits in both lanes.
+__device__ __forceinline__ void pair_halves(float x, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float pair_max(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float pair_sum(float x) {
+  float lo, hi;
+  pair_halves(x, lo, hi);
+  return lo + hi;
+}
+
 // largest |value| of a sample's features held in NB accumulator blocks of its two lanes
 template <int NB>
 __device__ __forceinline__ float sample_absmax(const f32x16 (&a)[NB]) {
@@ -464,6 +485,6 @@ __device__ __forceinline__ float sample_absmax(const f32x16 (&a)[NB]) {
   for (int m = 0; m < NB; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(a[m][r]));
-  return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  return pair_max(mx);
 }
 

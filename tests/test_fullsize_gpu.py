@@ -80,7 +80,7 @@ def test_ping_pong_decoder_with_wider_film_stage_equals_the_staged_kernel_and_th
     against decoder_kernel<4,64,2,0> (the two sum layer 5 in different orders: 3e-6) and against the CPU oracle."""
     from matchnerf_amd import hip
     opt, model, sd = build(n_views=n_views, S=64)
-    scene = syn.make_scene(32, 40, n_views, seed=24)
+    scene = syn.make_scene(32, 48, n_views, seed=24)
     batch = gpu_batch(scene)
     with torch.no_grad():
         pp = model(batch, mode="test")
