@@ -414,6 +414,42 @@ int64_t mnerf_encoder_block_wstream_floats(int32_t ffn);
 int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
                         int32_t n_tokens, void* stream);
 
+/* Backward of a transformer layer around the window attention (what `loss.backward()` does to
+ * models/gmflow/transformer.py:108-185 in coach.py:215-243; round 4).  Parameters in torch's layouts, gradients ACCUMULATED
+ * into the g_* tensors (a NULL g_* skips that parameter).  Exact-fp32 matrix products (csrc/gemm_f32.hpp). */
+typedef struct mnerf_encoder_layer_train {
+  int32_t ffn;            /* 0: self-attention layer (merge + norm1 only), 1: + cat / mlp / norm2 */
+  int32_t pad_;
+  const float* w_merge;   /* merge.weight [128,128] */
+  const float* ln1_w;     /* norm1.weight / bias [128] */
+  const float* ln1_b;
+  const float* w_mlp0;    /* mlp.0.weight [1024,256] (columns: source | message) */
+  const float* w_mlp2;    /* mlp.2.weight [128,1024] */
+  const float* ln2_w;
+  const float* ln2_b;
+  float* g_w_merge;
+  float* g_ln1_w;
+  float* g_ln1_b;
+  float* g_w_mlp0;
+  float* g_w_mlp2;
+  float* g_ln2_w;
+  float* g_ln2_b;
+} mnerf_encoder_layer_train;
+/* attn (the attention's output), source (the layer's input), g_out (gradient of the layer's output): [n_tokens,128] ->
+ * g_attn, g_source [n_tokens,128] (OVERWRITTEN; g_source includes the residual path).  The chain of mnerf_encoder_block is
+ * re-evaluated in fp32 with its pre-activations kept in `workspace` (mnerf_encoder_layer_backward_workspace_bytes:
+ * 3 970 floats per token). */
+int64_t mnerf_encoder_layer_backward_workspace_bytes(int32_t n_tokens);
+int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* layer, const float* attn, const float* source,
+                                 const float* g_out, float* g_attn, float* g_source, int32_t n_tokens, void* workspace,
+                                 void* stream);
+/* q = x_q Wq^T, k = x_kv Wk^T, v = x_kv Wv^T (mnerf_qkv_projection without the batch swap: the caller passes the key / value
+ * source it used):  g_xq = g_q Wq and g_xkv = g_k Wk + g_v Wv are OVERWRITTEN ([n_tokens,128], two different buffers),
+ * gw_* [128,128] += g_*^T x_* (NULL: skipped). */
+int mnerf_qkv_backward(const float* w_q, const float* w_k, const float* w_v, const float* x_q, const float* x_kv,
+                       const float* g_q, const float* g_k, const float* g_v, float* g_xq, float* g_xkv, float* gw_q,
+                       float* gw_k, float* gw_v, int32_t n_tokens, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

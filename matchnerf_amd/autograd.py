@@ -92,6 +92,56 @@ def window_attention(q, k, v, h, w, splits, shifted):
     return hip.window_attention(q, k, v, h, w, splits, shifted)
 
 
+# ----------------------------------------------------------------------------- a whole transformer layer
+
+
+class _TransformerLayerFn(torch.autograd.Function):
+    """TransformerLayer.forward (gmflow/transformer.py:147-185) as one autograd node.  Forward: the inference kernels
+    (mnerf_qkv_projection, K6, K7 = mnerf_encoder_block).  Backward, all HIP: mnerf_encoder_layer_backward (the chain after
+    the attention, re-evaluated in exact fp32 from the saved attention output and layer input) -> mnerf_window_attention_backward
+    -> mnerf_qkv_backward.  Saved: the layer's two inputs, q, k, v and the attention output (six [B, h*w, 128] tensors)."""
+
+    @staticmethod
+    def forward(ctx, source, target, geom, layer, *params):
+        h, w, splits, shifted = geom
+        source, target = source.contiguous(), target.contiguous()
+        ws, ews = layer._packed_qkv(source.device)
+        q, k, v = hip.qkv_projection(ws, ews, source, target, False)
+        attn = hip.window_attention(q, k, v, h, w, splits, shifted)
+        bws, ln, bews = layer._packed_block(source.device)
+        b, n, c = source.shape
+        out = hip.encoder_block(attn.reshape(b * n, c), source.reshape(b * n, c), bws, ln, not layer.no_ffn, bews).reshape(b, n, c)
+        ctx.save_for_backward(source, target, q, k, v, attn)
+        ctx.geom, ctx.layer, ctx.params = geom, layer, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        source, target, q, k, v, attn = ctx.saved_tensors
+        layer, params = ctx.layer, ctx.params
+        h, w, splits, shifted = ctx.geom
+        b, n, c = source.shape
+        flat = lambda t: t.reshape(b * n, c)
+        grads = {p: torch.zeros_like(p) for p, need in zip(params, ctx.needs_input_grad[4:]) if need}
+        g_attn, g_source = hip.encoder_layer_backward(layer, flat(attn), flat(source), flat(g_out.contiguous()), grads)
+        gq, gk, gv = hip.window_attention_backward(q, k, v, attn, g_attn.reshape(b, n, c), h, w, splits, shifted)
+        wq, wk, wv = layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight
+        g_xq, g_xkv = hip.qkv_backward(wq, wk, wv, flat(source), flat(target), flat(gq), flat(gk), flat(gv),
+                                       grads.get(wq), grads.get(wk), grads.get(wv))
+        g_src = (g_source + g_xq).reshape(b, n, c) if ctx.needs_input_grad[0] else None
+        g_tgt = g_xkv.reshape(b, n, c) if ctx.needs_input_grad[1] else None
+        return (g_src, g_tgt, None, None) + tuple(grads.get(p) for p in params)
+
+
+def transformer_layer(layer, source, target, h, w, splits, shifted):
+    """``layer``: a gmflow.TransformerLayer; source / target [B, h*w, 128] (target = the key / value source, already batch-swapped
+    for cross attention).  Differentiable w.r.t. both inputs and every parameter of the layer."""
+    params = [layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight, layer.merge.weight, layer.norm1.weight, layer.norm1.bias]
+    if not layer.no_ffn:
+        params += [layer.mlp[0].weight, layer.mlp[2].weight, layer.norm2.weight, layer.norm2.bias]
+    return _TransformerLayerFn.apply(source, target, (h, w, splits, shifted), layer, *params)
+
+
 # ----------------------------------------------------------------------------- K1..K5
 
 

@@ -29,6 +29,7 @@ extern "C" int64_t mnerf_struct_size(int32_t which) {
     case 4: return (int64_t)sizeof(mnerf_encoder_layer);
     case 5: return (int64_t)sizeof(mnerf_conv);
     case 6: return (int64_t)sizeof(mnerf_decoder_train);
+    case 7: return (int64_t)sizeof(mnerf_encoder_layer_train);
     default: return -1;
   }
 }

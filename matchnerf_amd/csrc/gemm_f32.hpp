@@ -1,0 +1,125 @@
+// Exact-fp32 MFMA GEMM with strided operands and the Linear-layer wrappers built on it (shared by decoder_backward.hip and
+// encoder_backward.hip; kernels are templates / static so that two translation units may include this header).
+#pragma once
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ exact-fp32 GEMM  C[I,J] (+)= sum_k A(i,k) B(k,j) (+ bias[j])
+struct GemmArgs {
+  const float* a;
+  long long sa_i, sa_k;
+  const float* b;
+  long long sb_k, sb_j;
+  float* c;
+  long long sc_i;
+  const float* bias;
+  int I, J, K;
+  int mode;  // 0: C = ..   1: C += .. (one workgroup per tile)   2: atomicAdd (split-K)
+};
+
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const int chunks = (g.K + 15) / 16, per = (chunks + gridDim.z - 1) / gridDim.z;
+  const int kb = blockIdx.z * per * 16;
+  const int ke = min(g.K, kb + per * 16);
+  f32x16 acc = (f32x16)(0.0f);
+  for (int k0 = kb; k0 < ke; k0 += 16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = A_KCONT ? (t & 15) : ((t >> 6) + 4 * r);
+      const int ii = A_KCONT ? ((t >> 4) + 16 * r) : (t & 63);
+      const int i = i0 + ii, k = k0 + kk;
+      As[kk][ii] = (i < g.I && k < ke) ? g.a[(long long)i * g.sa_i + (long long)k * g.sa_k] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = B_KCONT ? (t & 15) : ((t >> 6) + 4 * r);
+      const int jj = B_KCONT ? ((t >> 4) + 16 * r) : (t & 63);
+      const int j = j0 + jj, k = k0 + kk;
+      Bs[kk][jj] = (j < g.J && k < ke) ? g.b[(long long)k * g.sb_k + (long long)j * g.sb_j] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const float av = As[2 * k2 + (l >> 5)][wi * 32 + (l & 31)];
+      const float bv = Bs[2 * k2 + (l >> 5)][wj * 32 + (l & 31)];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int j = j0 + wj * 32 + (l & 31);
+  if (j >= g.J) return;
+  const float bj = (g.bias && blockIdx.z == 0) ? g.bias[j] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wi * 32 + 8 * (r >> 2) + (l >> 5) * 4 + (r & 3);
+    if (i >= g.I) continue;
+    float* p = g.c + (long long)i * g.sc_i + j;
+    const float v = acc[r] + bj;
+    if (g.mode == 0) *p = v;
+    else if (g.mode == 1) *p += v;
+    else atomicAdd(p, v);
+  }
+}
+
+static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k, const float* b, long long sb_k, long long sb_j,
+                 float* c, long long sc_i, const float* bias, int I, int J, int K, int mode) {
+  GemmArgs g{a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode};
+  const int ti = (I + 63) / 64, tj = (J + 63) / 64;
+  int split = 1;
+  if (mode == 2) {  // the reduction runs over the samples: enough splits to fill the chip, at least 256 samples each
+    split = 1024 / (ti * tj);  // (512 measured slower: 3.1 vs 2.9 ms per pass at 65 536 samples)
+    const int max_split = (K + 255) / 256;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+  }
+  const dim3 grid(ti, tj, split);
+  const bool ak = sa_k == 1, bk = sb_k == 1;
+  if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+  else if (ak) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+  else if (bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+}
+// Y[N,M] = X[N,K] W[M,K]^T + bias          (torch Linear; ldx / ldw / ldy = row strides)
+static void linear_fwd(hipStream_t st, const float* x, long long ldx, const float* w, long long ldw, const float* bias, float* y,
+                       long long ldy, int N, int M, int K, bool add = false) {
+  gemm(st, x, ldx, 1, w, 1, ldw, y, ldy, bias, N, M, K, add ? 1 : 0);
+}
+// dX[N,K] (+)= dY[N,M] W[M,K]
+static void linear_bwd_data(hipStream_t st, const float* dy, long long lddy, const float* w, long long ldw, float* dx, long long lddx,
+                            int N, int M, int K, bool add) {
+  gemm(st, dy, lddy, 1, w, ldw, 1, dx, lddx, nullptr, N, K, M, add ? 1 : 0);
+}
+// dW[M,K] += dY[N,M]^T X[N,K]
+static void linear_bwd_weight(hipStream_t st, const float* dy, long long lddy, const float* x, long long ldx, float* dw, long long lddw,
+                              int N, int M, int K) {
+  if (dw) gemm(st, dy, 1, lddy, x, ldx, 1, dw, lddw, nullptr, M, K, N, 2);
+}
+
+// ------------------------------------------------------------------ elementwise pieces
+// out[j] += sum_n x[n, j]   (bias gradients, LayerNorm gain / shift gradients); M <= 128
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ldx, int N, int M, float* __restrict__ out) {
+  __shared__ float part[256];
+  const int rows_per_pass = 256 / M;
+  const int j = threadIdx.x % M, lane_row = threadIdx.x / M;
+  float s = 0.0f;
+  if (lane_row < rows_per_pass)
+    for (long long n = (long long)blockIdx.x * rows_per_pass + lane_row; n < N; n += (long long)gridDim.x * rows_per_pass) s += x[n * ldx + j];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < M) {
+    float tot = 0.0f;
+    for (int r = 0; r < rows_per_pass; ++r) tot += part[r * M + threadIdx.x];
+    atomicAdd(out + threadIdx.x, tot);
+  }
+}
+static void colsum(hipStream_t st, const float* x, long long ldx, int N, int M, float* out) {
+  if (!out) return;
+  hipLaunchKernelGGL(colsum_kernel<0>, dim3(256), dim3(256), 0, st, x, ldx, N, M, out);
+}
+

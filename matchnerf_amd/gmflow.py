@@ -23,6 +23,7 @@ forward pass designed around what the render kernels consume:
 There is no CPU path: ``forward`` needs the HIP library and a GPU tensor.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -299,6 +300,11 @@ class TransformerLayer(nn.Module):
             if kv_swap:
                 half = target.shape[0] // 2
                 target = torch.cat([target[half:], target[:half]], 0)
+            if source.is_cuda and os.environ.get("MNERF_ENC_BACKWARD", "hip") != "torch":
+                # training: the layer as ONE autograd node - fused HIP kernels forward (the inference kernels), HIP backward
+                # (mnerf_encoder_layer_backward / mnerf_window_attention_backward / mnerf_qkv_backward): autograd.py
+                from .autograd import transformer_layer
+                return transformer_layer(self, source, target, h, w, splits, shifted)
             q = self.q_proj(source)
             k = self.k_proj(target)
             v = self.v_proj(target)

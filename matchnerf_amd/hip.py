@@ -27,7 +27,8 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats")
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
+           "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward")
 
 
 class MnerfError(RuntimeError):
@@ -78,6 +79,13 @@ class DecoderTrain(C.Structure):
 class EncoderLayer(C.Structure):
     _fields_ = [("wstream", C.c_void_p), ("wstream_floats", C.c_int64), ("ln", C.c_void_p), ("ffn", C.c_int32),
                 ("ew_merge", C.c_int32), ("ew_w1", C.c_int32), ("ew_w2", C.c_int32)]
+
+
+class EncoderLayerTrain(C.Structure):
+    """mnerf_encoder_layer_train: parameters of a transformer layer after the attention in torch's layouts + their gradients"""
+    _fields_ = [("ffn", C.c_int32), ("pad_", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("w_merge", "ln1_w", "ln1_b", "w_mlp0", "w_mlp2", "ln2_w", "ln2_b",
+                                          "g_w_merge", "g_ln1_w", "g_ln1_b", "g_w_mlp0", "g_w_mlp2", "g_ln2_w", "g_ln2_b")]
 
 
 WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
@@ -186,10 +194,16 @@ def load():
     lib.mnerf_encoder_block_wstream_floats.argtypes = [i32]
     lib.mnerf_encoder_block.restype = C.c_int
     lib.mnerf_encoder_block.argtypes = [C.POINTER(EncoderLayer), fp, fp, fp, i32, vp]
+    lib.mnerf_encoder_layer_backward_workspace_bytes.restype = i64
+    lib.mnerf_encoder_layer_backward_workspace_bytes.argtypes = [i32]
+    lib.mnerf_encoder_layer_backward.restype = C.c_int
+    lib.mnerf_encoder_layer_backward.argtypes = [C.POINTER(EncoderLayerTrain), fp, fp, fp, fp, fp, i32, vp, vp]
+    lib.mnerf_qkv_backward.restype = C.c_int
+    lib.mnerf_qkv_backward.argtypes = [fp] * 13 + [i32, vp]
     ver = lib.mnerf_abi_version()
     if ver != MNERF_ABI_VERSION:
         raise MnerfError(f"libmnerf_hip.so ABI {ver} != binding ABI {MNERF_ABI_VERSION}")
-    for which, st in enumerate((View, Rays, Scene, Decoder, EncoderLayer, ConvLayer, DecoderTrain)):
+    for which, st in enumerate((View, Rays, Scene, Decoder, EncoderLayer, ConvLayer, DecoderTrain, EncoderLayerTrain)):
         if lib.mnerf_struct_size(which) != C.sizeof(st):
             raise MnerfError(f"struct {st.__name__}: library says {lib.mnerf_struct_size(which)} bytes, "
                              f"ctypes mirror has {C.sizeof(st)}")
@@ -663,6 +677,64 @@ def window_attention_images(q, workspace, h, w, num_splits, shifted, out=None, s
                                                 C.c_void_p(workspace.data_ptr()), workspace.numel(), st),
               "mnerf_window_attention_images")
     return out
+
+
+def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None):
+    """Backward of everything after the attention in a transformer layer (mnerf_encoder_layer_backward).  ``layer``: the
+    TransformerLayer module (merge / norm1 / mlp / norm2 parameters are read in torch's layouts); attn, source, g_out [N,128];
+    ``grads``: dict parameter tensor -> gradient tensor to ACCUMULATE into (a missing entry skips that parameter).
+    -> (g_attn, g_source) [N,128]."""
+    import torch
+    lib = load()
+    for t, name in ((attn, "attn"), (source, "source"), (g_out, "g_out")):
+        _f32c(t, name)
+    n, c = source.shape
+    if c != 128 or tuple(attn.shape) != (n, c) or tuple(g_out.shape) != (n, c):
+        raise MnerfError(f"encoder_layer_backward: attn {tuple(attn.shape)}, source {tuple(source.shape)}, g_out {tuple(g_out.shape)}")
+    L = EncoderLayerTrain()
+    L.ffn = int(not layer.no_ffn)
+    keep = []
+
+    def put(field, p):
+        w = p.detach()
+        _f32c(w, field)
+        keep.append(w)
+        setattr(L, field, w.data_ptr())
+        g = grads.get(p)
+        if g is not None:
+            _f32c(g, "grad " + field)
+            if tuple(g.shape) != tuple(p.shape):
+                raise MnerfError(f"encoder_layer_backward: gradient of {field} has shape {tuple(g.shape)}")
+            setattr(L, "g_" + field, g.data_ptr())
+
+    put("w_merge", layer.merge.weight), put("ln1_w", layer.norm1.weight), put("ln1_b", layer.norm1.bias)
+    if not layer.no_ffn:
+        put("w_mlp0", layer.mlp[0].weight), put("w_mlp2", layer.mlp[2].weight)
+        put("ln2_w", layer.norm2.weight), put("ln2_b", layer.norm2.bias)
+    g_attn, g_source = torch.empty_like(source), torch.empty_like(source)
+    ws = _grow_only_workspace(source.device, int(lib.mnerf_encoder_layer_backward_workspace_bytes(n)) // 4, stream)
+    with _on(source.device, stream) as st:
+        check(lib.mnerf_encoder_layer_backward(C.byref(L), _ptr(attn), _ptr(source), _ptr(g_out), _ptr(g_attn), _ptr(g_source), n,
+                                               C.c_void_p(ws.data_ptr()), st), "mnerf_encoder_layer_backward")
+    return g_attn, g_source
+
+
+def qkv_backward(w_q, w_k, w_v, x_q, x_kv, g_q, g_k, g_v, gw_q=None, gw_k=None, gw_v=None, stream=None):
+    """Backward of the three bias-free projections (mnerf_qkv_backward): x_* and g_* [N,128], w_* [128,128];
+    gw_* (optional) are ACCUMULATED into.  -> (g_xq, g_xkv) [N,128]."""
+    import torch
+    lib = load()
+    ts = [w_q.detach(), w_k.detach(), w_v.detach(), x_q, x_kv, g_q, g_k, g_v]
+    for t in ts:
+        _f32c(t, "qkv_backward operand")
+    n = x_q.shape[0]
+    if any(tuple(t.shape) != (n, 128) for t in ts[3:]) or any(tuple(t.shape) != (128, 128) for t in ts[:3]):
+        raise MnerfError("qkv_backward: expected [N,128] activations / gradients and [128,128] weights")
+    g_xq, g_xkv = torch.empty_like(x_q), torch.empty_like(x_q)
+    with _on(x_q.device, stream) as st:
+        check(lib.mnerf_qkv_backward(*[_ptr(t) for t in ts], _ptr(g_xq), _ptr(g_xkv), _ptr(gw_q), _ptr(gw_k), _ptr(gw_v), n, st),
+              "mnerf_qkv_backward")
+    return g_xq, g_xkv
 
 
 def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):

@@ -166,7 +166,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     """ctypes mirrors of the by-value structs have the sizes the C side was compiled with."""
     lib = hip.load()
-    for which, st in enumerate((hip.View, hip.Rays, hip.Scene, hip.Decoder, hip.EncoderLayer, hip.ConvLayer, hip.DecoderTrain)):
+    for which, st in enumerate((hip.View, hip.Rays, hip.Scene, hip.Decoder, hip.EncoderLayer, hip.ConvLayer, hip.DecoderTrain,
+                                hip.EncoderLayerTrain)):
         assert lib.mnerf_struct_size(which) == ctypes.sizeof(st), st.__name__
     assert lib.mnerf_struct_size(99) == -1
     assert ctypes.sizeof(hip.View) == 23 * 4

@@ -9,10 +9,11 @@ import bench
 
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = False
-for mode in ("hip", "torch", "hip"):
-    os.environ["MNERF_WA_BACKWARD"] = mode
+for enc, wa in (("hip", "hip"), ("torch", "hip"), ("torch", "torch"), ("hip", "hip")):
+    os.environ["MNERF_ENC_BACKWARD"], os.environ["MNERF_WA_BACKWARD"] = enc, wa
     r = bench.train_step_workload(dev)
-    print(mode, r["ms_per_iteration"], "ms per iteration, decoder backward", r["decoder_backward_ms"], "loss", r["loss"], flush=True)
+    print(f"transformer layers {enc}, attention backward {wa}:", r["ms_per_iteration"], "ms per iteration, decoder backward",
+          r["decoder_backward_ms"], "loss", r["loss"], flush=True)
 # the attention backward alone at the DTU shape: 6 sequences, 64 x 80 tokens, 2 x 2 windows
 from matchnerf_amd import autograd as ag, hip
 g = torch.Generator().manual_seed(0)
