@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void eb_add_kernel(long long n, const float* _
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = a[i] + (b ? b[i] : 0.0f);
 }
 static int eb_grid(long long n) { return (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256); }
-static int eb_row_grid(long long rows) { return (int)((rows + 7) / 8 > 4096 ? 4096 : (rows + 7) / 8); }
+static int eb_row_grid(long long rows) { return (int)((rows + 7) / 8 > 512 ? 512 : (rows + 7) / 8); }  // (each block ends with 256 float atomics)
 
 // workspace, floats per token
 enum {

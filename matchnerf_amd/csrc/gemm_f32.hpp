@@ -66,9 +66,112 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// The same product with a 128 x 128 tile per workgroup (round 4: the transformer layers' backward runs ~550 GFLOP per training
+// step through this file, and the 64 x 64 kernel above sustains ~34 TFLOP/s): a wave owns 64 x 64 = 2 x 2 blocks, so one
+// K-step is four matrix instructions for four LDS reads (two per instruction above); the operands of chunk c + 1 are fetched
+// into registers while chunk c is multiplied and written to the OTHER LDS buffer afterwards: one barrier per 16-wide chunk.
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(256) void gemm_f32_tile128_kernel(GemmArgs g) {
+  __shared__ float As[2][16][128 + 4], Bs[2][16][128 + 4];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  const int m = l & 31, kk2 = l >> 5;
+  const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128;
+  const int chunks = (g.K + 15) / 16, per = (chunks + gridDim.z - 1) / gridDim.z;
+  const int kb = blockIdx.z * per * 16;
+  const int ke = min(g.K, kb + per * 16);
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int kk = A_KCONT ? (t & 15) : ((t >> 7) + 2 * r);
+      const int ii = A_KCONT ? ((t >> 4) + 16 * r) : (t & 127);
+      const int i = i0 + ii, k = k0 + kk;
+      ra[r] = (i < g.I && k < ke) ? g.a[(long long)i * g.sa_i + (long long)k * g.sa_k] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int kk = B_KCONT ? (t & 15) : ((t >> 7) + 2 * r);
+      const int jj = B_KCONT ? ((t >> 4) + 16 * r) : (t & 127);
+      const int j = j0 + jj, k = k0 + kk;
+      rb[r] = (j < g.J && k < ke) ? g.b[(long long)k * g.sb_k + (long long)j * g.sb_j] : 0.0f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      As[buf][A_KCONT ? (t & 15) : ((t >> 7) + 2 * r)][A_KCONT ? ((t >> 4) + 16 * r) : (t & 127)] = ra[r];
+      Bs[buf][B_KCONT ? (t & 15) : ((t >> 7) + 2 * r)][B_KCONT ? ((t >> 4) + 16 * r) : (t & 127)] = rb[r];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = (f32x16)(0.0f);
+  if (kb < ke) {
+    fetch(kb);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 16, buf ^= 1) {
+    const bool more = k0 + 16 < ke;
+    if (more) fetch(k0 + 16);  // in flight during the matrix instructions below
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) {
+      const float a0 = As[buf][2 * k2 + kk2][wi * 64 + m], a1 = As[buf][2 * k2 + kk2][wi * 64 + 32 + m];
+      const float b0 = Bs[buf][2 * k2 + kk2][wj * 64 + m], b1 = Bs[buf][2 * k2 + kk2][wj * 64 + 32 + m];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);  // (the other buffer was last read before the previous barrier)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) {
+    const int j = j0 + wj * 64 + bj * 32 + m;
+    if (j >= g.J) continue;
+    const float bias_j = (g.bias && blockIdx.z == 0) ? g.bias[j] : 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 64 + bi * 32 + 8 * (r >> 2) + kk2 * 4 + (r & 3);
+        if (i >= g.I) continue;
+        float* p = g.c + (long long)i * g.sc_i + j;
+        const float v = acc[bi][bj][r] + bias_j;
+        if (g.mode == 0) *p = v;
+        else if (g.mode == 1) *p += v;
+        else atomicAdd(p, v);
+      }
+  }
+}
+
+#ifndef MNERF_GEMM_TILE128
+#define MNERF_GEMM_TILE128 1  // 0: every product through the 64 x 64 kernel (round 3)
+#endif
 static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k, const float* b, long long sb_k, long long sb_j,
                  float* c, long long sc_i, const float* bias, int I, int J, int K, int mode) {
   GemmArgs g{a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode};
+  const bool ak = sa_k == 1, bk = sb_k == 1;
+  if (MNERF_GEMM_TILE128 && I >= 128 && J >= 128) {  // both tile dimensions at least half used on average
+    const int ti = (I + 127) / 128, tj = (J + 127) / 128;
+    int split = 1;
+    if (mode == 2) {
+      split = 512 / (ti * tj);
+      const int max_split = (K + 511) / 512;
+      if (split > max_split) split = max_split;
+      if (split < 1) split = 1;
+    }
+    const dim3 grid(ti, tj, split);
+    if (ak && bk) hipLaunchKernelGGL((gemm_f32_tile128_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (ak) hipLaunchKernelGGL((gemm_f32_tile128_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (bk) hipLaunchKernelGGL((gemm_f32_tile128_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_tile128_kernel<false, false>), grid, dim3(256), 0, st, g);
+    return;
+  }
   const int ti = (I + 63) / 64, tj = (J + 63) / 64;
   int split = 1;
   if (mode == 2) {  // the reduction runs over the samples: enough splits to fill the chip, at least 256 samples each
@@ -78,7 +181,6 @@ static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k,
     if (split < 1) split = 1;
   }
   const dim3 grid(ti, tj, split);
-  const bool ak = sa_k == 1, bk = sb_k == 1;
   if (ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
   else if (ak) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
   else if (bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
