@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 6
+#define MNERF_ABI_VERSION 7
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
@@ -76,7 +76,18 @@ typedef struct mnerf_rays {
   float c2w[12];          /* target camera->world 3x4 (legacy: fp64 inverse cast to fp32,      */
                           /* camera.py:231-240; else [R^T | -R^T t], camera.py:36-42)          */
   float near_, far_;      /* target near / far (batch.near_fars[:, -1])                       */
+  /* POSE TABLE (ABI v7; video paths of small frames, models/matchnerf.py:42-71): several target poses in ONE launch.
+   * With pose_table != NULL the launch's rays are the concatenation of the poses' frames: global ray g = ray_begin + r
+   * renders pixel g % rays_per_pose of pose g / rays_per_pose, and kinv / c2w / near_ / far_ above are ignored in favour
+   * of row `pose` of the table: [kinv 9 | c2w 12 | near | far | pad] = MNERF_POSE_FLOATS fp32.  rays_per_pose must be a
+   * multiple of 64 (so that a wavefront never straddles two poses); ray_idx and strat_u must be NULL.  Accepted by
+   * mnerf_cost_volume (<= 5 views), mnerf_decoder_chunk (split-fp16 stream, S <= 64, <= 5 views) and mnerf_render_chunk
+   * (staged form) where mnerf_render_takes_pose_table() returns 1; MNERF_E_UNSUPPORTED everywhere else. */
+  const float* pose_table;
+  int32_t rays_per_pose;
+  int32_t pad_;
 } mnerf_rays;
+#define MNERF_POSE_FLOATS 24
 
 /* Source-view data resident in HBM.  Feature maps are PAIR-MAJOR and CHANNEL-LAST:
  *   feat[s] : [n_pairs][2][fh[s]][fw[s]][128] fp32,  pair p=(a,b), a<b lexicographic,
@@ -199,6 +210,11 @@ int mnerf_decoder_samples(const mnerf_decoder* dec, int32_t n_rays, int32_t n_sa
  *                             form wherever it is available (`workspace` may then be NULL). */
 int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_samples, int32_t cond_stride);
 int32_t mnerf_render_chunk_is_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays);
+/* 1 if mnerf_render_chunk accepts a mnerf_rays.pose_table for this scene / decoder / sample count / frame size (rays_per_pose
+ * = H*W): the kernel instances that take a table are the ones of the shipped shape (<= 5 source views, split-fp16 stream,
+ * sample_intvs <= 64, H*W a multiple of 64).  A caller renders pose by pose otherwise. */
+int32_t mnerf_render_takes_pose_table(const mnerf_scene* scene, const mnerf_decoder* dec, int32_t n_samples,
+                                      int32_t rays_per_pose);
 int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,
                        void* workspace, float* rgb, float* depth, float* opacity, void* stream);
 int mnerf_render_chunk_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,

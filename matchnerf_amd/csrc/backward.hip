@@ -244,6 +244,7 @@ extern "C" int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_
   if (rc) return rc;
   MNERF_REQUIRE(g_cond && g_feat0 && (scene->n_scales < 2 || g_feat1), MNERF_E_NULL,
                 "mnerf_cost_volume_backward: NULL buffer");
+  MNERF_REQUIRE(!rays->pose_table, MNERF_E_UNSUPPORTED, "mnerf_cost_volume_backward: pose tables are inference-only");
   const int sumG = scene->n_group[0] + (scene->n_scales > 1 ? scene->n_group[1] : 0);
   MNERF_REQUIRE(cond_stride >= sumG + 4 * scene->n_views + 1, MNERF_E_RANGE,
                 "mnerf_cost_volume_backward: cond_stride=%d < cond_dim+1=%d", cond_stride, sumG + 4 * scene->n_views + 1);

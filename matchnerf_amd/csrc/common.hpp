@@ -52,6 +52,8 @@ bool mnerf_once_per_device(std::atomic<unsigned long long>& mask);
 int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char* who);
 // fused ray-chunk form (decoder.hip), used by mnerf_render_chunk (render_chunk.hip)
 bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays);
+bool mnerf_cost_volume_takes_pose_table(const mnerf_scene* sc);                 // cost_volume.hip
+bool mnerf_decoder_takes_pose_table(const mnerf_decoder* dec, int n_samples);   // decoder.hip
 int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays, float* rgb,
                               float* depth, float* opacity, void* stream);
 
@@ -78,6 +80,26 @@ struct RayGeom {
   float cx, cy, cz;  // centre (camera position in world)
   float rx, ry, rz;  // un-normalised direction
 };
+
+// Pose table (mnerf_rays.pose_table): the per-launch target-camera constants of `Rt` replaced by those of pose `pose` = the one
+// the launch-local ray `first_ray` belongs to.  Callers pass a wave-uniform ray (a tile's / a ray block's first one:
+// rays_per_pose is a multiple of 64), so the 23 floats are scalar loads (from the scalar cache after a tile's first use).  The
+// address is opaque to the compiler: a kernel that needs the constants at several places of a long tile loads them again at
+// each place instead of keeping 23 more scalars alive across the tile.
+__device__ __forceinline__ int pose_of_ray(const mnerf_rays& R, int first_ray) {
+  return __builtin_amdgcn_readfirstlane((R.ray_begin + first_ray) / R.rays_per_pose);
+}
+__device__ __forceinline__ void rays_for_pose(mnerf_rays& Rt, const mnerf_rays& R, int pose) {
+  const float* p = R.pose_table + (size_t)pose * MNERF_POSE_FLOATS;
+  asm volatile("" : "+s"(p));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rt.kinv[i] = p[i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Rt.c2w[i] = p[9 + i];
+  Rt.near_ = p[21];
+  Rt.far_ = p[22];
+  Rt.ray_begin = R.ray_begin - pose * R.rays_per_pose;  // make_ray: pixel = ray_begin + local ray = the pixel inside this pose's frame
+}
 
 __device__ __forceinline__ RayGeom make_ray(const mnerf_rays& R, int ray_local) {
   int pix = R.ray_idx ? R.ray_idx[ray_local] : (R.ray_begin + ray_local);

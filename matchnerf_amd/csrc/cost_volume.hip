@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
   // re-used again by the next depth steps (temporal L1 reuse).  One chunk = a run of 32-ray
   // blocks; all lanes of a wave iterate the same number of times (shuffles need full slots).
   const long long blocks_total = ((long long)R.n_rays + 31) / 32;   // 32-ray blocks
-  const long long bpc = (blocks_total + nwg - 1) / nwg;             // blocks per chunk
-  const long long b_begin = (long long)chunk * bpc;
-  long long b_end = b_begin + bpc;
-  if (b_end > blocks_total) b_end = blocks_total;
+  // chunk c = blocks [c n / nwg, (c + 1) n / nwg): every chunk gets floor or ceil of the mean, so that all eight XCDs carry the same
+  // load at every launch size (ceil(n / nwg) blocks per chunk left the last XCDs idle whenever n was not a multiple of nwg)
+  const long long b_begin = (long long)chunk * blocks_total / nwg;
+  const long long b_end = (long long)(chunk + 1) * blocks_total / nwg;
 
   for (long long it = b_begin * S; it < b_end * S; ++it) {
     const long long rb = it / S;
@@ -224,7 +224,7 @@ __host__ __device__ inline size_t cvw_lean_lds_floats(int nslot, int seg, int vi
 
 // ============================================================================ segment walk (stand-alone kernel)
 // The walk itself lives in cv_walk.hpp (shared with the fused ray-chunk kernel); this kernel maps slots to rays.
-template <int CPL, bool UVPAIR = false>
+template <int CPL, bool UVPAIR = false, bool POSES = false>  // POSES: pose table (mnerf_rays.pose_table), one pose per block of 16 rays
 __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_lean_kernel(mnerf_scene sc, mnerf_rays R,
                                                                                    int cond_stride,
                                                                                    float* __restrict__ cond,
@@ -255,10 +255,8 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin;
   const long long blocks_total = ((long long)R.n_rays + NSLOT - 1) / NSLOT;
-  const long long bpc = (blocks_total + nwg - 1) / nwg;
-  const long long b_begin = (long long)chunk * bpc;
-  long long b_end = b_begin + bpc;
-  if (b_end > blocks_total) b_end = blocks_total;
+  const long long b_begin = (long long)chunk * blocks_total / nwg;  // balanced contiguous runs (see cost_volume_kernel)
+  const long long b_end = (long long)(chunk + 1) * blocks_total / nwg;
 
   for (long long it = b_begin * n_seg; it < b_end * n_seg; ++it) {
     const long long rb = it / n_seg;
@@ -268,8 +266,16 @@ __global__ __launch_bounds__(256, (CPL == 16 ? 2 : CVW_WAVES)) void cost_volume_
     if (!ray_live) ray_ll = R.n_rays - 1;
     const int ray = (int)ray_ll;
     const int jrow = j0 < S ? j0 : S - 1;
-    cv_walk_unit<CPL, CVW_SEG, true, UVPAIR>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
-                                       uv_lds, wrec_lds, cs_lds, sub, pair_begin, pair_end);
+    if constexpr (POSES) {
+      mnerf_rays Rt = R;  // the block's NSLOT rays share a pose (rays_per_pose is a multiple of 64)
+      const long long first = rb * NSLOT < R.n_rays ? rb * NSLOT : R.n_rays - 1;
+      rays_for_pose(Rt, R, pose_of_ray(R, (int)first));
+      cv_walk_unit<CPL, CVW_SEG, true, UVPAIR>(sc, Rt, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
+                                         uv_lds, wrec_lds, cs_lds, sub, pair_begin, pair_end);
+    } else {
+      cv_walk_unit<CPL, CVW_SEG, true, UVPAIR>(sc, R, ray, ray_live, j0, cond + ((size_t)ray * S + jrow) * cond_stride, cond_stride,
+                                         uv_lds, wrec_lds, cs_lds, sub, pair_begin, pair_end);
+    }
   }
 }
 
@@ -349,10 +355,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume_tile_kernel(mnerf_scene sc
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int chunk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin;
   const long long blocks_total = ((long long)R.n_rays + NSLOT - 1) / NSLOT;
-  const long long bpc = (blocks_total + nwg - 1) / nwg;
-  const long long b_begin = (long long)chunk * bpc;
-  long long b_end = b_begin + bpc;
-  if (b_end > blocks_total) b_end = blocks_total;
+  const long long b_begin = (long long)chunk * blocks_total / nwg;  // balanced contiguous runs (see cost_volume_kernel)
+  const long long b_end = (long long)(chunk + 1) * blocks_total / nwg;
 
   for (int i = tid; i < 2 * 2 * CVT_PLACES_MAX; i += 256) tags[i] = -1;
   __syncthreads();
@@ -491,6 +495,8 @@ __global__ __launch_bounds__(256, 2) void cost_volume_tile_kernel(mnerf_scene sc
 
 int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char* who) {
   MNERF_REQUIRE(sc && rays, MNERF_E_NULL, "%s: NULL argument struct", who);
+  MNERF_REQUIRE(rays->pose_table || rays->rays_per_pose == 0, MNERF_E_RANGE, "%s: rays_per_pose=%d without a pose table", who,
+                rays->rays_per_pose);
   MNERF_REQUIRE(sc->n_views >= 2 && sc->n_views <= MNERF_MAX_VIEWS, MNERF_E_RANGE,
                 "%s: n_views=%d outside [2,%d]", who, sc->n_views, MNERF_MAX_VIEWS);
   MNERF_REQUIRE(sc->n_scales == 1 || sc->n_scales == 2, MNERF_E_RANGE, "%s: n_scales=%d", who,
@@ -515,6 +521,34 @@ int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char*
   return MNERF_OK;
 }
 
+// Which kernel a scene gets: variant 3 / 4 = segment walk with 16 / 8 lanes per sample, 5 = texel tiles, 0 = one sample per slot
+// iteration; uvpair = the 16-lane walk that keeps only the current pair's projections (many views).
+static void cv_pick_kernel(const mnerf_scene* scene, int sumG, int* variant_out, bool* uvpair_out) {
+  int variant = mnerf_tune().cv_variant;
+  if (variant != 3 && variant != 4 && variant != 5) variant = 0;
+  if (sumG > CVW_CS_MAX) variant = 0;
+  if (variant == 5) {  // texel tiles: 8-sample walks need at most 8 lanes per channel group; LDS for two workgroups per CU
+    bool ok = cvt_lds_bytes(scene->n_views, sumG) <= 80 * 1024;
+    for (int s = 0; s < scene->n_scales; ++s) ok = ok && scene->n_group[s] >= 2;
+    if (!ok) variant = 3;
+  }
+  // A workgroup's LDS is NSLOT x SEG x (2 V + 16 + cs) floats: 38 KiB at 3 views (four workgroups per CU, what 128 VGPRs
+  // allow), 52 KiB at 10 views (three).  From the view count at which the fourth workgroup no longer fits, the 16-lane form
+  // keeps only the current pair's projections (UVPAIR, cv_walk.hpp).
+  bool uvpair = variant == 3 && cvw_lean_lds_floats(16, CVW_SEG, scene->n_views, (sumG + 3) & ~3) * sizeof(float) > 40 * 1024;
+  if (variant == 3 && mnerf_tune().cv_uvpair >= 0) uvpair = mnerf_tune().cv_uvpair != 0;
+  *variant_out = variant, *uvpair_out = uvpair;
+}
+
+// the pose-table instance of the cost volume is the 16-lane walk with all views' projections resident (<= 5 views)
+bool mnerf_cost_volume_takes_pose_table(const mnerf_scene* scene) {
+  int sumG = 0, variant;
+  bool uvpair;
+  for (int s = 0; s < scene->n_scales; ++s) sumG += scene->n_group[s];
+  cv_pick_kernel(scene, sumG, &variant, &uvpair);
+  return variant == 3 && !uvpair;
+}
+
 extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* rays,
                                  int32_t cond_stride, float* cond, void* stream) {
   int rc = mnerf_scene_check(scene, rays, "mnerf_cost_volume");
@@ -525,17 +559,21 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
                 "mnerf_cost_volume: cond_stride=%d < cond_dim+1=%d", cond_stride,
                 sumG + 4 * scene->n_views + 1);
   if (rays->n_rays == 0) return MNERF_OK;
+  const bool poses = rays->pose_table != nullptr;
+  if (poses) {
+    MNERF_REQUIRE(rays->rays_per_pose > 0 && rays->rays_per_pose % 64 == 0, MNERF_E_RANGE,
+                  "mnerf_cost_volume: pose table needs rays_per_pose = a positive multiple of 64, got %d", rays->rays_per_pose);
+    MNERF_REQUIRE(!rays->ray_idx && !rays->strat_u, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: a pose table excludes ray_idx / strat_u");
+  }
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 31) / 32;  // 32 sample slots per 256-thread workgroup
   if (blocks > 2048) blocks = 2048;      // 8 workgroups per CU, contiguous chunk each
-  int variant = mnerf_tune().cv_variant;  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 0 = one sample per slot iteration
-  if (variant != 3 && variant != 4 && variant != 5) variant = 0;
-  if (sumG > CVW_CS_MAX) variant = 0;
-  if (variant == 5) {  // texel tiles: 8-sample walks need at most 8 lanes per channel group; LDS for two workgroups per CU
-    bool ok = cvt_lds_bytes(scene->n_views, sumG) <= 80 * 1024;
-    for (int s = 0; s < scene->n_scales; ++s) ok = ok && scene->n_group[s] >= 2;
-    if (!ok) variant = 3;
-  }
+  int variant;
+  bool uvpair;
+  cv_pick_kernel(scene, sumG, &variant, &uvpair);
+  MNERF_REQUIRE(!poses || (variant == 3 && !uvpair), MNERF_E_UNSUPPORTED,
+                "mnerf_cost_volume: a pose table needs the 16-lane segment walk with all views' projections resident "
+                "(cv_variant 3, <= 5 source views; mnerf_render_takes_pose_table tells)");
   if (variant == 5) {
     const size_t lds = cvt_lds_bytes(scene->n_views, sumG);
     static std::atomic<int> tile_lds_set[64];
@@ -564,11 +602,6 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
   if (variant == 3 || variant == 4) {  // lean walk: 16 / 8 lanes per sample
     const int nslot = variant == 4 ? 32 : 16;
     const int cs_pad = (sumG + 3) & ~3;
-    // A workgroup's LDS is NSLOT x SEG x (2 V + 16 + cs) floats: 38 KiB at 3 views (four workgroups per CU, what 128 VGPRs
-    // allow), 52 KiB at 10 views (three).  From the view count at which the fourth workgroup no longer fits, the 16-lane form
-    // keeps only the current pair's projections (UVPAIR, cv_walk.hpp).
-    bool uvpair = variant == 3 && cvw_lean_lds_floats(nslot, CVW_SEG, scene->n_views, cs_pad) * sizeof(float) > 40 * 1024;
-    if (variant == 3 && mnerf_tune().cv_uvpair >= 0) uvpair = mnerf_tune().cv_uvpair != 0;
     const size_t lds = cvw_lean_lds_floats(nslot, CVW_SEG, uvpair ? 2 : scene->n_views, cs_pad) * sizeof(float);
     MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
     // the LDS attribute is per device and only ever raised: largest request seen per (variant, device)
@@ -587,7 +620,11 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
       seen.store((int)lds, std::memory_order_relaxed);
     }
     long long wgs = ((long long)rays->n_rays + nslot - 1) / nslot;
-    int cap = variant == 4 ? 2048 : 4096;
+    // 16-lane walk: ONE ray block per workgroup at every launch size.  A capped grid (4 096 until round 4) gave the workgroups
+    // 1 or 2 blocks each whenever the launch was not a multiple of the cap, and the hardware's round-robin placement put the
+    // 2-block workgroups on the same quarter of the CUs: 81 920 rays took 15.7 ms where 65 536 take 9.5 (now 9.4; one launch
+    // of the whole 327 680-ray frame 9.2).  MNERF_CV_GRID caps it again.
+    long long cap = variant == 4 ? 2048 : (1ll << 30);
     if (mnerf_tune().cv_grid > 0) cap = mnerf_tune().cv_grid;
     if (wgs > cap) wgs = cap;
     const int n_pairs = scene->n_views * (scene->n_views - 1) / 2;
@@ -603,6 +640,15 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
       for (int p0 = 0; p0 < n_pairs; p0 += blk)
         hipLaunchKernelGGL((cost_volume_lean_kernel<8, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                            *scene, *rays, cond_stride, cond, p0, p0 + blk < n_pairs ? p0 + blk : n_pairs);
+    } else if (poses) {
+      static std::atomic<int> pose_lds_set[64];
+      std::atomic<int>& pseen = pose_lds_set[dev & 63];
+      if ((int)lds > pseen.load(std::memory_order_relaxed)) {
+        (void)hipFuncSetAttribute((const void*)cost_volume_lean_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        pseen.store((int)lds, std::memory_order_relaxed);
+      }
+      hipLaunchKernelGGL((cost_volume_lean_kernel<8, false, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
+                         *scene, *rays, cond_stride, cond, 0, n_pairs);
     } else
       hipLaunchKernelGGL(cost_volume_lean_kernel<8>, dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                          *scene, *rays, cond_stride, cond, 0, n_pairs);

@@ -1872,9 +1872,12 @@ __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float
 // 6-7, 4 for 8-11 (BASELINE config[4]: 10 views, 50 inputs).  Only the first stage, its operands and its place in the weight
 // stream depend on it; with FS > 2 a team's rows of the next tile (128 x cond_stride floats) no longer fit its half of ring
 // slot 1, so V_0 reads them from global memory.
-template <int SP, int FS = 2>
+// POSES: the launch carries a pose table (mnerf_rays.pose_table: several target poses of a small frame in one launch); a team's
+// rays of a tile belong to one pose (rays_per_pose is a multiple of 64), whose camera constants replace the launch-wide ones
+// once per tile.  A separate instance so that the default kernel's scalar-register budget is untouched.
+template <int SP, int FS = 2, bool POSES = false>
 __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
-    mnerf_decoder D, DecSched sch, PPSched pps, mnerf_view view0, mnerf_rays R, const float* __restrict__ cond,
+    mnerf_decoder D, DecSched sch, PPSched pps, mnerf_view view0, mnerf_rays Rl, const float* __restrict__ cond,
     float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_opacity,
     float* __restrict__ dbg_rgb_s, float* __restrict__ dbg_sigma, const float* __restrict__ ext_ndc,
     const float* __restrict__ ext_dir) {
@@ -1893,6 +1896,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   const int lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, tw = wave & 3;
+  const mnerf_rays& R = Rl;  // launch-wide fields (counts, sizes); the camera constants are read through Rt inside the tile loop
   const int S = R.n_samples;
   const int rays_per_team = TEAM / Sp, rays_per_tile = 2 * rays_per_team;
   const int n_tiles = (R.n_rays + rays_per_tile - 1) / rays_per_tile;
@@ -2108,6 +2112,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     pp_ph = 0;
 #endif
     const bool has_next = tile + tile_step < tile_end;
+    // this team's target camera for the tile: the launch's, or (POSES) its pose's row of the table, fetched where it is used
+    int tile_pose = 0;
+    if constexpr (POSES)
+      tile_pose = pose_of_ray(Rl, (tile * rays_per_tile + team * rays_per_team < Rl.n_rays) ? tile * rays_per_tile + team * rays_per_team : Rl.n_rays - 1);
+#define PP_TILE_RAYS(NAME_)                                  \
+  mnerf_rays NAME_ = Rl;                                     \
+  if constexpr (POSES) rays_for_pose(NAME_, Rl, tile_pose)
     // Everything that depends only on the lane index is re-derived per tile from an OPAQUE copy of it: hoisted out of the
     // tile loop these values (sample indices, LDS addresses, pointers) stay live across all 28 phases, the register
     // allocator parks them in scratch, and phase V_0 became a chain of ~20 scratch reloads (7 k cycles, measured).
@@ -2172,8 +2183,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       y = ext_ndc[gs * 3 + 1];
       z = ext_ndc[gs * 3 + 2];
     } else {
-      const RayGeom g = make_ray(R, ray);
-      const float dpt = sample_depth(R, ray, j);
+      PP_TILE_RAYS(Rt);
+      const RayGeom g = make_ray(Rt, ray);
+      const float dpt = sample_depth(Rt, ray, j);
       float wx_, wy_, wz_;
       ray_point(g, dpt, wx_, wy_, wz_);
       project(view0, wx_, wy_, wz_, wm1, hm1, x, y, z);
@@ -2376,7 +2388,8 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         dy = ext_dir[gs * 3 + 1];
         dz = ext_dir[gs * 3 + 2];
       } else {
-        const RayGeom g = make_ray(R, ray);
+        PP_TILE_RAYS(Rt);
+        const RayGeom g = make_ray(Rt, ray);
         const float rn = fmaxf(sqrtf(g.rx * g.rx + g.ry * g.ry + g.rz * g.rz), 1e-12f);
         const float ux = g.rx / rn, uy = g.ry / rn, uz = g.rz / rn;
         dx = ux * view0.extr[0] + uy * view0.extr[1] + uz * view0.extr[2];
@@ -2564,12 +2577,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     if (team == 1 && has_next) stage_dma(0, 2);
     PP_TSYNC();
     // ============================================================ phase 27 = T4: compositing (one wavefront per ray)
+    PP_TILE_RAYS(Rt);
     for (int rt = tw; rt < rays_per_team; rt += 4) {
       const int rr = tile * rays_per_tile + team * rays_per_team + rt;
       if (rr >= R.n_rays || !out_rgb) continue;
       float rlen = 1.0f;
       if (!D.wo_render_interval) {
-        const RayGeom gg = make_ray(R, rr);
+        const RayGeom gg = make_ray(Rt, rr);
         rlen = sqrtf(gg.rx * gg.rx + gg.ry * gg.ry + gg.rz * gg.rz);
       }
       float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, ao = 0.f;
@@ -2580,9 +2594,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         float dd = 0.f;
         if (ok) {
           c = reinterpret_cast<const float4*>(rs_lds)[rt * Sp + jj];
-          dd = sample_depth(R, rr, jj);
+          dd = sample_depth(Rt, rr, jj);
           if (!D.wo_render_interval) {
-            const float intv = (jj + 1 < S) ? (sample_depth(R, rr, jj + 1) - dd) : 1e10f;
+            const float intv = (jj + 1 < S) ? (sample_depth(Rt, rr, jj + 1) - dd) : 1e10f;
             c.w = c.w * (intv * rlen);
           }
         }
@@ -2661,6 +2675,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #undef PP_MFMA
 #undef PP_MFMA1
 #undef PP_HDR_LDS
+#undef PP_TILE_RAYS
 #undef PP_SEG_SRC
 #undef PP_SLOT_LDS
 }
@@ -2793,6 +2808,19 @@ extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_s
 
 #endif  // MNERF_DECODER_PART == 0
 
+#if MNERF_DECODER_PART == 0
+// Does the ping-pong form (decoder_pp_kernel) take this decoder at Sp padded samples?  -> its FiLM K16-step count (2 .. 4), or 0.
+static int pp_film_steps(const mnerf_decoder* dec, const DecSched& sch, int Sp) {
+  const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
+  // FiLM stages of 2 K16-steps (<= 5 views) at every S; of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
+  const int fs = sch.film_steps;
+  const bool ok = dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp > 0 && Sp <= pp_max_s && dec->L_3D == 10 &&
+                  (fs == 2 || ((fs == 3 || fs == 4) && Sp == 64)) && dec->cond_stride <= 16 * fs && sch.enc_steps == 4 &&
+                  sch.n_seg == 20 && mnerf_tune().decoder_pp;
+  return ok ? fs : 0;
+}
+#endif
+
 static int pick_padded_samples(int S) {
   if (S <= 32) return 32;
   if (S <= 64) return 64;
@@ -2839,6 +2867,15 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   const int Sp = pick_padded_samples(rays->n_samples);
   MNERF_REQUIRE(Sp > 0, MNERF_E_UNSUPPORTED, "%s: sample_intvs=%d > 256 is not supported by the fused kernel", who,
                 rays->n_samples);
+  const bool poses = rays->pose_table != nullptr;
+  if (poses) {
+    MNERF_REQUIRE(rays->rays_per_pose > 0 && rays->rays_per_pose % 64 == 0, MNERF_E_RANGE,
+                  "%s: pose table needs rays_per_pose = a positive multiple of 64, got %d", who, rays->rays_per_pose);
+    MNERF_REQUIRE(!rays->ray_idx && !rays->strat_u && !ext_ndc && !fused_scene, MNERF_E_UNSUPPORTED,
+                  "%s: a pose table excludes ray_idx / strat_u / caller-supplied samples / the one-launch form", who);
+  } else {
+    MNERF_REQUIRE(rays->rays_per_pose == 0, MNERF_E_RANGE, "%s: rays_per_pose=%d without a pose table", who, rays->rays_per_pose);
+  }
   DecSched sch;
   const int total = build_schedule(dec, &sch);
   MNERF_REQUIRE(total > 0, MNERF_E_RANGE, "%s: cannot schedule weight stream", who);
@@ -2867,12 +2904,8 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
 #if MNERF_DECODER_PART == 0
   // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream, S <= 128 (round 3: 82.3 vs
   // 88.7 ms per 800x800 frame at 128 samples per ray; the knob can only LOWER the limit: there is no 256-sample instance)
-  const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
-  // FiLM stages of 2 K16-steps (<= 5 views) at every S; of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
-  const int fs = sch.film_steps;
-  if (!fused_scene && dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp <= pp_max_s && dec->L_3D == 10 &&
-      (fs == 2 || ((fs == 3 || fs == 4) && Sp == 64)) && dec->cond_stride <= 16 * fs &&
-      sch.enc_steps == 4 && sch.n_seg == 20 && mnerf_tune().decoder_pp) {
+  const int fs = fused_scene ? 0 : pp_film_steps(dec, sch, Sp);
+  if (fs) {
     PPSched pps;
 #if MNERF_PP_L5_H_FIRST
     const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 11, 10, 13, 14, 16, 18};  // layer 5: activation half, then encoding half
@@ -2895,16 +2928,24 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     const int tiles = (rays->n_rays + rpt - 1) / rpt;
     const int cus = mnerf_tune().decoder_pp_grid > 0 ? mnerf_tune().decoder_pp_grid : 1;  // persistent: one 8-wave workgroup per CU
     const int grid = tiles < cus ? tiles : cus;
-#define MNERF_LAUNCH_PP(SP_, FS_)                                                                                     \
+#define MNERF_LAUNCH_PP_(SP_, FS_, POSES_)                                                                            \
   do {                                                                                                                \
     const size_t lds = SmemPP<SP_>::TOTAL_FLOATS * sizeof(float);                                                     \
     static std::atomic<unsigned long long> attr_set{0};                                                               \
     if (mnerf_once_per_device(attr_set))                                                                              \
-      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_, FS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((decoder_pp_kernel<SP_, FS_>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
+      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_, FS_, POSES_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((decoder_pp_kernel<SP_, FS_, POSES_>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
                        opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
   } while (0)
-    if (fs == 3)
+#define MNERF_LAUNCH_PP(SP_, FS_) MNERF_LAUNCH_PP_(SP_, FS_, false)
+    if (poses) {  // the instances that exist with a pose table: the shipped 3-view shape at S <= 64
+      MNERF_REQUIRE(fs == 2 && (Sp == 32 || Sp == 64), MNERF_E_UNSUPPORTED,
+                    "%s: pose tables are built for <= 5 source views and sample_intvs <= 64", who);
+      if (Sp == 32)
+        MNERF_LAUNCH_PP_(32, 2, true);
+      else
+        MNERF_LAUNCH_PP_(64, 2, true);
+    } else if (fs == 3)
       MNERF_LAUNCH_PP(64, 3);
     else if (fs == 4)
       MNERF_LAUNCH_PP(64, 4);
@@ -2915,9 +2956,12 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     else
       MNERF_LAUNCH_PP(128, 2);
 #undef MNERF_LAUNCH_PP
+#undef MNERF_LAUNCH_PP_
     return mnerf_check_launch(who);
   }
 #endif
+  MNERF_REQUIRE(!poses, MNERF_E_UNSUPPORTED, "%s: a pose table needs the ping-pong decoder (split-fp16 stream, <= 5 source views, "
+                "sample_intvs <= 64, MNERF_DECODER_PP on)", who);
 #if MNERF_DECODER_PART == 1
   MNERF_REQUIRE(fused_scene, MNERF_E_NULL, "%s: the one-launch form needs the scene", who);
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_) MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1)
@@ -2961,6 +3005,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
 // walk scratch that fits one weight buffer.
 bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays) {
   if (dec->wstream_format != MNERF_WSTREAM_F16X2 || rays->n_samples > 128) return false;
+  if (rays->pose_table) return false;  // pose tables: two-launch form only
   if (dec->cond_stride > 32 || (dec->cond_dim + 15) / 16 > 2) return false;
   if (sc->n_views < 2 || sc->n_views != dec->n_views) return false;
   int sumG = 0;
@@ -2985,6 +3030,15 @@ int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, c
 }
 
 #else  // MNERF_DECODER_PART == 0
+// the pose-table instances of the decoder: the ping-pong form with a 2-step FiLM stage (<= 5 source views) at S <= 64
+bool mnerf_decoder_takes_pose_table(const mnerf_decoder* dec, int n_samples) {
+  if (!known_format(dec->wstream_format) || dec->L_3D < 0 || dec->L_3D > 16) return false;
+  DecSched sch;
+  if (build_schedule(dec, &sch) <= 0) return false;
+  const int Sp = pick_padded_samples(n_samples);
+  return (Sp == 32 || Sp == 64) && pp_film_steps(dec, sch, Sp) == 2;
+}
+
 extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,
                                    const mnerf_rays* rays, const float* cond, float* rgb,
                                    float* depth, float* opacity, float* dbg_rgb_s,

@@ -42,6 +42,8 @@ extern "C" int mnerf_ray_samples(const mnerf_rays* rays, const mnerf_view* view,
   MNERF_REQUIRE(rays->n_rays >= 0 && rays->n_samples >= 1, MNERF_E_RANGE,
                 "mnerf_ray_samples: n_rays=%d S=%d", rays->n_rays, rays->n_samples);
   MNERF_REQUIRE(!ndc || view, MNERF_E_NULL, "mnerf_ray_samples: view required for ndc output");
+  MNERF_REQUIRE(!rays->pose_table && rays->rays_per_pose == 0, MNERF_E_UNSUPPORTED,
+                "mnerf_ray_samples: pose tables are a rendering-launch feature (mnerf_cost_volume / mnerf_decoder_chunk)");
   if (rays->n_rays == 0) return MNERF_OK;
   mnerf_view v = {};
   if (view) v = *view;

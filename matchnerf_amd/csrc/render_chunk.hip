@@ -35,6 +35,13 @@ extern "C" int32_t mnerf_render_chunk_is_fused(const mnerf_scene* scene, const m
   return mnerf_fused_render_applies(scene, dec, rays) ? 1 : 0;
 }
 
+extern "C" int32_t mnerf_render_takes_pose_table(const mnerf_scene* scene, const mnerf_decoder* dec, int32_t n_samples,
+                                                 int32_t rays_per_pose) {
+  if (!scene || !dec || n_samples < 1 || rays_per_pose <= 0 || rays_per_pose % 64) return 0;
+  if (scene->n_views < 2 || scene->n_views > MNERF_MAX_VIEWS || scene->n_scales < 1 || scene->n_scales > 2) return 0;
+  return mnerf_cost_volume_takes_pose_table(scene) && mnerf_decoder_takes_pose_table(dec, n_samples) ? 1 : 0;
+}
+
 extern "C" int mnerf_render_chunk_fused(const mnerf_scene* scene, const mnerf_decoder* dec,
                                         const mnerf_rays* rays, float* rgb, float* depth,
                                         float* opacity, void* stream) {

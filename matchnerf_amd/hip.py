@@ -14,7 +14,8 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 6
+MNERF_ABI_VERSION = 7
+MNERF_POSE_FLOATS = 24  # floats of one row of mnerf_rays.pose_table
 MNERF_OK, MNERF_E_NULL, MNERF_E_RANGE, MNERF_E_UNSUPPORTED, MNERF_E_ALIGN = 0, -1, -2, -3, -4  # include/mnerf.h
 MNERF_MAX_VIEWS = 16
 MNERF_COND_STRIDE_MAX, MNERF_COND_STRIDE_MAX_F32 = 96, 64
@@ -26,7 +27,7 @@ _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
-           "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_window_attention",
+           "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward")
 
@@ -43,7 +44,8 @@ class Rays(C.Structure):
     _fields_ = [("n_rays", C.c_int32), ("n_samples", C.c_int32), ("ray_begin", C.c_int32),
                 ("legacy_coord", C.c_int32), ("depth_inverse", C.c_int32), ("height", C.c_int32),
                 ("width", C.c_int32), ("ray_idx", C.c_void_p), ("strat_u", C.c_void_p),
-                ("kinv", C.c_float * 9), ("c2w", C.c_float * 12), ("near_", C.c_float), ("far_", C.c_float)]
+                ("kinv", C.c_float * 9), ("c2w", C.c_float * 12), ("near_", C.c_float), ("far_", C.c_float),
+                ("pose_table", C.c_void_p), ("rays_per_pose", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Scene(C.Structure):
@@ -156,6 +158,8 @@ def load():
     lib.mnerf_render_workspace_bytes.argtypes = [i32, i32, i32]
     lib.mnerf_render_chunk_is_fused.restype = i32
     lib.mnerf_render_chunk_is_fused.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays)]
+    lib.mnerf_render_takes_pose_table.restype = i32
+    lib.mnerf_render_takes_pose_table.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), i32, i32]
     lib.mnerf_render_chunk_fused.restype = C.c_int
     lib.mnerf_render_chunk_fused.argtypes = [C.POINTER(Scene), C.POINTER(Decoder), C.POINTER(Rays), fp, fp, fp, vp]
     lib.mnerf_render_chunk.restype = C.c_int
@@ -248,8 +252,12 @@ def make_view(extr34, intr33, near, far):
 
 
 def make_rays(n_rays, n_samples, height, width, kinv, c2w, near, far, ray_begin=0, legacy=True,
-              depth_inverse=False, ray_idx_ptr=None, strat_u_ptr=None):
+              depth_inverse=False, ray_idx_ptr=None, strat_u_ptr=None, pose_table_ptr=None, rays_per_pose=0):
+    """``pose_table_ptr`` / ``rays_per_pose``: several target poses in one launch (include/mnerf.h: POSE TABLE; rows from
+    ``pose_table_rows``); kinv / c2w / near / far are then ignored (pass those of any pose)."""
     r = Rays()
+    r.pose_table = pose_table_ptr
+    r.rays_per_pose = int(rays_per_pose) if pose_table_ptr else 0
     r.n_rays, r.n_samples, r.ray_begin = int(n_rays), int(n_samples), int(ray_begin)
     r.legacy_coord, r.depth_inverse = int(bool(legacy)), int(bool(depth_inverse))
     r.height, r.width = int(height), int(width)
@@ -259,6 +267,16 @@ def make_rays(n_rays, n_samples, height, width, kinv, c2w, near, far, ray_begin=
     _fill(r.c2w, c2w)
     r.near_, r.far_ = float(near), float(far)
     return r
+
+
+def pose_table_rows(poses):
+    """[(kinv [3,3], c2w [3,4], near, far), ...] -> float32 [n, MNERF_POSE_FLOATS] rows of mnerf_rays.pose_table"""
+    rows = np.zeros((len(poses), MNERF_POSE_FLOATS), np.float32)
+    for i, (kinv, c2w, near, far) in enumerate(poses):
+        rows[i, :9] = np.asarray(kinv, np.float32).reshape(-1)
+        rows[i, 9:21] = np.asarray(c2w, np.float32).reshape(-1)
+        rows[i, 21], rows[i, 22] = near, far
+    return rows
 
 
 @contextlib.contextmanager
@@ -515,6 +533,11 @@ class KernelTimer:
 def render_is_fused(scene, dec, rays):
     """True when the one-launch form of the ray chunk (mnerf_render_chunk_fused) exists for this configuration."""
     return bool(load().mnerf_render_chunk_is_fused(C.byref(scene), C.byref(dec), C.byref(rays)))
+
+
+def render_takes_pose_table(scene, dec, n_samples, rays_per_pose):
+    """True when a ray chunk of this scene / decoder may carry several target poses (``make_rays(pose_table_ptr=...)``)."""
+    return bool(load().mnerf_render_takes_pose_table(C.byref(scene), C.byref(dec), int(n_samples), int(rays_per_pose)))
 
 
 def render_chunk(scene, dec, rays, workspace, rgb, depth, opacity, stream=None, timer=None, fused=False):

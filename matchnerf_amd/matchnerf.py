@@ -29,7 +29,7 @@ from .gmflow import GMFlow, pair_major_to_view_chunks
 # rays per kernel launch when a full image is rendered.  The reference's
 # ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
 # chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
-MAX_RAYS_PER_LAUNCH = 65536
+MAX_RAYS_PER_LAUNCH = int(os.environ.get("MNERF_MAX_RAYS_PER_LAUNCH", "65536"))
 # rays per autograd node when gradients are required (bounds the temporaries of the re-evaluated backward)
 GRAD_RAYS_PER_CALL = 8192
 
@@ -57,6 +57,7 @@ class MatchNeRF(torch.nn.Module):
         self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
         self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
+        self.pose_batching = os.environ.get("MNERF_POSE_BATCHING", "1") != "0"  # video of small frames: several poses per launch
 
     def _dec(self):
         """the CondNeRF module, also when the reference's coach wrapped it in nn.DataParallel (coach.py:83-85)"""
@@ -80,6 +81,18 @@ class MatchNeRF(torch.nn.Module):
 
         mode_rand_rays = getattr(self.opts.nerf, f"rand_rays_{mode}", 0)
         collected, frames_done = {}, {}
+        if render_video and self.pose_batching:
+            # small frames: as many poses per launch as fill one (mnerf_rays.pose_table); None where the kernels or the
+            # frame size do not take a table -> the pose loop below
+            frames = self.render_poses(self.opts, poses_paths, ref_poses=ref_poses, ref_images=ref_images,
+                                       ref_feats_list=ref_feats_list)
+            if frames is not None:
+                for k, v in frames.items():  # [n_poses, B, N, C] -> the reference's frame-major [n_poses * B, N, C]
+                    host = torch.empty((v.shape[0] * v.shape[1],) + tuple(v.shape[2:]), dtype=v.dtype, pin_memory=True)
+                    host.copy_(v.reshape(host.shape), non_blocking=True)
+                    collected[k] = host
+                    frames_done[k] = v
+                poses_paths = []
         for cur_tgt_pose in poses_paths:
             if mode_rand_rays and mode in ["train", "test-optim"]:
                 batch.ray_idx = torch.randperm(img_h * img_w, device=ref_images.device)[:mode_rand_rays // batch_size]
@@ -280,6 +293,62 @@ class MatchNeRF(torch.nn.Module):
                     ws = self._workspace(hip.render_workspace_bytes(chunk, n_samples, dec.cond_stride) // 4, device)
                 hip.render_chunk(sc, dec, rays, ws, rgb[b, c:c + m], depth[b, c:c + m], opacity[b, c:c + m],
                                  timer=self.kernel_timer, fused=fused)
+        return edict(rgb=rgb, depth=depth, opacity=opacity)
+
+    def render_poses(self, opt, poses, ref_poses=None, ref_images=None, ref_feats_list=None):
+        """Full frames of SEVERAL target poses of one source set (the video loop of matchnerf.py:42-71) with as many poses per
+        launch as fit MAX_RAYS_PER_LAUNCH rays: the poses' camera constants travel as a table in HBM (mnerf_rays.pose_table,
+        include/mnerf.h) instead of by value in the kernel arguments.  A 128 x 160 frame is 20 480 rays = 80 decoder tiles, a
+        third of the 256 workgroups the decoder keeps resident; three poses per launch fill them.  Results are bit-identical
+        to ``render`` pose by pose (tests/test_model_gpu.py).
+        -> edict(rgb [n_poses,B,N,3], depth [n_poses,B,N,1], opacity [n_poses,B,N,1]) on the device, or None when a table does
+        not apply (one pose per launch already fills it, H*W not a multiple of 64, more than 5 source views, sample_intvs >
+        64, a non-default decoder form: ``hip.render_takes_pose_table``)."""
+        batch_size, _, _, img_h, img_w = ref_images.shape
+        device = ref_images.device
+        n_pix = img_h * img_w
+        per_launch = MAX_RAYS_PER_LAUNCH // n_pix
+        if per_launch < 2 or len(poses) < 2 or not ref_images.is_cuda or self.fused_render:
+            return None
+        n_samples = int(opt.nerf.sample_intvs)
+        legacy = bool(opt.nerf.legacy_coord)
+        ref_host, images_cl = self._frame_ctx(ref_poses, ref_images)
+        dec = self._decoder(n_samples, device)
+        scenes = [self._scene(b, ref_host, ref_feats_list, images_cl) for b in range(batch_size)]
+        if not all(hip.render_takes_pose_table(sc, dec, n_samples, n_pix) for sc in scenes):
+            return None
+        n_poses = len(poses)
+        hosts = [self._tgt_host(p) for p in poses]
+        rows = np.zeros((batch_size, n_poses, hip.MNERF_POSE_FLOATS), np.float32)
+        for b in range(batch_size):
+            rows[b] = hip.pose_table_rows([camera.target_ray_consts(ex[b], it[b], legacy) + (nf[b, 0], nf[b, 1])
+                                           for ex, it, nf in hosts])
+        table = torch.from_numpy(rows).to(device)  # one small copy per video; stream-ordered before the launches
+        rgb = torch.empty(n_poses, batch_size, n_pix, 3, device=device)
+        depth = torch.empty(n_poses, batch_size, n_pix, 1, device=device)
+        opacity = torch.empty(n_poses, batch_size, n_pix, 1, device=device)
+        # outputs of a launch are [poses of the group] x [pixels]: a contiguous scratch block per launch, then one strided copy
+        # into the frame-major result (the batch dimension sits between pose and pixel there)
+        ws = self._workspace(hip.render_workspace_bytes(per_launch * n_pix, n_samples, dec.cond_stride) // 4, device)
+        contiguous_out = batch_size == 1
+        if not contiguous_out:
+            tmp = [torch.empty(per_launch * n_pix, c, device=device) for c in (3, 1, 1)]
+        for b in range(batch_size):
+            kinv, c2w = rows[b, 0, :9], rows[b, 0, 9:21]
+            for p0 in range(0, n_poses, per_launch):
+                g = min(per_launch, n_poses - p0)
+                rays = hip.make_rays(g * n_pix, n_samples, img_h, img_w, kinv, c2w, rows[b, 0, 21], rows[b, 0, 22],
+                                     ray_begin=p0 * n_pix, legacy=legacy, depth_inverse=(opt.nerf.depth.param == "inverse"),
+                                     pose_table_ptr=table[b].data_ptr(), rays_per_pose=n_pix)
+                if contiguous_out:
+                    outs = (rgb[p0:p0 + g, 0].reshape(-1, 3), depth[p0:p0 + g, 0].reshape(-1, 1),
+                            opacity[p0:p0 + g, 0].reshape(-1, 1))
+                else:
+                    outs = tuple(t[:g * n_pix] for t in tmp)
+                hip.render_chunk(scenes[b], dec, rays, ws, *outs, timer=self.kernel_timer, fused=False)
+                if not contiguous_out:
+                    for dst, src in zip((rgb, depth, opacity), outs):
+                        dst[p0:p0 + g, b] = src.view(g, n_pix, -1)
         return edict(rgb=rgb, depth=depth, opacity=opacity)
 
     def _render_with_grad(self, opt, ref_host, tgt_host, ray_idx, stratified, ref_images, ref_feats_list, images_cl,

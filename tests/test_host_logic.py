@@ -173,6 +173,26 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(hip.View) == 23 * 4
 
 
+def test_pose_table_rows_and_ray_struct_fields():
+    """mnerf_rays.pose_table (ABI 7): row layout [kinv 9 | c2w 12 | near | far | pad] as the header states it; make_rays only sets
+    rays_per_pose together with a table"""
+    header = open(os.path.join(REPO, "include", "mnerf.h")).read()
+    assert int(re.search(r"#define MNERF_POSE_FLOATS (\d+)", header).group(1)) == hip.MNERF_POSE_FLOATS == 24
+    assert int(re.search(r"#define MNERF_ABI_VERSION (\d+)", header).group(1)) == hip.MNERF_ABI_VERSION
+    kinv = np.arange(9, dtype=np.float32).reshape(3, 3)
+    c2w = 100 + np.arange(12, dtype=np.float32).reshape(3, 4)
+    rows = hip.pose_table_rows([(kinv, c2w, 2.0, 6.0), (kinv * 2, c2w * 2, 1.0, 3.0)])
+    assert rows.shape == (2, 24) and rows.dtype == np.float32
+    assert (rows[0, :9] == kinv.reshape(-1)).all() and (rows[0, 9:21] == c2w.reshape(-1)).all()
+    assert tuple(rows[0, 21:]) == (2.0, 6.0, 0.0) and tuple(rows[1, 21:23]) == (1.0, 3.0)
+    r = hip.make_rays(128, 64, 8, 16, kinv, c2w, 2.0, 6.0, rays_per_pose=128)
+    assert r.pose_table is None and r.rays_per_pose == 0
+    r = hip.make_rays(256, 64, 8, 16, kinv, c2w, 2.0, 6.0, ray_begin=128, pose_table_ptr=0x1000, rays_per_pose=128)
+    assert r.pose_table == 0x1000 and r.rays_per_pose == 128 and r.ray_begin == 128
+    lib = hip.load()  # the predicate is host-only: NULL / malformed arguments answer 0 without a GPU
+    assert lib.mnerf_render_takes_pose_table(None, None, 64, 128) == 0
+
+
 def test_decoder_train_tensor_order_matches_the_header_and_the_module():
     """mnerf_decoder_train indexes the decoder's parameters by the MNERF_DT_* enum; the binding's name table must list them
     in that order, name every parameter of the CondNeRF module exactly once, and the knob hook must know its knobs."""

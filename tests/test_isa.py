@@ -32,15 +32,15 @@ def kernels():
 def test_scan_sees_the_kernels(kernels):
     """the disassembly is really the library's: the hot kernels are there with their matrix instructions"""
     names = list(kernels)
-    for want in ("decoder_pp_kernel<64, 2>", "decoder_pp_kernel<64, 4>", "decoder_kernel<4, 64, 2, 0>", "decoder_kernel<4, 64, 2, 1>", "decoder_kernel<8, 256, 2, 0>",
-                 "cost_volume_lean_kernel<8, false>", "cost_volume_backward_kernel", "conv_kernel<4, 2, false>",
+    for want in ("decoder_pp_kernel<64, 2, false>", "decoder_pp_kernel<64, 2, true>", "decoder_pp_kernel<64, 4, false>", "decoder_kernel<4, 64, 2, 0>", "decoder_kernel<4, 64, 2, 1>", "decoder_kernel<8, 256, 2, 0>",
+                 "cost_volume_lean_kernel<8, false, false>", "cost_volume_lean_kernel<8, false, true>", "cost_volume_backward_kernel", "conv_kernel<4, 2, false>",
                  "window_attention_pre_kernel<4>", "encoder_block_kernel<4>", "qkv_images_kernel", "ray_head_kernel",
                  "wa_bwd_dq_kernel", "wa_bwd_dkv_kernel", "eb_ln_bwd_kernel"):
         hit = [n for n in names if want in n]
         assert hit, f"{want} not found in the disassembly"
-    pp = next(v for n, v in kernels.items() if "decoder_pp_kernel<64, 2>" in n)
+    pp = next(v for n, v in kernels.items() if "decoder_pp_kernel<64, 2, false>" in n)
     assert pp["mfma16"] >= 700 and pp["mfma"] > pp["mfma16"]  # 786 split-fp16 products + the f32 tail stages
-    cv = next(v for n, v in kernels.items() if "cost_volume_lean_kernel<8, false>" in n)
+    cv = next(v for n, v in kernels.items() if "cost_volume_lean_kernel<8, false, false>" in n)
     assert cv["mfma"] == 0
 
 
