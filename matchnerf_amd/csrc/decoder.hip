@@ -1617,8 +1617,8 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
 // ring slots 2 (s & 1) (+1), team A reads it in global step 2s+1, team B in step 2s+2; it is requested in two halves from VALU
 // phases (team B the even 1-KiB pieces at the end of its V_{s-1}, step 2s-1: the slot pair's previous tenant, stage s-2, was
 // last read in step 2s-2; team A the odd pieces at the start of its V_s, step 2s), each team waits for its own pieces in
-// step 2s.  (Requests between the matrix instructions were measured: the LDS-DMA path drains ~11 B/clk per CU, a stage's
-// 65 KiB takes 5.7 k cycles, and a wave that issues faster than that stalls inside its MFMA phase.)  Resident for the whole kernel: the tail segment (ray-transformer weights)
+// step 2s.  (Requests between the matrix instructions were measured, rounds 3 and 4: a request stalls its wave ~50 cycles
+// there against ~95 in a vector phase, but the matrix phase is the other long side of a slot: no gain, MNERF_PP_DMA_IN_M.)  Resident for the whole kernel: the tail segment (ray-transformer weights)
 // and the 1-KiB headers (biases, weight scales) of all stages, so that a V phase can also load the next accumulators.
 // The conditioning rows of the next tile are copied to LDS during the tail phases (half of ring slot 1 per team).
 // Same arithmetic in the same order as decoder_kernel<.., 2, 0>: results are bit-identical (tests).
@@ -1685,6 +1685,19 @@ __device__ __host__ constexpr int pp_seg_first(int s) {
   return t[s];
 }
 __device__ __host__ constexpr int pp_seg_off_floats(int s, int i, int fs = 2) { return pp_stream_off_floats(pp_seg_first(s) + i, fs); }
+#ifndef MNERF_PP_DMA_IN_M
+#define MNERF_PP_DMA_IN_M 0  // measured (r4l, same box, 3 runs each): 4 -> 16.45-16.53 ms per frame, 2 -> 16.54-16.76, 0 -> 16.35-16.43
+#endif
+// how many of a wave's requests for stage n are issued inside the matrix phase M_{n-1} (decoder_pp_kernel: pp_m_dma).  Stages
+// whose previous matrix phase is not a plain ksteps_presplit2 call (M_0: FiLM + geometry, M_1 / M_7: the encoding halves with
+// the operand split between them) or has the next tile's first stage in flight (M_11) keep every request in the vector phase.
+__device__ __host__ constexpr int pp_km(int n) {
+  const int enc_stage = MNERF_PP_L5_H_FIRST ? 7 : 6;  // the stage AFTER the encoding half of layer 5 stays in the burst
+  if (n < 3 || n > 11 || n == enc_stage + 1) return 0;
+  // requests k = 0 .. km-1 of a wave are pieces 2 tw + half + 8 k of the stage's first segment: they must exist for tw = 3, half = 1
+  const int fit = pp_p0(n) / 8;  // largest km with 7 + 8 (km - 1) < pp_p0
+  return fit < MNERF_PP_DMA_IN_M ? fit : MNERF_PP_DMA_IN_M;
+}
 __device__ __host__ constexpr int pp_p1(int s) {
 #if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 32, 0, 0, 32, 20, 0};
@@ -1988,6 +2001,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #define PP_NOSYNC() PP_STAMPED((void)0)
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
+#ifdef MNERF_EXP_NO_DMA  // timing experiment (wrong results): what do the weight requests cost in total?
+    return;
+#endif
     unsigned voff = (unsigned)lane0 * 16u;
     asm volatile("" : "+v"(voff));
     for (int i = 0; i < 2; ++i) {
@@ -2050,22 +2066,71 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_SYNC();                                                      \
   } while (0)
 #else
-#define PP_BEGIN_V(stage_)                    \
-  do {                                        \
-    if (team == 0) stage_dma(stage_, 1);      \
+  // MNERF_PP_B_EARLY (round 4, after the issue microbenchmark tools/exp/ubench/mfma_issue.hip): team B asks for its half of
+  // stage s+1 at the START of its V_s instead of at its end.  The ring slots of stage s+1 are free from that point (their last
+  // reader was team B's own M_{s-1}); asked for at the end of the phase, B's burst met team A's burst at the start of A's
+  // V_{s+1} right behind the barrier — 65 KiB requested at once, and both teams stalled longer per request than one team's burst
+  // alone does (~95 cycles).  Measured: 16.43-16.50 against 16.51-16.68 ms per frame (same box, three runs each).  V_0 keeps the late request: its rows sit in that buffer.
+#ifndef MNERF_PP_B_EARLY
+#define MNERF_PP_B_EARLY 1
+#endif
+#ifdef MNERF_EXP_NO_WAIT  // timing experiment (racy): the trunk's waits for the weight requests removed
+#define PP_SEGMENT_WAIT() do {} while (0)
+#else
+#define PP_SEGMENT_WAIT() segment_wait()
+#endif
+  // MNERF_PP_DMA_IN_M = KM (round 4 experiment, default 0): the first KM of a wave's (up to 10) requests for stage n go out INSIDE
+  // the matrix phase M_{n-1}, behind its matrix instructions (pp_m_dma below), the rest in the burst of the vector phase.  A
+  // request stalls the issuing wave ~95 cycles in a vector phase and ~50 among matrix instructions
+  // (tools/exp/ubench/mfma_issue.hip).  MEASURED: no gain (KM = 4: 16.45-16.53, 2: 16.54-16.76, 0: 16.35-16.43 ms per frame) — the
+  // two phases of a slot are equally long, what one side saves the other pays.  Stages whose previous matrix phase has no hook
+  // keep all requests in the burst.
+  auto burst_from = [&](int s, int half, int k0) {
+    if (k0 == 0) {
+      stage_dma(s, half);
+      return;
+    }
+#pragma unroll
+    for (int k = k0; k < 10; ++k) stage_piece(s, half, k);
+  };
+  // requests of matrix phase M_s (n_units units of three matrix instructions): stage s+1; team A spreads its KM over all units,
+  // team B over the first half (its pieces are needed one slot earlier: team A's M_{s+1} starts when this phase ends)
+  // (the per-lane offset of these requests is the matrix phase's own fragment address register: see ksteps_presplit2)
+  // NO control flow here: a branch inside the matrix phase splits it into basic blocks, and the compiler then sinks the tail of
+  // the previous vector phase (48 bias multiplies, the last operand conversions) into them, behind the first matrix
+  // instructions, and spills around the blocks (23 -> 63 spilled registers in the first version).  So: pp_km(n) only counts
+  // requests that exist for every wave of both teams (piece 2 tw + half + 8 k < the first segment's piece count), the teams
+  // differ in a scalar operand (half) instead of a branch, and both front-load their requests into the first half of the units
+  // (team B's must have landed when the phase ends: team A's M_{s+1} starts there).
+  auto stage_piece_m = [&](int s, int k, unsigned lane_addr, unsigned lane_addr_base) {
+    int twl = tw;
+    asm volatile("" : "+s"(twl));
+    const int pce = 2 * twl + (1 - team) + 8 * k;  // team A: the odd pieces, team B: the even ones (as in the bursts)
+    glds16_s(reinterpret_cast<const float*>(reinterpret_cast<const char*>(PP_SEG_SRC(s, 0) + pce * 256) - lane_addr_base), lane_addr,
+             __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(s, 0) + (unsigned)pce * 1024u));
+  };
+  auto pp_m_dma = [&](int s, int n_units, int i, unsigned lane_addr, unsigned lane_addr_base) {
+#pragma unroll
+    for (int j = 0; j < pp_km(s + 1); ++j)
+      if ((j * (n_units / 2)) / pp_km(s + 1) == i) stage_piece_m(s + 1, j, lane_addr, lane_addr_base);
+  };
+#define PP_BEGIN_V(stage_)                                                          \
+  do {                                                                              \
+    if (team == 0) burst_from(stage_, 1, pp_km(stage_));                            \
+    else if (MNERF_PP_B_EARLY && (stage_) + 1 < PP_STAGES) burst_from((stage_) + 1, 0, pp_km((stage_) + 1)); \
   } while (0)
   (void)dma_some;
 #define PP_DMA(sa_, sb_, n_) do {} while (0)
 #define PP_END_V(sa_, next_stage_)                                  \
   do {                                                              \
-    if (team == 1) { if ((next_stage_) >= 0) stage_dma(next_stage_, 0); } \
-    else segment_wait();                                            \
+    if (team == 1) { if ((next_stage_) >= 0 && (!MNERF_PP_B_EARLY || (sa_) < 0)) stage_dma(next_stage_, 0); } \
+    else PP_SEGMENT_WAIT();                                         \
     PP_SYNC();                                                      \
   } while (0)
 #endif
 #define PP_END_M()                   \
   do {                               \
-    if (team == 1) segment_wait();   \
+    if (team == 1) PP_SEGMENT_WAIT();   \
     PP_SYNC();                       \
   } while (0)
   // M_s: stage s's matrix instructions (+ team A: the requests for stage NXT_)
@@ -2087,21 +2152,31 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #define PP_PRIO_UP() do {} while (0)
 #define PP_PRIO_DOWN() do {} while (0)
 #endif
-#if MNERF_PP_PAIRS
+#ifdef MNERF_EXP_NO_MFMA  // timing experiment (wrong results): the trunk's matrix phases empty -> what the vector side alone takes
+#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) do {} while (0)
+#elif MNERF_PP_PAIRS
 #define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
 #else
 #define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
 #endif
+#if defined(MNERF_EXP_NO_MFMA) || MNERF_PP_PAIRS
+#define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
+  PP_MFMA_(NMB_, NS0_, NS1_, acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), hs_)
+#else
+#define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                      \
+  ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_,             \
+                                     [&](int i_, unsigned la_, unsigned lb_) { pp_m_dma(s_, ((NS0_) + (NS1_)) * (NMB_), i_, la_, lb_); })
+#endif
 #define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                   \
   do {                                                                                                         \
     PP_PRIO_UP();                                                                                              \
-    PP_MFMA_(NMB_, NS0_, NS1_, acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), hs_);               \
+    PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_);                                                \
     PP_PRIO_DOWN();                                                                                            \
   } while (0)
 #define PP_MFMA1(NS0_, acc_, s_, hdr_bytes_, hs_)                                                              \
   do {                                                                                                         \
     PP_PRIO_UP();                                                                                              \
-    ksteps_presplit2<1, NS0_, 0>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_);       \
+    PP_MFMA_HOOKED(1, NS0_, 0, acc_, s_, hdr_bytes_, hs_);                                                      \
     PP_PRIO_DOWN();                                                                                            \
   } while (0)
 

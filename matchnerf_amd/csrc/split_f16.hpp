@@ -317,9 +317,17 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
   }
 }
 #else
-template <int NMB, int NS0, int NS1>
+// `hook(i, lane_addr, lane_addr_base)` runs behind the three matrix instructions of unit i (i is a constant after unrolling): the
+// place where a wave can issue something else — a weight request — at the lowest cost (tools/exp/ubench/mfma_issue.hip: ~50
+// cycles per LDS-DMA request among matrix instructions against ~95 in a vector phase).  lane_addr = lane_addr_base + 16 lane is
+// the vector register this function reads its fragments through: a request can use it as its per-lane offset (with the
+// wave-uniform base lowered by lane_addr_base) instead of claiming a register of its own in the fullest phase of the kernel.
+struct KstepsNoHook {
+  __device__ __forceinline__ void operator()(int, unsigned, unsigned) const {}
+};
+template <int NMB, int NS0, int NS1, class Hook = KstepsNoHook>
 __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
-                                                 const PartsH* b) {
+                                                 const PartsH* b, Hook hook = Hook()) {
   constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB, DEP = MNERF_PP_DEPTH, NB = DEP + 1;
   lds_u32x4_cptr a0 = (lds_u32x4_cptr)(size_t)base0_lds + lane;
   lds_u32x4_cptr a1 = (lds_u32x4_cptr)(size_t)base1_lds + lane;
@@ -349,6 +357,8 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
     acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
     acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
     acc[m] = mfma16h(ah, b[u].hi, acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(i, (unsigned)(size_t)a0, base0_lds);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
