@@ -466,6 +466,14 @@ int mnerf_qkv_backward(const float* w_q, const float* w_k, const float* w_v, con
                        const float* g_q, const float* g_k, const float* g_v, float* g_xq, float* g_xkv, float* gw_q,
                        float* gw_k, float* gw_v, int32_t n_tokens, void* stream);
 
+/* Test hook — the strided GEMM under the backward entry points above:  C[I,J] (mode 0: =, 1: +=, 2: atomic +=)
+ * sum_k A(i,k) B(k,j) (+ bias[j]),  A(i,k) = a[i sa_i + k sa_k],  B(k,j) = b[k sb_k + j sb_j],  C row stride sc_i.
+ * math 1 = split-bf16 on the 16-bit matrix instruction (six term products per product, fp32-grade; what the library uses
+ * for products with I, J >= 128 unless MNERF_GEMM_MATH=f32), 0 = the exact-f32 matrix instruction. */
+int mnerf_debug_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c,
+                     int64_t sc_i, const float* bias, int32_t I, int32_t J, int32_t K, int32_t mode, int32_t math,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,15 @@ extern "C" int mnerf_qkv_backward(const float* w_q, const float* w_k, const floa
   linear_bwd_weight(st, g_v, EB_C, x_kv, EB_C, gw_v, EB_C, N, EB_C, EB_C);
   return mnerf_check_launch(who);
 }
+
+// Test hook: the strided GEMM the backward kernels are built on (gemm_f32.hpp), so that its arithmetic can be pinned on its own.
+extern "C" int mnerf_debug_gemm(const float* a, int64_t sa_i, int64_t sa_k, const float* b, int64_t sb_k, int64_t sb_j, float* c,
+                                int64_t sc_i, const float* bias, int32_t I, int32_t J, int32_t K, int32_t mode, int32_t math,
+                                void* stream) {
+  const char* who = "mnerf_debug_gemm";
+  MNERF_REQUIRE(a && b && c, MNERF_E_NULL, "%s: NULL operand", who);
+  MNERF_REQUIRE(I >= 1 && J >= 1 && K >= 1, MNERF_E_RANGE, "%s: I=%d J=%d K=%d", who, I, J, K);
+  MNERF_REQUIRE(mode >= 0 && mode <= 2 && (math == 0 || math == 1), MNERF_E_RANGE, "%s: mode=%d math=%d", who, mode, math);
+  gemm_with((hipStream_t)stream, a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode, math);
+  return mnerf_check_launch(who);
+}

@@ -1,6 +1,9 @@
 // Exact-fp32 MFMA GEMM with strided operands and the Linear-layer wrappers built on it (shared by decoder_backward.hip and
 // encoder_backward.hip; kernels are templates / static so that two translation units may include this header).
 #pragma once
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -149,13 +152,190 @@ __global__ __launch_bounds__(256) void gemm_f32_tile128_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ the same product on the 16-bit matrix pipe: split-bf16
+// Every fp32 operand element is three bf16 terms (hi + mid + lo = the fp32 value exactly: 3 x 8 significand bits), a product is
+// accumulated in fp32 from the six term products that are not below 2^-24 of it (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi;
+// the scheme of the decoder's "bf16x6" matrix path, decoder.hip) on v_mfma_f32_32x32x16_bf16: 16 K-elements per 32-cycle
+// instruction against 2 for the exact-f32 one, i.e. 8/6 x 2 = 2.7 x its rate, with fp32's exponent range (no scaling, unlike the
+// split-fp16 form) and fp32-grade results (tests/test_gemm_gpu.py: error against float64 at the level of an fp32 FMA chain).
+// The operands are split ONCE per tile load — each element then serves 128 rows / columns of the tile — and wait in LDS as
+// [term][k half][row] 16-byte fragments (lane (n, half) of a 16-bit matrix instruction supplies k = 8 half .. 8 half + 7 of row n).
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gemm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gemm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned gemm_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  const gemm_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gemm_bf16x2));
+}
+__device__ __forceinline__ void gemm_split8(const float (&v)[8], gemm_u32x4& H, gemm_u32x4& M, gemm_u32x4& L) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h = gemm_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = gemm_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    H[i] = h;
+    M[i] = m;
+    L[i] = gemm_pk_bf16(sa, sb);
+  }
+}
+
+// TI x TJ tile per workgroup (128 or 64 each), the four waves as 2 x 2, a wave owns (TI/2) x (TJ/2) = BI x BJ blocks of 32 x 32:
+// one 16-wide K chunk is 6 BI BJ matrix instructions for 3 (BI + BJ) ds_read_b128 (128 x 128: 24 for 12).  Fetch items: (row,
+// k half) of A (2 TI of them) and of B (2 TJ), dealt to the 256 threads in order; an item is 8 consecutive k of one row.
+// a_vec / b_vec (host): the K-contiguous operand may be fetched as two float4 (row stride and base multiples of 4 floats).
+// The 64-tiles are for products with few 128-tiles (N x 128 x 128: 240 of them = one 4-wave workgroup per CU, which cannot hide
+// the latency of its own operand fetches; 960 64-tiles can: 25 -> 14 us).
+template <bool A_KCONT, bool B_KCONT, int TI, int TJ>
+__global__ __launch_bounds__(256) void gemm_b6_kernel(GemmArgs g, int a_vec, int b_vec) {
+  constexpr int BI = TI / 64, BJ = TJ / 64, ITEMS = 2 * TI + 2 * TJ, NIT = ITEMS / 256;
+  static_assert(ITEMS % 256 == 0, "fetch items are dealt in rounds of 256");
+  __shared__ gemm_u32x4 S[2][3][2][TI + TJ];  // [buffer][term][k half][A rows | B rows]: 48 KiB at 128 x 128
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  const int m = l & 31, kk2 = l >> 5;
+  const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
+  const int chunks = (g.K + 15) / 16, per = (chunks + gridDim.z - 1) / gridDim.z;
+  const int kb = blockIdx.z * per * 16;
+  const int ke = min(g.K, kb + per * 16);
+  float r[NIT][8];
+  auto fetch1 = [&](float (&v)[8], const float* base, long long s_row, long long s_k, int row, int n_rows, int k, bool kcont, int vec) {
+    const float* p = base + (long long)row * s_row + (long long)k * s_k;
+    if (row < n_rows && k + 8 <= ke) {
+      if (kcont && vec) {
+        const float4 u = *reinterpret_cast<const float4*>(p), x = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w, v[4] = x.x, v[5] = x.y, v[6] = x.z, v[7] = x.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[q * s_k];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (row < n_rows && k + q < ke) ? p[q * s_k] : 0.0f;
+    }
+  };
+  // item it: A for it < 2 TI (row it % TI, k half it / TI), B after that; slot = its row in S
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+      const int it = t + 256 * n;
+      if (it < 2 * TI)
+        fetch1(r[n], g.a, g.sa_i, g.sa_k, i0 + it % TI, g.I, k0 + 8 * (it / TI), A_KCONT, a_vec);
+      else
+        fetch1(r[n], g.b, g.sb_j, g.sb_k, j0 + (it - 2 * TI) % TJ, g.J, k0 + 8 * ((it - 2 * TI) / TJ), B_KCONT, b_vec);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+      const int it = t + 256 * n;
+      const int kh = it < 2 * TI ? it / TI : (it - 2 * TI) / TJ;
+      const int slot = it < 2 * TI ? it % TI : TI + (it - 2 * TI) % TJ;
+      gemm_u32x4 H, M, L;
+      gemm_split8(r[n], H, M, L);
+      S[buf][0][kh][slot] = H, S[buf][1][kh][slot] = M, S[buf][2][kh][slot] = L;
+    }
+  };
+  f32x16 acc[BI][BJ];
+#pragma unroll
+  for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < BJ; ++bj) acc[bi][bj] = (f32x16)(0.0f);
+  if (kb < ke) {
+    fetch(kb);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 16, buf ^= 1) {
+    const bool more = k0 + 16 < ke;
+    if (more) fetch(k0 + 16);  // in flight during the matrix instructions below
+    gemm_bf16x8 a[BI][3], b[BJ][3];
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+#pragma unroll
+      for (int q = 0; q < BI; ++q) a[q][term] = __builtin_bit_cast(gemm_bf16x8, S[buf][term][kk2][wi * (TI / 2) + q * 32 + m]);
+#pragma unroll
+      for (int q = 0; q < BJ; ++q) b[q][term] = __builtin_bit_cast(gemm_bf16x8, S[buf][term][kk2][TI + wj * (TJ / 2) + q * 32 + m]);
+    }
+    // smallest terms first; the accumulators take turns, so (with more than one) no instruction has its predecessor's accumulator
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+      for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < BJ; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[bi][TA[p]], b[bj][TB[p]], acc[bi][bj], 0, 0, 0);
+    if (more) stash(buf ^ 1);  // (the other buffer was last read before the previous barrier)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int bj = 0; bj < BJ; ++bj) {
+    const int j = j0 + wj * (TJ / 2) + bj * 32 + m;
+    if (j >= g.J) continue;
+    const float bias_j = (g.bias && blockIdx.z == 0) ? g.bias[j] : 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int i = i0 + wi * (TI / 2) + bi * 32 + 8 * (rr >> 2) + kk2 * 4 + (rr & 3);
+        if (i >= g.I) continue;
+        float* p = g.c + (long long)i * g.sc_i + j;
+        const float v = acc[bi][bj][rr] + bias_j;
+        if (g.mode == 0) *p = v;
+        else if (g.mode == 1) *p += v;
+        else atomicAdd(p, v);
+      }
+  }
+}
+
 #ifndef MNERF_GEMM_TILE128
 #define MNERF_GEMM_TILE128 1  // 0: every product through the 64 x 64 kernel (round 3)
 #endif
-static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k, const float* b, long long sb_k, long long sb_j,
-                 float* c, long long sc_i, const float* bias, int I, int J, int K, int mode) {
+// MNERF_GEMM_MATH (environment, read once): "bf16x6" (default) = split-bf16 on the 16-bit matrix pipe for 128-tile products,
+// "f32" = the exact-f32 matrix instruction everywhere
+static int gemm_math_b6() {
+  static const int v = [] {
+    const char* e = getenv("MNERF_GEMM_MATH");
+    return (e && !strcmp(e, "f32")) ? 0 : 1;
+  }();
+  return v;
+}
+static void gemm_with(hipStream_t st, const float* a, long long sa_i, long long sa_k, const float* b, long long sb_k, long long sb_j,
+                      float* c, long long sc_i, const float* bias, int I, int J, int K, int mode, int math_b6) {
   GemmArgs g{a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode};
   const bool ak = sa_k == 1, bk = sb_k == 1;
+  if (math_b6 && I >= 128 && J >= 128) {
+    // split-bf16: 128 x 128 tiles where they fill the chip twice, 64 x 64 ones below that; a reduction over the rows (mode 2)
+    // is split into parts of at least 128 until ~1 000 workgroups exist
+    const long long t128 = (long long)((I + 127) / 128) * ((J + 127) / 128);
+    const int T = t128 >= 512 ? 128 : 64;
+    const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
+    int split = 1;
+    if (mode == 2) {
+      split = 1024 / (ti * tj);
+      const int max_split = (K + 127) / 128;
+      if (split > max_split) split = max_split;
+      if (split < 1) split = 1;
+    }
+    const dim3 grid(ti, tj, split);
+    const int a_vec = ak && sa_i % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
+    const int b_vec = bk && sb_j % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
+#define GEMM_B6_LAUNCH(AK_, BK_)                                                                                              \
+  do {                                                                                                                        \
+    if (T == 128) hipLaunchKernelGGL((gemm_b6_kernel<AK_, BK_, 128, 128>), grid, dim3(256), 0, st, g, a_vec, b_vec);           \
+    else hipLaunchKernelGGL((gemm_b6_kernel<AK_, BK_, 64, 64>), grid, dim3(256), 0, st, g, a_vec, b_vec);                       \
+  } while (0)
+    if (ak && bk) GEMM_B6_LAUNCH(true, true);
+    else if (ak) GEMM_B6_LAUNCH(true, false);
+    else if (bk) GEMM_B6_LAUNCH(false, true);
+    else GEMM_B6_LAUNCH(false, false);
+#undef GEMM_B6_LAUNCH
+    return;
+  }
   if (MNERF_GEMM_TILE128 && I >= 128 && J >= 128) {  // both tile dimensions at least half used on average
     const int ti = (I + 127) / 128, tj = (J + 127) / 128;
     int split = 1;
@@ -185,6 +365,10 @@ static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k,
   else if (ak) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
   else if (bk) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+}
+static void gemm(hipStream_t st, const float* a, long long sa_i, long long sa_k, const float* b, long long sb_k, long long sb_j,
+                 float* c, long long sc_i, const float* bias, int I, int J, int K, int mode) {
+  gemm_with(st, a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode, gemm_math_b6());
 }
 // Y[N,M] = X[N,K] W[M,K]^T + bias          (torch Linear; ldx / ldw / ldy = row strides)
 static void linear_fwd(hipStream_t st, const float* x, long long ldx, const float* w, long long ldw, const float* bias, float* y,

@@ -29,7 +29,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
-           "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward")
+           "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm")
 
 
 class MnerfError(RuntimeError):
@@ -758,6 +758,29 @@ def qkv_backward(w_q, w_k, w_v, x_q, x_kv, g_q, g_k, g_v, gw_q=None, gw_k=None, 
         check(lib.mnerf_qkv_backward(*[_ptr(t) for t in ts], _ptr(g_xq), _ptr(g_xkv), _ptr(gw_q), _ptr(gw_k), _ptr(gw_v), n, st),
               "mnerf_qkv_backward")
     return g_xq, g_xkv
+
+
+def debug_gemm(a, b, bias=None, out=None, mode=0, math="bf16x6", stream=None):
+    """Test hook (mnerf_debug_gemm): C (mode 0: =, 1: +=, 2: atomic +=) a @ b (+ bias) for 2-D fp32 tensors of ANY strides (views and
+    transposes go through as they are); ``math``: "bf16x6" (the library's default for 128-tile products) or "f32"."""
+    import torch
+    lib = load()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0] or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise MnerfError(f"debug_gemm: {tuple(a.shape)} @ {tuple(b.shape)}")
+    I, K = a.shape
+    J = b.shape[1]
+    if out is None:
+        out = torch.zeros(I, J, device=a.device)
+    if out.stride(1) != 1:
+        raise MnerfError("debug_gemm: out must have unit column stride")
+    fn = lib.mnerf_debug_gemm
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    with _on(a.device, stream) as st:
+        check(fn(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1), out.data_ptr(), out.stride(0),
+                 _ptr(bias), I, J, K, int(mode), {"f32": 0, "bf16x6": 1}[math], st), "mnerf_debug_gemm")
+    return out
 
 
 def instance_norm(x, residual=None, relu_inner=False, relu_outer=False, eps=1e-5, out=None, out_absmax=None, stream=None):
