@@ -4,8 +4,9 @@ ground-truth depth != 0) or, without a mask, over the 80 % centre crop; SSIM as 
 not part of this image: 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03 and, for FLOAT images with no
 `data_range` given, data_range = 2 (that version takes the dtype's nominal range [-1, 1]; the reference passes none).
 LPIPS needs the `lpips` package and its pretrained VGG weights, neither available offline: `EvalTools` takes it as an optional
-callable.  PARITY: PSNR is checked against the reference's formula; the SSIM restatement is checked against a direct per-window
-evaluation of the published definition (tests/test_datasets.py), not against scikit-image."""
+callable.  PARITY: PSNR is checked against the reference's formula; the SSIM restatement against a direct per-window evaluation of the
+published definition and against hand-derived closed-form vectors (tests/golden/ssim_hand_derived.json, generator
+tools/gen_ssim_golden.py; tests/test_datasets.py) — not against scikit-image itself, which this image does not have."""
 from collections import OrderedDict
 
 import numpy as np

@@ -143,6 +143,28 @@ def test_ssim_matches_direct_definition():
         metrics.ssim(x[:5], y[:5])
 
 
+def test_ssim_matches_the_hand_derived_golden_vectors():
+    """tests/golden/ssim_hand_derived.json (tools/gen_ssim_golden.py): images whose 7x7 window statistics are known in closed form —
+    constant images, opposite stripes, stripes at half contrast — with the SSIM value derived on paper and evaluated in exact
+    rationals.  Independent of any filter implementation, this one's and scikit-image's alike."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ssim_hand_derived.json")))
+    assert len(g["cases"]) == 3
+    for c in g["cases"]:
+        h, w, ch = c["shape"]
+        s = np.where(np.arange(w) % 2 == 0, 1.0, -1.0)[None, :, None]
+        if c["kind"] == "constant":
+            x, y = np.full((h, w, ch), c["a"]), np.full((h, w, ch), c["b"])
+        elif c["kind"] == "stripes":
+            x, y = np.broadcast_to(c["m"] + c["amp"] * s, (h, w, ch)), np.broadcast_to(c["m"] - c["amp"] * s, (h, w, ch))
+        else:
+            x, y = np.broadcast_to(c["m"] + c["amp"] * s, (h, w, ch)), np.broadcast_to(c["m"] + 0.5 * c["amp"] * s, (h, w, ch))
+        assert metrics.ssim(np.array(x), np.array(y)) == pytest.approx(c["ssim"], abs=1e-12), c["name"]
+        assert metrics.ssim(np.array(x, np.float32), np.array(y, np.float32)) == pytest.approx(c["ssim"], abs=5e-6), c["name"]
+        assert c["data_range"] == 2.0  # what a float image gets when the caller passes none (misc/metrics.py:43-45 passes none)
+
+
 def test_eval_tools_mask_and_crop():
     rng = np.random.default_rng(4)
     gt = rng.random((40, 50, 3)).astype(np.float32)
