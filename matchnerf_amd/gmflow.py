@@ -279,6 +279,8 @@ class TransformerLayer(nn.Module):
             self._qkv = (key, torch.from_numpy(ws).to(device), ews)
         return self._qkv[1:]
 
+    _warned_eval_grad = False
+
     def forward(self, source, target, h, w, splits, shifted, kv_swap=False):
         """``kv_swap`` (inference only): ``target`` is given un-swapped and read with its batch halves exchanged"""
         # ONE decision per layer: if anything this layer touches needs a gradient, the whole layer takes the autograd
@@ -286,6 +288,11 @@ class TransformerLayer(nn.Module):
         # trainable parameters without a gradient and without an error)
         needs_grad = torch.is_grad_enabled() and (source.requires_grad or target.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
+        if needs_grad and not self.training and not TransformerLayer._warned_eval_grad:
+            TransformerLayer._warned_eval_grad = True
+            import warnings
+            warnings.warn("GMFlow transformer layer in eval() mode with autograd enabled: it records an autograd graph (saved "
+                          "activations, the training form of the layer). Run inference under torch.no_grad().")
         if source.is_cuda and not needs_grad:
             ws, ews = self._packed_qkv(source.device)
             if hip.wa_math() == hip.WA_PRESPLIT_F16:

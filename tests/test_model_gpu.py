@@ -112,13 +112,17 @@ def test_random_ray_mode_matches_oracle():
     assert linf(out.rgb[0], ref[0]) < 1e-4 and linf(out.opacity[0], ref[2]) < 1e-4
 
 
-def test_train_mode_gradients_match_oracle_autograd():
+def test_train_mode_gradients_match_oracle_autograd(monkeypatch):
     """mode='train' under autograd: forward values from the HIP kernels; the ray chunk's backward is HIP end to end
     (compositing, conditional MLP + ray transformer on the forward's own sample coordinates, cost volume:
     matchnerf_amd/autograd.py) — compared with autograd through the CPU oracle on all nine probe parameters."""
     g, cfg, sd, batch_cpu = golden_case("c1_default")
     opt, model = build_model(g["meta"])
     model.train()
+    # MIOpen picks the convolutions' backward solvers by TIMING them when benchmark mode is on: that choice differed from box to
+    # box (see the gate below).  Heuristic (immediate-mode) choice + deterministic solvers: the same kernels everywhere.
+    monkeypatch.setattr(torch.backends.cudnn, "benchmark", False)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
     opt.nerf.rand_rays_train = 96
     opt.nerf.sample_stratified = False
     batch = to_batch(g)
@@ -154,11 +158,12 @@ def test_train_mode_gradients_match_oracle_autograd():
             worst_enc = max(worst_enc, rel)
         checked += 1
     # Decoder parameters: HIP forward + HIP K5 / K1+K2 backward + the re-evaluated MLP on the forward's own (bit-exact)
-    # sample coordinates: 1e-3 (observed <= 2e-4).  Encoder parameters: their backward runs in the ROCm libraries (MIOpen
-    # convolutions, rocBLAS), whose fp32 solver choice differs from box to box — the SAME code measured 7e-5 ... 1.2e-4 on
-    # most boxes, 1.3e-3 with Winograd backward-data solvers and 3.7e-3 with one weight-gradient solver of the 7x7 stem:
-    # gate 5e-3 for those, the figures are printed.
-    assert checked == 9 and worst < 1e-3 and worst_enc < 5e-3, (worst, worst_enc)
+    # sample coordinates: 1e-3 (observed <= 2e-4).  Encoder parameters: the transformer layers' backward is HIP since round 4
+    # (attention backward, split-bf16 GEMMs), but every encoder gradient still passes through the up-sampler's and the backbone's
+    # convolutions on MIOpen.  With benchmark mode ON the SAME code measured 7e-5 ... 1.2e-4 on most boxes, 1.3e-3 with Winograd
+    # backward-data solvers and 3.7e-3 with one weight-gradient solver of the 7x7 stem (round 3's 5e-3 gate); with the solver
+    # choice pinned above the gate is 2e-3 and the figures are printed.
+    assert checked == 9 and worst < 1e-3 and worst_enc < 2e-3, (worst, worst_enc)
 
 
 def test_stratified_depths_match_oracle():
