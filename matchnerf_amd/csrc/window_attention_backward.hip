@@ -19,10 +19,15 @@
 //   wa_bwd_dkv_kernel  one workgroup per (window, 64-key tile): loops over the query tiles with S = Q K^T (lane = key,
 //                      registers = queries), so that P and dS in their accumulators are the B operands of
 //                      dV^T = dO^T P and dK^T = Q^T dS.
-// Every product is exact fp32 on v_mfma_f32_32x32x2_f32 (the gradients feed an optimizer: no reduced-precision shortcut);
-// tiles are staged in LDS channel-major ([channel][row], row stride 65 floats: conflict-free for both operand roles).
+// Two forms of the two kernels (MNERF_WA_BWD_MATH): the split-bf16 one further down (default: three bf16 terms per operand, six
+// term products, fp32-grade on the 16-bit matrix instruction) and this one, where every product is exact fp32 on
+// v_mfma_f32_32x32x2_f32; its tiles are staged in LDS channel-major ([channel][row], row stride 65 floats: conflict-free for both
+// operand roles).
 // Roll, window split / merge and the wrap-region mask are index arithmetic (wa_common.hpp: win_token), as in the forward.
 // No atomics: every output row is written by exactly one workgroup; results are deterministic.
+#include <stdlib.h>
+#include <string.h>
+
 #include "wa_common.hpp"
 
 #define WB_T 64             // rows (queries or keys) per tile
@@ -388,6 +393,414 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_kernel(WaBwdArgs A) {
   }
 }
 
+
+// ================================================================================================================ split-bf16 form
+// The same two kernels with every product on the 16-bit matrix instruction: each fp32 operand element as three bf16 terms (exact:
+// 3 x 8 significand bits), a product from the six term products that are not below 2^-24 of it, fp32 accumulation — the scheme of
+// gemm_b6_kernel (gemm_f32.hpp) and of the decoder's "bf16x6" path: fp32-grade gradients (the tests judge both forms against
+// float64 with one gate) at 2.7 x the matrix rate of v_mfma_f32_32x32x2_f32, with fp32's exponent range (no gains to manage).
+//
+// Geometry.  A workgroup owns 128 STATIONARY rows (dK/dV kernel: keys, dQ kernel: queries), one 32-row block per wave, and loops
+// over 32-row STREAMING tiles of the other side.  Lane (n, half) of a 16-bit matrix instruction supplies 8 consecutive k of row /
+// column n, so an operand must be stored k-contiguous, and the backward needs the streaming tiles in BOTH orientations:
+//   role 1  [row][channel]  k = channels:  S = Q K^T, dP = dO V^T           -> R1: [term][32 rows][128 ch] bf16, row stride 272 B
+//   role 2  [channel][row]  k = rows:      dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T
+//                                                                           -> R2: [term][128 ch][32 rows] bf16, row stride 80 B
+// (strides chosen so that the 16 lanes of a ds_read_b128 group fall into distinct banks).  Role 2 stores the rows PERMUTED: the B
+// operand of those products is P / dS straight out of its accumulator registers — register r of lane (n, half) is row
+// f(r, half) = (r & 3) + 8 (r >> 2) + 4 half — so K16-step s of lane half h pairs slot j with row 16 s + 8 (j >> 2) + 4 h + (j & 3),
+// and position 16 s + 8 h + j of an R2 line holds exactly that row: one ds_read_b128 per fragment.
+// The stationary rows never touch LDS: each wave keeps the 8 K16-steps x 3 terms of its own 32 rows (x 2 tensors) in 192 registers
+// (one wave per SIMD, 512 registers), read from global memory once.  A streaming tile is fetched into registers one iteration ahead
+// (thread (row, 8-channel chunk): role 1's own shape), split and stored as R1, staged as fp32 [row][132] for the transposition, and
+// re-read by thread (channel, 16 rows) in permuted order to be split and stored as R2.
+// No cross-wave reduction, no atomics: a wave owns its 32 rows of the result; results are deterministic.
+#define WB6_R 128                // stationary rows per workgroup
+#define WB6_T 32                 // rows of a streaming tile
+#define WB6_R1_ROW 272           // bytes of an R1 row (128 bf16 + 16 pad)
+#define WB6_R1_TERM (WB6_T * WB6_R1_ROW)
+#define WB6_R1_BYTES (3 * WB6_R1_TERM)
+#define WB6_R2_ROW 80            // bytes of an R2 line (32 bf16 + 16 pad)
+#define WB6_R2_TERM (WA_C * WB6_R2_ROW)
+#define WB6_R2_BYTES (3 * WB6_R2_TERM)
+#define WB6_ST_LD 132            // floats per row of the fp32 staging tile
+#define WB6_ST_BYTES (WB6_T * WB6_ST_LD * 4)
+
+typedef __bf16 wb6_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wb6_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wb6_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned wb6_pk(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
+  const wb6_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wb6_bf16x2));
+}
+struct Wb6Frag {
+  u32x4 t[3];  // hi | mid | lo: 8 bf16 each
+};
+__device__ __forceinline__ Wb6Frag wb6_split8(const float (&v)[8]) {
+  Wb6Frag f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h = wb6_pk(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned m = wb6_pk(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    f.t[0][i] = h;
+    f.t[1][i] = m;
+    f.t[2][i] = wb6_pk(sa, sb);
+  }
+  return f;
+}
+// acc += A . B from the six term products, smallest first
+__device__ __forceinline__ f32x16 wb6_mfma6(const Wb6Frag& a, const Wb6Frag& b, f32x16 acc) {
+#define WB6_P(TA_, TB_) \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wb6_bf16x8, a.t[TA_]), __builtin_bit_cast(wb6_bf16x8, b.t[TB_]), acc, 0, 0, 0)
+  WB6_P(2, 0);
+  WB6_P(0, 2);
+  WB6_P(1, 1);
+  WB6_P(1, 0);
+  WB6_P(0, 1);
+  WB6_P(0, 0);
+#undef WB6_P
+  return acc;
+}
+__device__ __forceinline__ Wb6Frag wb6_lds_frag(const unsigned char* base, int term_stride) {
+  Wb6Frag f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) f.t[t] = *reinterpret_cast<const u32x4*>(base + t * term_stride);
+  return f;
+}
+
+// the 8 K16-steps of one stationary row (window-local index li; zero beyond the window): lane (n, half) holds channels 16 u + 8 half ..
+__device__ __forceinline__ void wb6_stationary(Wb6Frag (&f)[8], const float* __restrict__ src_seq, int tok, int half) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tok >= 0) {
+      const float4 a = reinterpret_cast<const float4*>(src_seq + (size_t)tok * WA_C + 16 * u + 8 * half)[0];
+      const float4 b = reinterpret_cast<const float4*>(src_seq + (size_t)tok * WA_C + 16 * u + 8 * half)[1];
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    }
+    f[u] = wb6_split8(v);
+  }
+}
+
+// streaming tile, fetch role: thread t -> row t >> 3, chunks (t & 7) and (t & 7) + 8 of 8 channels
+struct Wb6TileRegs {
+  float4 v[4];
+};
+__device__ __forceinline__ void wb6_fetch(Wb6TileRegs& r, const float* __restrict__ src_seq, const WinGeom& G, int wy, int wx, int i0,
+                                          int tid) {
+  const int li = i0 + (tid >> 3), c = tid & 7;
+  r.v[0] = r.v[1] = r.v[2] = r.v[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (li < G.Lw) {
+    int region;
+    const int tok = win_token(G, wy, wx, li, region);
+    const float4* p = reinterpret_cast<const float4*>(src_seq + (size_t)tok * WA_C);
+    r.v[0] = p[2 * c], r.v[1] = p[2 * c + 1], r.v[2] = p[2 * (c + 8)], r.v[3] = p[2 * (c + 8) + 1];
+  }
+}
+// registers -> R1 (split) and, if st, the fp32 staging tile
+__device__ __forceinline__ void wb6_store_r1(unsigned char* r1, float* st, const Wb6TileRegs& r, int tid) {
+  const int row = tid >> 3, c = tid & 7;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float4 a = r.v[2 * q], b = r.v[2 * q + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const Wb6Frag f = wb6_split8(v);
+    const int ch0 = 8 * (c + 8 * q);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(r1 + t * WB6_R1_TERM + row * WB6_R1_ROW + ch0 * 2) = f.t[t];
+    if (st) {
+      *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0) = a;
+      *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0 + 4) = b;
+    }
+  }
+}
+// registers -> the fp32 staging tile only (a tensor that is needed in role 2 alone)
+__device__ __forceinline__ void wb6_store_staging(float* st, const Wb6TileRegs& r, int tid) {
+  const int row = tid >> 3, c = tid & 7;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ch0 = 8 * (c + 8 * q);
+    *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0) = r.v[2 * q];
+    *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0 + 4) = r.v[2 * q + 1];
+  }
+}
+// staging tile -> R2: thread t -> channel t & 127, K16-step t >> 7; both lane halves' fragments of that step
+__device__ __forceinline__ void wb6_build_r2(unsigned char* r2, const float* st, int tid) {
+  const int ch = tid & 127, s = tid >> 7;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = st[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * WB6_ST_LD + ch];
+    const Wb6Frag f = wb6_split8(v);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(r2 + t * WB6_R2_TERM + ch * WB6_R2_ROW + (16 * s + 8 * h) * 2) = f.t[t];
+  }
+}
+// S-type product: acc[rows = the tile's 32 rows][cols = this wave's stationary rows] over the 128 channels.  The fragments of
+// step u + 1 are requested before the six matrix instructions of step u (one wave per SIMD: nothing else hides an LDS round trip).
+__device__ __forceinline__ f32x16 wb6_tile_product(const unsigned char* r1, const Wb6Frag (&stat)[8], int n, int half) {
+  f32x16 acc = (f32x16)(0.0f);
+  const unsigned char* base = r1 + n * WB6_R1_ROW + 16 * half;
+  Wb6Frag cur = wb6_lds_frag(base, WB6_R1_TERM);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    Wb6Frag nxt = cur;
+    if (u + 1 < 8) nxt = wb6_lds_frag(base + 32 * (u + 1), WB6_R1_TERM);
+    __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the reads to their use: read, wait, multiply, read, wait ...)
+    asm volatile("" : "+v"(cur.t[0]), "+v"(cur.t[1]), "+v"(cur.t[2]));
+    acc = wb6_mfma6(cur, stat[u], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+  return acc;
+}
+// chain product: out^T[channel][col] += sum over the tile's 32 rows X^T[channel][row] s[row][col], s = accumulator registers
+__device__ __forceinline__ void wb6_chain_product(f32x16 (&out)[4], const unsigned char* r2, const f32x16& s, int n, int half) {
+  const unsigned char* base = r2 + n * WB6_R2_ROW + 16 * half;
+  Wb6Frag cur = wb6_lds_frag(base, WB6_R2_TERM);  // unit (st, mb) = (0, 0); in flight while s is split
+  Wb6Frag b[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = s[8 * st + j];
+    b[st] = wb6_split8(v);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int st = i >> 2, mb = i & 3;
+    Wb6Frag nxt = cur;
+    if (i + 1 < 8) nxt = wb6_lds_frag(base + 32 * ((i + 1) >> 2) + ((i + 1) & 3) * 32 * WB6_R2_ROW, WB6_R2_TERM);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(cur.t[0]), "+v"(cur.t[1]), "+v"(cur.t[2]));
+    out[mb] = wb6_mfma6(cur, b[st], out[mb]);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+  }
+}
+__device__ __forceinline__ void wb6_store_rows(float* __restrict__ dst_row, const f32x16 (&acc)[4], int half, float scale) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int ch = mb * 32 + 8 * q4 + 4 * half;  // registers 4 q4 .. 4 q4 + 3: four consecutive channels
+      *reinterpret_cast<float4*>(dst_row + ch) = make_float4(acc[mb][4 * q4 + 0] * scale, acc[mb][4 * q4 + 1] * scale,
+                                                             acc[mb][4 * q4 + 2] * scale, acc[mb][4 * q4 + 3] * scale);
+    }
+}
+
+// LDS of both kernels: R1 x 2 | R2 x 2 | staging x 2 | token ids, regions, statistics of the streaming tile
+#define WB6_OFF_R1(i_) ((i_) * WB6_R1_BYTES)
+#define WB6_OFF_R2(i_) (2 * WB6_R1_BYTES + (i_) * WB6_R2_BYTES)
+#define WB6_OFF_ST(i_) (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + (i_) * WB6_ST_BYTES)
+#define WB6_OFF_MISC (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + 2 * WB6_ST_BYTES)
+static size_t wb6_lds_bytes() { return (size_t)WB6_OFF_MISC + WB6_T * sizeof(float4); }
+
+// ---------------------------------------------------------------------------------------------------------------- dK, dV
+// Two launches, WHICH = 0: dV (S -> P -> dV^T = dO^T P), 1: dK (S, dP -> dS -> dK^T = Q^T dS).  One kernel for both needs the
+// stationary K and V fragments (192 registers) next to two 64-register results and the tile in flight: 512 registers and 71 spilled
+// ones, slower than the exact-f32 kernel.  Apart, the dV pass keeps only K (96 + 64) and the dK pass K and V (192 + 64); the price
+// is S twice (240 instead of 192 matrix instructions per 32 x 32 block pair).
+template <int WHICH>
+__global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wb6_smem[];
+  unsigned char* q_r1 = wb6_smem + WB6_OFF_R1(0);
+  unsigned char* do_r1 = wb6_smem + WB6_OFF_R1(1);
+  unsigned char* x_r2 = wb6_smem + WB6_OFF_R2(0);   // role 2 of the tensor the chain product reads: dO (dV pass) or Q (dK pass)
+  float* x_st = reinterpret_cast<float*>(wb6_smem + WB6_OFF_ST(0));
+  float4* q_info = reinterpret_cast<float4*>(wb6_smem + WB6_OFF_MISC);  // per query of the tile: maximum, 1 / sum, <dO, O>, wrap region
+
+  const WinGeom& G = A.G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  const int n_tiles = (G.Lw + WB6_T - 1) / WB6_T;
+  const int ktile = blockIdx.x, win = blockIdx.y, seq = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_off = (size_t)seq * G.h * G.w;
+  const float* qs = A.q + seq_off * WA_C;
+  const float* ks = A.k + seq_off * WA_C;
+  const float* vs = A.v + seq_off * WA_C;
+  const float* gos = A.g_out + seq_off * WA_C;
+
+  // this lane's key: row n of the wave's block
+  const int my_li = ktile * WB6_R + wave * 32 + n;
+  int my_kreg = 0;
+  const int my_ktok = my_li < G.Lw ? win_token(G, wy, wx, my_li, my_kreg) : -1;
+  const bool k_ok = my_ktok >= 0;
+  Wb6Frag kf[8], vf[WHICH ? 8 : 1];
+  wb6_stationary(kf, ks, my_ktok, half);
+  if constexpr (WHICH == 1) wb6_stationary(vf, vs, my_ktok, half);
+
+  f32x16 res[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) res[mb] = (f32x16)(0.0f);
+  Wb6TileRegs nq, ndo;  // the next query / dO tile, in flight
+  wb6_fetch(nq, qs, G, wy, wx, 0, tid);
+  wb6_fetch(ndo, gos, G, wy, wx, 0, tid);
+  for (int qt = 0; qt < n_tiles; ++qt) {
+    __syncthreads();  // the previous tile has been consumed
+    if constexpr (WHICH == 0) {
+      wb6_store_r1(q_r1, nullptr, nq, tid);
+      wb6_store_staging(x_st, ndo, tid);
+    } else {
+      wb6_store_r1(q_r1, x_st, nq, tid);
+      wb6_store_r1(do_r1, nullptr, ndo, tid);
+    }
+    if (tid < WB6_T) {
+      int region = 0;
+      const int li = qt * WB6_T + tid;
+      const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
+      // (1 / sum = 0 for rows beyond the window: they contribute nothing)
+      q_info[tid] = make_float4(tok >= 0 ? A.row_m[seq_off + tok] : 0.0f, tok >= 0 ? 1.0f / A.row_l[seq_off + tok] : 0.0f,
+                                tok >= 0 ? A.row_d[seq_off + tok] : 0.0f, __int_as_float(region));
+    }
+    __syncthreads();
+    if (qt + 1 < n_tiles) {
+      wb6_fetch(nq, qs, G, wy, wx, (qt + 1) * WB6_T, tid);
+      wb6_fetch(ndo, gos, G, wy, wx, (qt + 1) * WB6_T, tid);
+    }
+    wb6_build_r2(x_r2, x_st, tid);
+    __syncthreads();
+    const f32x16 s_ = wb6_tile_product(q_r1, kf, n, half);    // S block: rows = queries, columns = keys
+    f32x16 dp = (f32x16)(0.0f);
+    if constexpr (WHICH == 1) dp = wb6_tile_product(do_r1, vf, n, half);   // dP block
+    float4 info[16];  // one batch of 16 reads, one wait (read where they are used they are 64 reads with a wait each)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) info[r] = q_info[wb_row(r, half)];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 x;  // P (dV pass) or dS (dK pass)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s = wb_score(s_[r], A.scale, A.do_shift && __float_as_int(info[r].w) != my_kreg, k_ok);
+      const float pr = k_ok ? __builtin_amdgcn_exp2f(s - info[r].x) * info[r].y : 0.0f;
+      x[r] = WHICH == 0 ? pr : pr * (dp[r] - info[r].z);
+    }
+    // dV^T[channel][key] += dO^T[channel][query] P[query][key]   |   dK^T[channel][key] += Q^T[channel][query] dS[query][key]
+    wb6_chain_product(res, x_r2, x, n, half);
+  }
+  if (k_ok) wb6_store_rows((WHICH == 0 ? A.g_v : A.g_k) + (seq_off + my_ktok) * WA_C, res, half, WHICH == 0 ? 1.0f : A.scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- dQ
+__global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wb6_smem[];
+  unsigned char* k_r1 = wb6_smem + WB6_OFF_R1(0);
+  unsigned char* v_r1 = wb6_smem + WB6_OFF_R1(1);
+  unsigned char* k_r2 = wb6_smem + WB6_OFF_R2(0);
+  float* k_st = reinterpret_cast<float*>(wb6_smem + WB6_OFF_ST(0));
+  int* k_info = reinterpret_cast<int*>(wb6_smem + WB6_OFF_MISC);  // per key of the tile: wrap region, -1 beyond the window
+
+  const WinGeom& G = A.G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, half = lane >> 5;
+  const int n_tiles = (G.Lw + WB6_T - 1) / WB6_T;
+  const int qtile = blockIdx.x, win = blockIdx.y, seq = blockIdx.z;
+  const int wy = win / G.splits, wx = win - wy * G.splits;
+  const size_t seq_off = (size_t)seq * G.h * G.w;
+  const float* qs = A.q + seq_off * WA_C;
+  const float* ks = A.k + seq_off * WA_C;
+  const float* vs = A.v + seq_off * WA_C;
+  const float* gos = A.g_out + seq_off * WA_C;
+
+  // this lane's query: row n of the wave's block
+  const int my_li = qtile * WB6_R + wave * 32 + n;
+  int my_qreg = 0;
+  const int my_qtok = my_li < G.Lw ? win_token(G, wy, wx, my_li, my_qreg) : -1;
+  const bool q_ok = my_qtok >= 0;
+  Wb6Frag qf[8], dof[8];
+  wb6_stationary(qf, qs, my_qtok, half);
+  wb6_stationary(dof, gos, my_qtok, half);
+  const float row_d = q_ok ? A.row_d[seq_off + my_qtok] : 0.0f;
+
+  auto publish_keys = [&](int kt) {
+    if (tid < WB6_T) {
+      int region = 0;
+      const int li = kt * WB6_T + tid;
+      const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
+      k_info[tid] = tok >= 0 ? region : -1;
+    }
+  };
+  // ---- pass 1: row statistics (online softmax over the key tiles; a wave sees every key of its queries: no merge across waves)
+  float run_m = -INFINITY, run_l = 0.0f;
+  Wb6TileRegs nk, nv;
+  wb6_fetch(nk, ks, G, wy, wx, 0, tid);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    wb6_store_r1(k_r1, nullptr, nk, tid);
+    publish_keys(kt);
+    __syncthreads();
+    if (kt + 1 < n_tiles) wb6_fetch(nk, ks, G, wy, wx, (kt + 1) * WB6_T, tid);
+    const f32x16 st = wb6_tile_product(k_r1, qf, n, half);  // S^T block: rows = keys, columns = queries
+    int4 ki[4];  // keys 4 half + 8 g .. + 3 are registers 4 g .. 4 g + 3
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[half + 2 * gq];
+    __builtin_amdgcn_sched_barrier(0);
+    float sc[16], mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
+      sc[r] = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
+      mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(run_m, mx);
+    if (m_new > -INFINITY) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(sc[r] - m_new);
+      sum += __shfl_xor(sum, 32, 64);
+      run_l = run_l * (run_m > -INFINITY ? __builtin_amdgcn_exp2f(run_m - m_new) : 0.0f) + sum;
+      run_m = m_new;
+    }
+  }
+  if (half == 0 && q_ok) {  // publish for the dK / dV kernel
+    A.row_m[seq_off + my_qtok] = run_m;
+    A.row_l[seq_off + my_qtok] = run_l;
+  }
+  const float inv_l = 1.0f / run_l;
+
+  // ---- pass 2: dQ^T[channel][query] = scale * sum_keys K^T[channel][key] dS^T[key][query]
+  f32x16 dq[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) dq[mb] = (f32x16)(0.0f);
+  wb6_fetch(nk, ks, G, wy, wx, 0, tid);
+  wb6_fetch(nv, vs, G, wy, wx, 0, tid);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    __syncthreads();
+    wb6_store_r1(k_r1, k_st, nk, tid);
+    wb6_store_r1(v_r1, nullptr, nv, tid);
+    publish_keys(kt);
+    __syncthreads();
+    if (kt + 1 < n_tiles) {
+      wb6_fetch(nk, ks, G, wy, wx, (kt + 1) * WB6_T, tid);
+      wb6_fetch(nv, vs, G, wy, wx, (kt + 1) * WB6_T, tid);
+    }
+    wb6_build_r2(k_r2, k_st, tid);
+    __syncthreads();
+    const f32x16 st = wb6_tile_product(k_r1, qf, n, half);
+    const f32x16 dpt = wb6_tile_product(v_r1, dof, n, half);  // dP^T block
+    int4 ki[4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[half + 2 * gq];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
+      const float s = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
+      const float p = q_ok ? __builtin_amdgcn_exp2f(s - run_m) * inv_l : 0.0f;
+      ds[r] = p * (dpt[r] - row_d);
+    }
+    wb6_chain_product(dq, k_r2, ds, n, half);
+  }
+  if (q_ok) wb6_store_rows(A.g_q + (seq_off + my_qtok) * WA_C, dq, half, A.scale);
+}
+
 static size_t wb_lds_bytes() { return (size_t)4 * WB_TILE_FLOATS * sizeof(float) + 4 * WB_T * sizeof(int) + 6 * WB_T * sizeof(float); }
 
 extern "C" int64_t mnerf_window_attention_backward_workspace_bytes(int32_t batch, int32_t h, int32_t w) {
@@ -427,6 +840,25 @@ extern "C" int mnerf_window_attention_backward(const float* q, const float* k, c
     (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(wa_bwd_rowdot_kernel, dim3((unsigned)((n_tok + 7) / 8)), dim3(256), 0, st, g_out, out, row_d, n_tok);
+  // MNERF_WA_BWD_MATH (environment, read once): "bf16x6" (default) = the split-bf16 kernels, "f32" = the exact-f32 ones
+  static const int math_b6 = [] {
+    const char* e = getenv("MNERF_WA_BWD_MATH");
+    return (e && !strcmp(e, "f32")) ? 0 : 1;
+  }();
+  if (math_b6) {
+    const size_t lds6 = wb6_lds_bytes();
+    static std::atomic<unsigned long long> attr6_set{0};
+    if (mnerf_once_per_device(attr6_set)) {
+      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+      (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+      (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+    }
+    const dim3 grid6((G.Lw + WB6_R - 1) / WB6_R, num_splits * num_splits, batch);
+    hipLaunchKernelGGL(wa_bwd_dq_b6_kernel, grid6, dim3(256), lds6, st, A);
+    hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<0>, grid6, dim3(256), lds6, st, A);
+    hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<1>, grid6, dim3(256), lds6, st, A);
+    return mnerf_check_launch(who);
+  }
   const int n_tiles = (G.Lw + WB_T - 1) / WB_T;
   const dim3 grid(n_tiles, num_splits * num_splits, batch);
   hipLaunchKernelGGL(wa_bwd_dq_kernel, grid, dim3(256), lds, st, A);
