@@ -8,6 +8,7 @@ import torch
 import bench
 
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = False  # (MIOpen would otherwise time every solver, naive ones included, inside the trace)
 opt, model, _ = bench.build_model(dev)
 model.train()
 opt.nerf.rand_rays_train = 1024
