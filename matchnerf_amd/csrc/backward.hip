@@ -7,6 +7,8 @@
 // The conditional MLP + ray transformer in between (K3+K4) is re-evaluated with torch ops from the saved
 // conditioning rows (matchnerf_amd/autograd.py): at training ray counts (rand_rays_train = 4096) it is a few
 // milliseconds; its hand-written backward is the remaining part of that row.
+#include <stdlib.h>
+
 #include "cv_walk.hpp"
 
 // ------------------------------------------------------------------ K5 backward, one wavefront per ray
@@ -238,6 +240,133 @@ __global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene s
   }
 }
 
+// The same gradients with the scatter-adds of CONSECUTIVE SAMPLES OF A RAY merged (round 4): a 16-lane slot owns one (ray, pair,
+// scale) and walks the ray's samples; the gradient of the four texels under the current sample accumulates in registers for as
+// long as the walk stays in that texel cell (2-4 samples at the 1/8 scale, 1-2 at 1/4) and goes out as one atomic per texel and
+// channel when it leaves the cell, instead of one per sample; the taps of a cell are loaded once per visit, not once per sample.
+// Same channel mapping as above (an atomic instruction of a slot covers one 64-byte line), same arithmetic per sample; what
+// differs is the order in which contributions reach a texel (they did not have a fixed order before either: float atomics).
+#ifndef CVB_WALK_WAVES
+#define CVB_WALK_WAVES 2
+#endif
+__global__ __launch_bounds__(256, CVB_WALK_WAVES) void cost_volume_backward_walk_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
+                                                                        const float* __restrict__ g_cond,
+                                                                        float* __restrict__ g_feat0,
+                                                                        float* __restrict__ g_feat1) {
+  constexpr int CPL = 8, LPS = FEAT_C / CPL;
+  const int sub = threadIdx.x % LPS;
+  const int S = R.n_samples, V = sc.n_views, NS = sc.n_scales;
+  const int P = V * (V - 1) / 2;
+  const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
+  const float inv_pairs = 1.0f / (float)P;
+  const long long total = (long long)R.n_rays * P * NS;
+  const long long slots = ((long long)gridDim.x * blockDim.x) / LPS;
+  const long long rounds = (total + slots - 1) / slots;  // every lane takes part in the DPP reductions of every round
+  const long long slot0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPS;
+  for (long long rnd = 0; rnd < rounds; ++rnd) {
+    const long long it_raw = slot0 + rnd * slots;
+    const bool live = it_raw < total;
+    const long long it = live ? it_raw : total - 1;
+    const int ray = (int)(it / (P * NS));
+    const int rem = (int)(it - (long long)ray * (P * NS));
+    const int p = rem / NS, s = rem - p * NS;
+    int va = 0, vb = p;  // pair p = (va, vb), va < vb, lexicographic order
+    while (vb >= V - 1 - va) {
+      vb -= V - 1 - va;
+      ++va;
+    }
+    vb += va + 1;
+    const int fh = sc.fh[s], fw = sc.fw[s];
+    const size_t map_elems = (size_t)fh * fw * FEAT_C;
+    const float* m0 = sc.feat[s] + (size_t)(2 * p) * map_elems + sub;
+    const float* m1 = m0 + map_elems;
+    float* gm0 = (s ? g_feat1 : g_feat0) + (size_t)(2 * p) * map_elems + sub;
+    float* gm1 = gm0 + map_elems;
+    const int G = sc.n_group[s];
+    const int cpg = CPL / G;  // register indices per channel group (G in {1, 2, 4, 8})
+    const int g_off = s ? sc.n_group[0] : 0;
+    const RayGeom g = make_ray(R, ray);
+
+    // the current texel cell of each side: its four texel indices, their taps and the gradient gathered for them so far
+    int ca[4] = {-1, -1, -1, -1}, cb[4] = {-1, -1, -1, -1};
+    float ta[4][CPL], tb[4][CPL], ga[4][CPL], gb[4][CPL];
+    auto flush = [&](float* gm, const int (&cell)[4], float (&acc)[4][CPL]) {
+      if (cell[0] < 0 || !live) return;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // (border cells repeat a texel: both of its entries go out, as two atomics on one address)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) atomicAdd(gm + (size_t)cell[t] * FEAT_C + c * LPS, acc[t][c]);
+      }
+    };
+    auto enter = [&](const float* m, const Bilin& b, int (&cell)[4], float (&taps)[4][CPL], float (&acc)[4][CPL]) {
+      cell[0] = b.o00, cell[1] = b.o01, cell[2] = b.o10, cell[3] = b.o11;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          taps[t][c] = m[(size_t)cell[t] * FEAT_C + c * LPS];
+          acc[t][c] = 0.0f;
+        }
+    };
+    for (int j = 0; j < S; ++j) {
+      const float d = sample_depth(R, ray, j);
+      float px, py, pz;
+      ray_point(g, d, px, py, pz);
+      float ua, va_, za, ub, vb_, zb;
+      project(sc.views[va], px, py, pz, wm1, hm1, ua, va_, za);
+      project(sc.views[vb], px, py, pz, wm1, hm1, ub, vb_, zb);
+      const Bilin ba = bilin_setup(ua, va_, fh, fw), bb = bilin_setup(ub, vb_, fh, fw);
+      if (ba.o00 != ca[0] || ba.o11 != ca[3]) {
+        flush(gm0, ca, ga);
+        enter(m0, ba, ca, ta, ga);
+      }
+      if (bb.o00 != cb[0] || bb.o11 != cb[3]) {
+        flush(gm1, cb, gb);
+        enter(m1, bb, cb, tb, gb);
+      }
+      float fa[CPL], fb[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        fa[c] = ta[0][c] * ba.w00 + ta[1][c] * ba.w01 + ta[2][c] * ba.w10 + ta[3][c] * ba.w11;
+        fb[c] = tb[0][c] * bb.w00 + tb[1][c] * bb.w01 + tb[2][c] * bb.w10 + tb[3][c] * bb.w11;
+      }
+      const float* gsrc = g_cond + ((size_t)ray * S + j) * cond_stride + g_off;
+#pragma unroll
+      for (int gi = 0; gi < CPL; ++gi) {
+        if (gi >= G) break;
+        float dot = 0.f, na2 = 0.f, nb2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (c / cpg == gi) {
+            dot += fa[c] * fb[c];
+            na2 += fa[c] * fa[c];
+            nb2 += fb[c] * fb[c];
+          }
+        dot = slot16_sum(dot);
+        na2 = slot16_sum(na2);
+        nb2 = slot16_sum(nb2);
+        const float ra = sqrtf(na2), rb = sqrtf(nb2);
+        const float na = fmaxf(ra, 1e-8f), nb = fmaxf(rb, 1e-8f);
+        const float inv = 1.0f / (na * nb);
+        const float cosv = dot * inv;
+        const float gcos = gsrc[gi] * inv_pairs;
+        const float ka = ra > 1e-8f ? cosv / na2 : 0.0f, kb = rb > 1e-8f ? cosv / nb2 : 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+          if (c / cpg == gi) {
+            const float da = gcos * (fb[c] * inv - ka * fa[c]);
+            const float db = gcos * (fa[c] * inv - kb * fb[c]);
+            ga[0][c] += da * ba.w00, ga[1][c] += da * ba.w01, ga[2][c] += da * ba.w10, ga[3][c] += da * ba.w11;
+            gb[0][c] += db * bb.w00, gb[1][c] += db * bb.w01, gb[2][c] += db * bb.w10, gb[3][c] += db * bb.w11;
+          }
+      }
+    }
+    flush(gm0, ca, ga);
+    flush(gm1, cb, gb);
+  }
+}
+
 extern "C" int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
                                           const float* g_cond, float* g_feat0, float* g_feat1, void* stream) {
   int rc = mnerf_scene_check(scene, rays, "mnerf_cost_volume_backward");
@@ -249,6 +378,19 @@ extern "C" int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_
   MNERF_REQUIRE(cond_stride >= sumG + 4 * scene->n_views + 1, MNERF_E_RANGE,
                 "mnerf_cost_volume_backward: cond_stride=%d < cond_dim+1=%d", cond_stride, sumG + 4 * scene->n_views + 1);
   if (rays->n_rays == 0) return MNERF_OK;
+  // MNERF_CV_BWD_WALK (environment, read once; default 1): the form that merges the scatter-adds along a ray
+  static const int walk = [] {
+    const char* e = getenv("MNERF_CV_BWD_WALK");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  if (walk) {
+    const long long items = (long long)rays->n_rays * (scene->n_views * (scene->n_views - 1) / 2) * scene->n_scales;
+    long long blocks = (items + 15) / 16;  // 16 slots per 256-thread workgroup, one (ray, pair, scale) each
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cost_volume_backward_walk_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *scene, *rays,
+                       cond_stride, g_cond, g_feat0, g_feat1);
+    return mnerf_check_launch("mnerf_cost_volume_backward");
+  }
   const long long total = (long long)rays->n_rays * rays->n_samples;
   long long blocks = (total + 15) / 16;  // 16 sample slots per 256-thread workgroup
   if (blocks > 4096) blocks = 4096;
