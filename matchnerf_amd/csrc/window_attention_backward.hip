@@ -599,7 +599,7 @@ __device__ __forceinline__ void wb6_store_rows(float* __restrict__ dst_row, cons
 #define WB6_OFF_R2(i_) (2 * WB6_R1_BYTES + (i_) * WB6_R2_BYTES)
 #define WB6_OFF_ST(i_) (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + (i_) * WB6_ST_BYTES)
 #define WB6_OFF_MISC (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + 2 * WB6_ST_BYTES)
-static size_t wb6_lds_bytes() { return (size_t)WB6_OFF_MISC + WB6_T * sizeof(float4); }
+static size_t wb6_lds_bytes() { return (size_t)WB6_OFF_MISC + 2 * WB6_T * sizeof(float4); }  // (statistics of two sub-tiles)
 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
 // Two launches, WHICH = 0: dV (S -> P -> dV^T = dO^T P), 1: dK (S, dP -> dS -> dK^T = Q^T dS).  One kernel for both needs the
@@ -639,49 +639,66 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
   f32x16 res[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) res[mb] = (f32x16)(0.0f);
-  Wb6TileRegs nq, ndo;  // the next query / dO tile, in flight
-  wb6_fetch(nq, qs, G, wy, wx, 0, tid);
-  wb6_fetch(ndo, gos, G, wy, wx, 0, tid);
-  for (int qt = 0; qt < n_tiles; ++qt) {
+  // NSUB 32-row sub-tiles per iteration (one set of barriers for all of them): 2 in the dV pass, whose LDS need per sub-tile is
+  // one R1, one R2 and one staging tile (the regions of the tensor it does not store are free); 1 in the dK pass
+  constexpr int NSUB = WHICH == 0 ? 2 : 1;
+  const int n_iter = (n_tiles + NSUB - 1) / NSUB;
+  Wb6TileRegs nq[NSUB], ndo[NSUB];  // the next query / dO sub-tiles, in flight
+#pragma unroll
+  for (int sb = 0; sb < NSUB; ++sb) {
+    wb6_fetch(nq[sb], qs, G, wy, wx, sb * WB6_T, tid);
+    wb6_fetch(ndo[sb], gos, G, wy, wx, sb * WB6_T, tid);
+  }
+  for (int qt = 0; qt < n_iter; ++qt) {
     __syncthreads();  // the previous tile has been consumed
-    if constexpr (WHICH == 0) {
-      wb6_store_r1(q_r1, nullptr, nq, tid);
-      wb6_store_staging(x_st, ndo, tid);
-    } else {
-      wb6_store_r1(q_r1, x_st, nq, tid);
-      wb6_store_r1(do_r1, nullptr, ndo, tid);
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb) {
+      if constexpr (WHICH == 0) {
+        wb6_store_r1(q_r1 + sb * WB6_R1_BYTES, nullptr, nq[sb], tid);
+        wb6_store_staging(x_st + sb * (WB6_ST_BYTES / 4), ndo[sb], tid);
+      } else {
+        wb6_store_r1(q_r1, x_st, nq[sb], tid);
+        wb6_store_r1(do_r1, nullptr, ndo[sb], tid);
+      }
     }
-    if (tid < WB6_T) {
+    if (tid < NSUB * WB6_T) {
       int region = 0;
-      const int li = qt * WB6_T + tid;
+      const int li = qt * NSUB * WB6_T + tid;
       const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
       // (1 / sum = 0 for rows beyond the window: they contribute nothing)
       q_info[tid] = make_float4(tok >= 0 ? A.row_m[seq_off + tok] : 0.0f, tok >= 0 ? 1.0f / A.row_l[seq_off + tok] : 0.0f,
                                 tok >= 0 ? A.row_d[seq_off + tok] : 0.0f, __int_as_float(region));
     }
     __syncthreads();
-    if (qt + 1 < n_tiles) {
-      wb6_fetch(nq, qs, G, wy, wx, (qt + 1) * WB6_T, tid);
-      wb6_fetch(ndo, gos, G, wy, wx, (qt + 1) * WB6_T, tid);
+    if (qt + 1 < n_iter) {
+#pragma unroll
+      for (int sb = 0; sb < NSUB; ++sb) {
+        wb6_fetch(nq[sb], qs, G, wy, wx, ((qt + 1) * NSUB + sb) * WB6_T, tid);
+        wb6_fetch(ndo[sb], gos, G, wy, wx, ((qt + 1) * NSUB + sb) * WB6_T, tid);
+      }
     }
-    wb6_build_r2(x_r2, x_st, tid);
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb) wb6_build_r2(x_r2 + sb * WB6_R2_BYTES, x_st + sb * (WB6_ST_BYTES / 4), tid);
     __syncthreads();
-    const f32x16 s_ = wb6_tile_product(q_r1, kf, n, half);    // S block: rows = queries, columns = keys
-    f32x16 dp = (f32x16)(0.0f);
-    if constexpr (WHICH == 1) dp = wb6_tile_product(do_r1, vf, n, half);   // dP block
-    float4 info[16];  // one batch of 16 reads, one wait (read where they are used they are 64 reads with a wait each)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) info[r] = q_info[wb_row(r, half)];
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 x;  // P (dV pass) or dS (dK pass)
+    for (int sb = 0; sb < NSUB; ++sb) {
+      const f32x16 s_ = wb6_tile_product(q_r1 + sb * WB6_R1_BYTES, kf, n, half);    // S block: rows = queries, columns = keys
+      f32x16 dp = (f32x16)(0.0f);
+      if constexpr (WHICH == 1) dp = wb6_tile_product(do_r1, vf, n, half);   // dP block
+      float4 info[16];  // one batch of 16 reads, one wait (read where they are used they are 64 reads with a wait each)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float s = wb_score(s_[r], A.scale, A.do_shift && __float_as_int(info[r].w) != my_kreg, k_ok);
-      const float pr = k_ok ? __builtin_amdgcn_exp2f(s - info[r].x) * info[r].y : 0.0f;
-      x[r] = WHICH == 0 ? pr : pr * (dp[r] - info[r].z);
+      for (int r = 0; r < 16; ++r) info[r] = q_info[sb * WB6_T + wb_row(r, half)];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 x;  // P (dV pass) or dS (dK pass)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float s = wb_score(s_[r], A.scale, A.do_shift && __float_as_int(info[r].w) != my_kreg, k_ok);
+        const float pr = k_ok ? __builtin_amdgcn_exp2f(s - info[r].x) * info[r].y : 0.0f;
+        x[r] = WHICH == 0 ? pr : pr * (dp[r] - info[r].z);
+      }
+      // dV^T[channel][key] += dO^T[channel][query] P[query][key]   |   dK^T[channel][key] += Q^T[channel][query] dS[query][key]
+      wb6_chain_product(res, x_r2 + sb * WB6_R2_BYTES, x, n, half);
     }
-    // dV^T[channel][key] += dO^T[channel][query] P[query][key]   |   dK^T[channel][key] += Q^T[channel][query] dS[query][key]
-    wb6_chain_product(res, x_r2, x, n, half);
   }
   if (k_ok) wb6_store_rows((WHICH == 0 ? A.g_v : A.g_k) + (seq_off + my_ktok) * WA_C, res, half, WHICH == 0 ? 1.0f : A.scale);
 }
@@ -726,38 +743,59 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
     }
   };
   // ---- pass 1: row statistics (online softmax over the key tiles; a wave sees every key of its queries: no merge across waves)
+  // (four 32-key sub-tiles per iteration: this pass only needs K in role 1, the LDS of the other regions is free, and one set of
+  // barriers then serves 128 keys)
+  constexpr int NSUB1 = 4;
+  const int n_iter1 = (n_tiles + NSUB1 - 1) / NSUB1;
   float run_m = -INFINITY, run_l = 0.0f;
   Wb6TileRegs nk, nv;
-  wb6_fetch(nk, ks, G, wy, wx, 0, tid);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();
-    wb6_store_r1(k_r1, nullptr, nk, tid);
-    publish_keys(kt);
-    __syncthreads();
-    if (kt + 1 < n_tiles) wb6_fetch(nk, ks, G, wy, wx, (kt + 1) * WB6_T, tid);
-    const f32x16 st = wb6_tile_product(k_r1, qf, n, half);  // S^T block: rows = keys, columns = queries
-    int4 ki[4];  // keys 4 half + 8 g .. + 3 are registers 4 g .. 4 g + 3
+  {
+    Wb6TileRegs nk1[NSUB1];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[half + 2 * gq];
-    __builtin_amdgcn_sched_barrier(0);
-    float sc[16], mx = -INFINITY;
+    for (int sb = 0; sb < NSUB1; ++sb) wb6_fetch(nk1[sb], ks, G, wy, wx, sb * WB6_T, tid);
+    for (int kt = 0; kt < n_iter1; ++kt) {
+      __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
-      sc[r] = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
-      mx = fmaxf(mx, sc[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(run_m, mx);
-    if (m_new > -INFINITY) {
-      float sum = 0.0f;
+      for (int sb = 0; sb < NSUB1; ++sb) wb6_store_r1(wb6_smem + sb * WB6_R1_BYTES, nullptr, nk1[sb], tid);
+      if (tid < NSUB1 * WB6_T) {
+        int region = 0;
+        const int li = kt * NSUB1 * WB6_T + tid;
+        const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
+        k_info[tid] = tok >= 0 ? region : -1;
+      }
+      __syncthreads();
+      if (kt + 1 < n_iter1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(sc[r] - m_new);
-      sum += __shfl_xor(sum, 32, 64);
-      run_l = run_l * (run_m > -INFINITY ? __builtin_amdgcn_exp2f(run_m - m_new) : 0.0f) + sum;
-      run_m = m_new;
+        for (int sb = 0; sb < NSUB1; ++sb) wb6_fetch(nk1[sb], ks, G, wy, wx, ((kt + 1) * NSUB1 + sb) * WB6_T, tid);
+      }
+#pragma unroll
+      for (int sb = 0; sb < NSUB1; ++sb) {
+        const f32x16 st = wb6_tile_product(wb6_smem + sb * WB6_R1_BYTES, qf, n, half);  // S^T block: rows = keys, columns = queries
+        int4 ki[4];  // keys 4 half + 8 g .. + 3 are registers 4 g .. 4 g + 3
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[sb * 8 + half + 2 * gq];
+        __builtin_amdgcn_sched_barrier(0);
+        float sc[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
+          sc[r] = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
+          mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(run_m, mx);
+        if (m_new > -INFINITY) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(sc[r] - m_new);
+          sum += __shfl_xor(sum, 32, 64);
+          run_l = run_l * (run_m > -INFINITY ? __builtin_amdgcn_exp2f(run_m - m_new) : 0.0f) + sum;
+          run_m = m_new;
+        }
+      }
     }
   }
+  __syncthreads();  // pass 2 stores into the same LDS
   if (half == 0 && q_ok) {  // publish for the dK / dV kernel
     A.row_m[seq_off + my_qtok] = run_m;
     A.row_l[seq_off + my_qtok] = run_l;
