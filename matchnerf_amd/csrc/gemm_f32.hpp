@@ -310,14 +310,15 @@ static void gemm_with(hipStream_t st, const float* a, long long sa_i, long long 
   const bool ak = sa_k == 1, bk = sb_k == 1;
   if (math_b6 && I >= 128 && J >= 128) {
     // split-bf16: 128 x 128 tiles where they fill the chip twice, 64 x 64 ones below that; a reduction over the rows (mode 2)
-    // is split into parts of at least 128 until ~1 000 workgroups exist
+    // is split into parts of at least 256 until ~1 000 workgroups exist
     const long long t128 = (long long)((I + 127) / 128) * ((J + 127) / 128);
     const int T = t128 >= 512 ? 128 : 64;
     const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
     int split = 1;
     if (mode == 2) {
+      // measured (N = 30 720 rows, [N,128]^T [N,128]): parts of >= 256 rows 29.4 us, >= 128 36.4, >= 512 31.2; 128-tiles 40.6
       split = 1024 / (ti * tj);
-      const int max_split = (K + 127) / 128;
+      const int max_split = (K + 255) / 256;
       if (split > max_split) split = max_split;
       if (split < 1) split = 1;
     }
