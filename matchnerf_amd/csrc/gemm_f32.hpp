@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void gemm_f32_tile128_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------ the same product on the 16-bit matrix pipe: split-bf16
-// Every fp32 operand element is three bf16 terms (hi + mid + lo = the fp32 value exactly: 3 x 8 significand bits), a product is
+// Every fp32 operand element is three bf16 terms (hi + mid + lo = the fp32 value exactly for |x| >= 2^-100: 3 x 8 significand bits;
+// below that the third term sinks into the subnormals and the value keeps >= 16 bits: tests/test_split_bf16_cpu.py), a product is
 // accumulated in fp32 from the six term products that are not below 2^-24 of it (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi;
 // the scheme of the decoder's "bf16x6" matrix path, decoder.hip) on v_mfma_f32_32x32x16_bf16: 16 K-elements per 32-cycle
 // instruction against 2 for the exact-f32 one, i.e. 8/6 x 2 = 2.7 x its rate, with fp32's exponent range (no scaling, unlike the
