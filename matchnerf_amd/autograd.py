@@ -122,7 +122,14 @@ class _TransformerLayerFn(torch.autograd.Function):
         h, w, splits, shifted = ctx.geom
         b, n, c = source.shape
         flat = lambda t: t.reshape(b * n, c)
-        grads = {p: torch.zeros_like(p) for p, need in zip(params, ctx.needs_input_grad[4:]) if need}
+        # (the kernels ACCUMULATE into the parameter gradients - split-K atomics -: one zero-filled buffer per layer, cut into views,
+        # instead of up to ten fill launches)
+        need = [p for p, nd in zip(params, ctx.needs_input_grad[4:]) if nd]
+        flat_grads = torch.zeros(sum(p.numel() for p in need), device=source.device, dtype=source.dtype)
+        grads, off = {}, 0
+        for p in need:
+            grads[p] = flat_grads[off:off + p.numel()].view_as(p)
+            off += p.numel()
         g_attn, g_source = hip.encoder_layer_backward(layer, flat(attn), flat(source), flat(g_out.contiguous()), grads)
         gq, gk, gv = hip.window_attention_backward(q, k, v, attn, g_attn.reshape(b, n, c), h, w, splits, shifted)
         wq, wk, wv = layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight
