@@ -61,7 +61,7 @@ def _window_attention_torch(q, k, v, h, w, splits, shifted):
 
 class _WindowAttentionFn(torch.autograd.Function):
     """HIP forward (the inference kernel) and HIP backward (mnerf_window_attention_backward: flash style, the
-    [windows, L_w, L_w] score tensor is never built; exact fp32, deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
+    [windows, L_w, L_w] score tensor is never built; fp32-grade split-bf16 products or, MNERF_WA_BWD_MATH=f32, exact fp32; deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
     form for comparison: re-evaluation of the op chain with torch ops under autograd (``_window_attention_torch``)."""
 
     @staticmethod
@@ -98,7 +98,7 @@ def window_attention(q, k, v, h, w, splits, shifted):
 class _TransformerLayerFn(torch.autograd.Function):
     """TransformerLayer.forward (gmflow/transformer.py:147-185) as one autograd node.  Forward: the inference kernels
     (mnerf_qkv_projection, K6, K7 = mnerf_encoder_block).  Backward, all HIP: mnerf_encoder_layer_backward (the chain after
-    the attention, re-evaluated in exact fp32 from the saved attention output and layer input) -> mnerf_window_attention_backward
+    the attention, re-evaluated in fp32 from the saved attention output and layer input; GEMMs split-bf16 or, MNERF_GEMM_MATH=f32, exact) -> mnerf_window_attention_backward
     -> mnerf_qkv_backward.  Saved: the layer's two inputs, q, k, v and the attention output (six [B, h*w, 128] tensors)."""
 
     @staticmethod
