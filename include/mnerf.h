@@ -353,6 +353,16 @@ int mnerf_window_attention_backward(const float* q, const float* k, const float*
                                     float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,
                                     int32_t num_splits, int32_t shifted, void* workspace, size_t workspace_bytes,
                                     void* stream);
+/* Training pair: the forward that also publishes the softmax's row statistics, row_stats = [2][batch * h*w] fp32 (running
+ * maximum | sum of exponentials, log2 domain, token order), and the backward that reads them instead of recomputing them in a
+ * first pass over all keys.  Same results as the pair above up to the last bits of the statistics. */
+int mnerf_window_attention_presplit_stats(const float* q, const float* k, const float* v, float* out, float* row_stats,
+                                          int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                          void* workspace, size_t workspace_bytes, void* stream);
+int mnerf_window_attention_backward_stats(const float* q, const float* k, const float* v, const float* out, const float* g_out,
+                                          const float* row_stats, float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h,
+                                          int32_t w, int32_t num_splits, int32_t shifted, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 
 /* InstanceNorm2d (no affine, biased variance, as torch.nn.functional.instance_norm) of an NCHW tensor fused with what
  * follows it in the GMFlow backbone (models/gmflow/backbone.py:27-35, 101-103):

@@ -59,17 +59,25 @@ def _window_attention_torch(q, k, v, h, w, splits, shifted):
     return out.reshape(b, h * w, c)
 
 
+def _forward_stats():
+    """the training forward publishes the softmax's row statistics for the backward (MNERF_WA_FWD_STATS=0: the backward recomputes
+    them in a first pass, the round-4 form before the statistics pair existed)"""
+    return hip.wa_math() == hip.WA_PRESPLIT_F16 and os.environ.get("MNERF_WA_FWD_STATS", "1") != "0"
+
+
 class _WindowAttentionFn(torch.autograd.Function):
-    """HIP forward (the inference kernel) and HIP backward (mnerf_window_attention_backward: flash style, the
-    [windows, L_w, L_w] score tensor is never built; fp32-grade split-bf16 products or, MNERF_WA_BWD_MATH=f32, exact fp32; deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
+    """HIP forward (the inference kernel, publishing the softmax's row statistics) and HIP backward
+    (mnerf_window_attention_backward_stats: flash style, the [windows, L_w, L_w] score tensor is never built; fp32-grade
+    split-bf16 products or, MNERF_WA_BWD_MATH=f32, exact fp32; deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
     form for comparison: re-evaluation of the op chain with torch ops under autograd (``_window_attention_torch``)."""
 
     @staticmethod
     def forward(ctx, q, k, v, h, w, splits, shifted):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out = hip.window_attention(q, k, v, h, w, splits, shifted)
+        stats = torch.empty(2, q.shape[0] * q.shape[1], device=q.device) if _forward_stats() else None
+        out = hip.window_attention(q, k, v, h, w, splits, shifted, row_stats=stats)
         ctx.save_for_backward(q, k, v, out)
-        ctx.geom = (h, w, splits, shifted)
+        ctx.geom, ctx.stats = (h, w, splits, shifted), stats
         return out
 
     @staticmethod
@@ -81,7 +89,7 @@ class _WindowAttentionFn(torch.autograd.Function):
                 re = _window_attention_torch(q, k, v, *ctx.geom)
             gq, gk, gv = torch.autograd.grad(re, (q, k, v), grad_out)
         else:
-            gq, gk, gv = hip.window_attention_backward(q, k, v, out, grad_out.contiguous(), *ctx.geom)
+            gq, gk, gv = hip.window_attention_backward(q, k, v, out, grad_out.contiguous(), *ctx.geom, row_stats=ctx.stats)
         return gq, gk, gv, None, None, None, None
 
 
@@ -97,9 +105,10 @@ def window_attention(q, k, v, h, w, splits, shifted):
 
 class _TransformerLayerFn(torch.autograd.Function):
     """TransformerLayer.forward (gmflow/transformer.py:147-185) as one autograd node.  Forward: the inference kernels
-    (mnerf_qkv_projection, K6, K7 = mnerf_encoder_block).  Backward, all HIP: mnerf_encoder_layer_backward (the chain after
-    the attention, re-evaluated in fp32 from the saved attention output and layer input; GEMMs split-bf16 or, MNERF_GEMM_MATH=f32, exact) -> mnerf_window_attention_backward
-    -> mnerf_qkv_backward.  Saved: the layer's two inputs, q, k, v and the attention output (six [B, h*w, 128] tensors)."""
+    (mnerf_qkv_projection, K6 with its row statistics, K7 = mnerf_encoder_block).  Backward, all HIP:
+    mnerf_encoder_layer_backward (the chain after the attention, re-evaluated in fp32 from the saved attention output and layer
+    input; GEMMs split-bf16 or, MNERF_GEMM_MATH=f32, exact) -> mnerf_window_attention_backward_stats -> mnerf_qkv_backward.
+    Saved: the layer's two inputs, q, k, v, the attention output (six [B, h*w, 128] tensors) and two floats per token."""
 
     @staticmethod
     def forward(ctx, source, target, geom, layer, *params):
@@ -107,11 +116,14 @@ class _TransformerLayerFn(torch.autograd.Function):
         source, target = source.contiguous(), target.contiguous()
         ws, ews = layer._packed_qkv(source.device)
         q, k, v = hip.qkv_projection(ws, ews, source, target, False)
-        attn = hip.window_attention(q, k, v, h, w, splits, shifted)
-        bws, ln, bews = layer._packed_block(source.device)
         b, n, c = source.shape
+        # the softmax's row statistics travel to the backward (2 floats per token), which then has no statistics pass
+        stats = torch.empty(2, b * n, device=source.device) if _forward_stats() else None
+        attn = hip.window_attention(q, k, v, h, w, splits, shifted, row_stats=stats)
+        bws, ln, bews = layer._packed_block(source.device)
         out = hip.encoder_block(attn.reshape(b * n, c), source.reshape(b * n, c), bws, ln, not layer.no_ffn, bews).reshape(b, n, c)
         ctx.save_for_backward(source, target, q, k, v, attn)
+        ctx.stats = stats
         ctx.geom, ctx.layer, ctx.params = geom, layer, params
         return out
 
@@ -131,7 +143,7 @@ class _TransformerLayerFn(torch.autograd.Function):
             grads[p] = flat_grads[off:off + p.numel()].view_as(p)
             off += p.numel()
         g_attn, g_source = hip.encoder_layer_backward(layer, flat(attn), flat(source), flat(g_out.contiguous()), grads)
-        gq, gk, gv = hip.window_attention_backward(q, k, v, attn, g_attn.reshape(b, n, c), h, w, splits, shifted)
+        gq, gk, gv = hip.window_attention_backward(q, k, v, attn, g_attn.reshape(b, n, c), h, w, splits, shifted, row_stats=ctx.stats)
         wq, wk, wv = layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight
         g_xq, g_xkv = hip.qkv_backward(wq, wk, wv, flat(source), flat(target), flat(gq), flat(gk), flat(gv),
                                        grads.get(wq), grads.get(wk), grads.get(wv))

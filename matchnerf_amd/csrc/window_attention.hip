@@ -684,7 +684,10 @@ __device__ __forceinline__ void wa_stage_image(const u32x4* __restrict__ img_til
               __builtin_amdgcn_readfirstlane(lds_base + (unsigned)piece * 1024u));
 }
 
-template <int NQW>
+// STATS (training forward): the row statistics of the online softmax - running maximum and sum of exponentials, log2 domain, the
+// very quantities the backward's first pass would recompute - are written to [2][n_batch * h * w] floats behind `tl` (the debug
+// pointer of the timeline build, otherwise unused: the inference instance keeps its signature and its code).
+template <int NQW, bool STATS = false>
 __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const float* __restrict__ q, const u32x4* __restrict__ img, const int* __restrict__ gains,
     float* __restrict__ out, WinGeom G, int shifted, float scale, int n_batch, int xcd_map, unsigned long long* tl) {
@@ -947,6 +950,16 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
                                      o[m][4 * g4 + 2] * inv_l, o[m][4 * g4 + 3] * inv_l);
         *reinterpret_cast<float4*>(dst + m * 32 + 8 * g4 + 4 * hl) = t;
       }
+#ifndef MNERF_TIMELINE
+    if constexpr (STATS) {
+      if (hl == 0) {  // both halves of a query's lane pair hold the same statistics
+        float* st = reinterpret_cast<float*>(tl);
+        const size_t tok = (size_t)b * G.h * G.w + q_tok, n_tok = (size_t)n_batch * G.h * G.w;
+        st[tok] = m_run;
+        st[n_tok + tok] = l_run;
+      }
+    }
+#endif
   }
 }
 
@@ -956,7 +969,7 @@ extern "C" size_t mnerf_window_attention_workspace_bytes(int32_t batch, int32_t 
 
 // the attention kernel over prepared images (filled by wa_presplit_kernel or by the q|k|v kernel, qkv.hip)
 static int wa_launch_main(const char* who, const float* q, float* out, const WinGeom& G, int do_shift, int32_t batch,
-                          int32_t num_splits, void* workspace, hipStream_t st) {
+                          int32_t num_splits, void* workspace, hipStream_t st, float* row_stats = nullptr) {
   const int n_tiles = (G.Lw + WA_KT - 1) / WA_KT;
   const int n_win = num_splits * num_splits;
   const u32x4* img = reinterpret_cast<const u32x4*>(workspace);
@@ -967,6 +980,8 @@ static int wa_launch_main(const char* who, const float* q, float* out, const Win
   if (mnerf_once_per_device(attr)) {
     (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)window_attention_pre_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   unsigned long long* tl = nullptr;
 #ifdef MNERF_TIMELINE
@@ -978,6 +993,18 @@ static int wa_launch_main(const char* who, const float* q, float* out, const Win
   const bool four = wgs4 >= mnerf_tune().wa_min4;
   const int n_qb = four ? (G.Lw + 127) / 128 : (G.Lw + 63) / 64;
   const dim3 grid((unsigned)(8 * win_groups * n_qb));
+#ifndef MNERF_TIMELINE
+  if (row_stats) {
+    unsigned long long* sp = reinterpret_cast<unsigned long long*>(row_stats);
+    if (four)
+      hipLaunchKernelGGL((window_attention_pre_kernel<4, true>), grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, sp);
+    else
+      hipLaunchKernelGGL((window_attention_pre_kernel<2, true>), grid, dim3(128), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, sp);
+    return mnerf_check_launch(who);
+  }
+#else
+  MNERF_REQUIRE(!row_stats, MNERF_E_UNSUPPORTED, "%s: no row statistics in the timeline build", who);
+#endif
   if (four)
     hipLaunchKernelGGL(window_attention_pre_kernel<4>, grid, dim3(256), lds, st, q, img, gains, out, G, do_shift, scale, batch, xcd, tl);
   else
@@ -993,10 +1020,9 @@ static int wa_check_workspace(const char* who, const void* workspace, size_t wor
   return MNERF_OK;
 }
 
-extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, const float* v, float* out,
-                                               int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
-                                               void* workspace, size_t workspace_bytes, void* stream) {
-  const char* who = "mnerf_window_attention_presplit";
+static int wa_presplit_impl(const char* who, const float* q, const float* k, const float* v, float* out, float* row_stats,
+                            int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   MNERF_REQUIRE(q && k && v && out, MNERF_E_NULL, "%s: NULL buffer", who);
   MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(k) && mnerf_aligned16(v) && mnerf_aligned16(out), MNERF_E_ALIGN,
                 "%s: buffers must be 16-byte aligned", who);
@@ -1011,7 +1037,23 @@ extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, c
   int* gains = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (size_t)batch * n_win * n_tiles * WA_IMG_BYTES);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wa_presplit_kernel, dim3(n_tiles, n_win, batch), dim3(64), 0, st, k, v, img, gains, G);
-  return wa_launch_main(who, q, out, G, do_shift, batch, num_splits, workspace, st);
+  return wa_launch_main(who, q, out, G, do_shift, batch, num_splits, workspace, st, row_stats);
+}
+
+extern "C" int mnerf_window_attention_presplit(const float* q, const float* k, const float* v, float* out,
+                                               int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  return wa_presplit_impl("mnerf_window_attention_presplit", q, k, v, out, nullptr, batch, h, w, num_splits, shifted, workspace,
+                          workspace_bytes, stream);
+}
+
+// the training forward: the same launch, and the softmax's row statistics for mnerf_window_attention_backward_stats
+extern "C" int mnerf_window_attention_presplit_stats(const float* q, const float* k, const float* v, float* out, float* row_stats,
+                                                     int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                                     void* workspace, size_t workspace_bytes, void* stream) {
+  const char* who = "mnerf_window_attention_presplit_stats";
+  MNERF_REQUIRE(row_stats, MNERF_E_NULL, "%s: row_stats is NULL", who);
+  return wa_presplit_impl(who, q, k, v, out, row_stats, batch, h, w, num_splits, shifted, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mnerf_window_attention_images(const float* q, float* out, int32_t batch, int32_t h, int32_t w,

@@ -704,6 +704,8 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dQ
+// HAVE_STATS: the forward published the row statistics (mnerf_window_attention_presplit_stats): no first pass
+template <bool HAVE_STATS>
 __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wb6_smem[];
   unsigned char* k_r1 = wb6_smem + WB6_OFF_R1(0);
@@ -749,7 +751,10 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
   const int n_iter1 = (n_tiles + NSUB1 - 1) / NSUB1;
   float run_m = -INFINITY, run_l = 0.0f;
   Wb6TileRegs nk, nv;
-  {
+  if constexpr (HAVE_STATS) {
+    run_m = q_ok ? A.row_m[seq_off + my_qtok] : 0.0f;
+    run_l = q_ok ? A.row_l[seq_off + my_qtok] : 1.0f;
+  } else {
     Wb6TileRegs nk1[NSUB1];
 #pragma unroll
     for (int sb = 0; sb < NSUB1; ++sb) wb6_fetch(nk1[sb], ks, G, wy, wx, sb * WB6_T, tid);
@@ -796,9 +801,11 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
     }
   }
   __syncthreads();  // pass 2 stores into the same LDS
-  if (half == 0 && q_ok) {  // publish for the dK / dV kernel
-    A.row_m[seq_off + my_qtok] = run_m;
-    A.row_l[seq_off + my_qtok] = run_l;
+  if constexpr (!HAVE_STATS) {
+    if (half == 0 && q_ok) {  // publish for the dK / dV kernel
+      A.row_m[seq_off + my_qtok] = run_m;
+      A.row_l[seq_off + my_qtok] = run_l;
+    }
   }
   const float inv_l = 1.0f / run_l;
 
@@ -846,11 +853,9 @@ extern "C" int64_t mnerf_window_attention_backward_workspace_bytes(int32_t batch
   return (int64_t)3 * batch * h * w * (int64_t)sizeof(float);  // row maximum | row sum | <dO, O>
 }
 
-extern "C" int mnerf_window_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* g_out,
-                                               float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,
-                                               int32_t num_splits, int32_t shifted, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
-  const char* who = "mnerf_window_attention_backward";
+static int wa_backward_impl(const char* who, const float* q, const float* k, const float* v, const float* out, const float* g_out,
+                            const float* row_stats, float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,
+                            int32_t num_splits, int32_t shifted, void* workspace, size_t workspace_bytes, void* stream) {
   MNERF_REQUIRE(q && k && v && out && g_out && g_q && g_k && g_v, MNERF_E_NULL, "%s: NULL buffer", who);
   MNERF_REQUIRE(mnerf_aligned16(q) && mnerf_aligned16(k) && mnerf_aligned16(v) && mnerf_aligned16(out) && mnerf_aligned16(g_out) &&
                     mnerf_aligned16(g_q) && mnerf_aligned16(g_k) && mnerf_aligned16(g_v),
@@ -887,12 +892,19 @@ extern "C" int mnerf_window_attention_backward(const float* q, const float* k, c
     const size_t lds6 = wb6_lds_bytes();
     static std::atomic<unsigned long long> attr6_set{0};
     if (mnerf_once_per_device(attr6_set)) {
-      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
       (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
       (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
     }
     const dim3 grid6((G.Lw + WB6_R - 1) / WB6_R, num_splits * num_splits, batch);
-    hipLaunchKernelGGL(wa_bwd_dq_b6_kernel, grid6, dim3(256), lds6, st, A);
+    if (row_stats) {  // the forward's statistics: read in place by all three kernels
+      A.row_m = const_cast<float*>(row_stats);
+      A.row_l = A.row_m + n_tok;
+      hipLaunchKernelGGL(wa_bwd_dq_b6_kernel<true>, grid6, dim3(256), lds6, st, A);
+    } else {
+      hipLaunchKernelGGL(wa_bwd_dq_b6_kernel<false>, grid6, dim3(256), lds6, st, A);
+    }
     hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<0>, grid6, dim3(256), lds6, st, A);
     hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<1>, grid6, dim3(256), lds6, st, A);
     return mnerf_check_launch(who);
@@ -902,4 +914,24 @@ extern "C" int mnerf_window_attention_backward(const float* q, const float* k, c
   hipLaunchKernelGGL(wa_bwd_dq_kernel, grid, dim3(256), lds, st, A);
   hipLaunchKernelGGL(wa_bwd_dkv_kernel, grid, dim3(256), lds, st, A);
   return mnerf_check_launch(who);
+}
+
+extern "C" int mnerf_window_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* g_out,
+                                               float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,
+                                               int32_t num_splits, int32_t shifted, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+  return wa_backward_impl("mnerf_window_attention_backward", q, k, v, out, g_out, nullptr, g_q, g_k, g_v, batch, h, w, num_splits,
+                          shifted, workspace, workspace_bytes, stream);
+}
+
+// the same with the row statistics of the forward (mnerf_window_attention_presplit_stats): the dQ kernel's first pass is skipped
+// (the exact-f32 form, MNERF_WA_BWD_MATH=f32, ignores them and recomputes)
+extern "C" int mnerf_window_attention_backward_stats(const float* q, const float* k, const float* v, const float* out,
+                                                     const float* g_out, const float* row_stats, float* g_q, float* g_k, float* g_v,
+                                                     int32_t batch, int32_t h, int32_t w, int32_t num_splits, int32_t shifted,
+                                                     void* workspace, size_t workspace_bytes, void* stream) {
+  const char* who = "mnerf_window_attention_backward_stats";
+  MNERF_REQUIRE(row_stats, MNERF_E_NULL, "%s: row_stats is NULL", who);
+  return wa_backward_impl(who, q, k, v, out, g_out, row_stats, g_q, g_k, g_v, batch, h, w, num_splits, shifted, workspace,
+                          workspace_bytes, stream);
 }

@@ -29,7 +29,8 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
-           "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm")
+           "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
+           "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
 
 
 class MnerfError(RuntimeError):
@@ -592,8 +593,9 @@ def wa_math():
     return table[m]
 
 
-def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, stream=None):
-    """K6 (gmflow/transformer.py:8-105). q,k,v [B,h*w,128] -> [B,h*w,128]."""
+def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, stream=None, row_stats=None):
+    """K6 (gmflow/transformer.py:8-105). q,k,v [B,h*w,128] -> [B,h*w,128].  ``row_stats`` (training forward, default arithmetic
+    only): a float32 [2, B*h*w] tensor that receives the softmax's row statistics for ``window_attention_backward``."""
     import torch
     lib = load()
     _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
@@ -609,18 +611,30 @@ def window_attention(q, k, v, h, w, num_splits, shifted, out=None, math=None, st
             ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)  # caching allocator: no hipMalloc
             if stream is not None:
                 ws.record_stream(stream)
+            if row_stats is not None:
+                if tuple(row_stats.shape) != (2, b * n) or row_stats.dtype != torch.float32 or not row_stats.is_contiguous():
+                    raise MnerfError(f"window_attention: row_stats must be a contiguous float32 [2, {b * n}] tensor")
+                fn = lib.mnerf_window_attention_presplit_stats
+                fn.restype = C.c_int
+                fn.argtypes = [C.c_void_p] * 5 + [C.c_int32] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]
+                check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), row_stats.data_ptr(), b, h, w, int(num_splits),
+                         int(bool(shifted)), ws.data_ptr(), nbytes, st), "mnerf_window_attention_presplit_stats")
+                return out
             check(lib.mnerf_window_attention_presplit(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                                       int(bool(shifted)), C.c_void_p(ws.data_ptr()), nbytes, st),
                   "mnerf_window_attention_presplit")
+        elif row_stats is not None:
+            raise MnerfError("window_attention: row_stats needs the default arithmetic (MNERF_WA_MATH=f16pre)")
         else:
             check(lib.mnerf_window_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, h, w, int(num_splits),
                                              int(bool(shifted)), math, st), "mnerf_window_attention")
     return out
 
 
-def window_attention_backward(q, k, v, out, g_out, h, w, num_splits, shifted, stream=None):
+def window_attention_backward(q, k, v, out, g_out, h, w, num_splits, shifted, stream=None, row_stats=None):
     """K6 backward (mnerf_window_attention_backward): gradients of q, k, v [B,h*w,128] given the forward's ``out`` and its
-    gradient ``g_out``; flash style (no score tensor), exact fp32, deterministic."""
+    gradient ``g_out``; flash style (no score tensor), fp32-grade, deterministic.  ``row_stats``: what ``window_attention``
+    filled in the forward (the statistics pass is skipped)."""
     import torch
     lib = load()
     for t, name in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (g_out, "g_out")):
@@ -634,6 +648,16 @@ def window_attention_backward(q, k, v, out, g_out, h, w, num_splits, shifted, st
     if stream is not None:
         ws.record_stream(stream)
     with _on(q.device, stream) as st:
+        if row_stats is not None:
+            if tuple(row_stats.shape) != (2, b * n) or row_stats.dtype != torch.float32 or not row_stats.is_contiguous():
+                raise MnerfError(f"window_attention_backward: row_stats must be a contiguous float32 [2, {b * n}] tensor")
+            fn = lib.mnerf_window_attention_backward_stats
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] * 9 + [C.c_int32] * 5 + [C.c_void_p, C.c_size_t, C.c_void_p]
+            check(fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), g_out.data_ptr(), row_stats.data_ptr(), g_q.data_ptr(),
+                     g_k.data_ptr(), g_v.data_ptr(), b, h, w, int(num_splits), int(bool(shifted)), ws.data_ptr(), ws.numel() * 4, st),
+                  "mnerf_window_attention_backward_stats")
+            return g_q, g_k, g_v
         check(lib.mnerf_window_attention_backward(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(g_out), _ptr(g_q), _ptr(g_k), _ptr(g_v),
                                                   b, h, w, int(num_splits), int(bool(shifted)), C.c_void_p(ws.data_ptr()),
                                                   ws.numel() * 4, st), "mnerf_window_attention_backward")

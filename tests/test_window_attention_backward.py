@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
     (2, 32, 40, 4, True),    # attn_splits 4 (rect_wide / IBRNet-style)
     (6, 64, 80, 2, True),    # the DTU shape: 3 pairs x 2 directions, 1280-token windows
 ])
-def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shifted):
+@pytest.mark.parametrize("forward_stats", [False, True])
+def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shifted, forward_stats):
+    """forward_stats: the training pair (mnerf_window_attention_presplit_stats -> mnerf_window_attention_backward_stats): the
+    forward publishes the softmax's row statistics, the backward has no statistics pass"""
     from matchnerf_amd import hip
     gen = torch.Generator().manual_seed(h * 1000 + w * 10 + splits + int(shifted))
     n, c = h * w, 128
@@ -26,9 +29,13 @@ def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shi
     v = torch.randn(b, n, c, generator=gen)
     g = torch.randn(b, n, c, generator=gen)
     qg, kg, vg, gg = q.cuda(), k.cuda(), v.cuda(), g.cuda()
-    out = hip.window_attention(qg, kg, vg, h, w, splits, shifted)
-    gq, gk, gv = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
-    again = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
+    stats = torch.full((2, b * n), float("nan"), device="cuda") if forward_stats else None
+    out = hip.window_attention(qg, kg, vg, h, w, splits, shifted, row_stats=stats)
+    if forward_stats:
+        assert torch.isfinite(stats).all() and float(stats[1].min()) >= 1.0   # every token's row was written; sum of exponentials >= its own maximum term
+        assert torch.equal(out, hip.window_attention(qg, kg, vg, h, w, splits, shifted))  # the statistics instance computes the same output bits
+    gq, gk, gv = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted, row_stats=stats)
+    again = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted, row_stats=stats)
     for a, bb in zip((gq, gk, gv), again):
         assert torch.equal(a, bb)                       # no atomics: bit-reproducible
     q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
