@@ -92,3 +92,73 @@ def test_lds_strides_are_conflict_free_for_16_lane_groups():
             for d in range(4):
                 banks.add((first + d) % 64)
         assert len(banks) == 64, stride_bytes
+
+
+def mfma6(a_terms, b_terms):
+    """one K16-step of wb6_mfma6: A [32,16] x B [16,32] from the six kept term products, smallest first, fp32 accumulation"""
+    acc = np.zeros((a_terms[0].shape[0], b_terms[0].shape[1]), np.float32)
+    for ta, tb in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+        acc = (acc + (a_terms[ta].astype(np.float64) @ b_terms[tb].astype(np.float64)).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def test_dk_dv_dataflow_of_the_split_bf16_attention_backward():
+    """wa_bwd_dkv_b6_kernel<0 | 1> for one workgroup, restated: a 96-token window (no shift) against a 128-row stationary key block
+    (32 rows beyond the window), three 32-query streaming tiles; role-1 fragments [row][16 channels of step u], role-2 lines with
+    the permuted rows, P / dS taken register by register from the accumulator map; the forward's row statistics as input.
+    Judge: the dense float64 gradients."""
+    rng = np.random.default_rng(7)
+    lw, c = 96, 128
+    q, k, v, go = (rng.standard_normal((lw, c)).astype(np.float32) * s for s in (0.6, 0.8, 1.0, 1.0))
+    scale, log2e = 1.0 / np.sqrt(c), 1.4426950408889634
+    # float64 reference
+    s64 = (q.astype(np.float64) @ k.astype(np.float64).T) * scale
+    p64 = np.exp(s64 - s64.max(1, keepdims=True))
+    p64 /= p64.sum(1, keepdims=True)
+    o64 = p64 @ v.astype(np.float64)
+    dp64 = go.astype(np.float64) @ v.astype(np.float64).T
+    d64 = (go.astype(np.float64) * o64).sum(1, keepdims=True)
+    ds64 = p64 * (dp64 - d64)
+    dv_ref, dk_ref = p64.T @ go.astype(np.float64), (ds64.T @ q.astype(np.float64)) * scale
+    # what the forward publishes (log2 domain) and the row dot products
+    s2 = s64 * log2e
+    row_m = s2.max(1).astype(np.float32)
+    row_l = np.exp2(s2 - row_m[:, None]).sum(1).astype(np.float32)
+    row_d = d64[:, 0].astype(np.float32)
+
+    def frag_terms(x):
+        return [t for t in split3(x)]
+
+    dk, dv = np.zeros((128, c), np.float32), np.zeros((128, c), np.float32)
+    for wave in range(4):                                   # a wave owns 32 keys
+        key_rows = np.arange(32 * wave, 32 * wave + 32)
+        k_ok = key_rows < lw
+        kblk = np.where(k_ok[:, None], k[np.minimum(key_rows, lw - 1)], 0.0).astype(np.float32)
+        vblk = np.where(k_ok[:, None], v[np.minimum(key_rows, lw - 1)], 0.0).astype(np.float32)
+        kf, vf = frag_terms(kblk), frag_terms(vblk)         # stationary fragments: [32 keys][128 ch] per term
+        res_k, res_v = np.zeros((c, 32), np.float32), np.zeros((c, 32), np.float32)  # dK^T / dV^T [channel][key]
+        for qt in range(3):                                 # streaming tiles of 32 queries
+            rows = np.arange(32 * qt, 32 * qt + 32)
+            qtile, dotile = q[rows], go[rows]
+            q_r1, do_r1 = frag_terms(qtile), frag_terms(dotile)
+            s_blk, dp_blk = np.zeros((32, 32), np.float32), np.zeros((32, 32), np.float32)
+            for u in range(8):                              # S = Q K^T and dP = dO V^T over the channels, one K16-step at a time
+                ch = slice(16 * u, 16 * u + 16)
+                s_blk = (s_blk + mfma6([t[:, ch] for t in q_r1], [t[:, ch].T for t in kf])).astype(np.float32)
+                dp_blk = (dp_blk + mfma6([t[:, ch] for t in do_r1], [t[:, ch].T for t in vf])).astype(np.float32)
+            sc = (s_blk * np.float32(scale)) * np.float32(log2e)
+            p = np.where(k_ok[None, :], np.exp2(sc - row_m[rows][:, None]) / row_l[rows][:, None], 0.0).astype(np.float32)
+            ds = (p * (dp_blk - row_d[rows][:, None])).astype(np.float32)
+            # role 2: [channel][position], position 16 s + 8 h + j holds row 16 s + 8 (j >> 2) + 4 h + (j & 3)
+            pos_row = np.array([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)])
+            do_r2 = [t[pos_row].T for t in frag_terms(dotile)]   # [term][channel][32 positions]
+            q_r2 = [t[pos_row].T for t in frag_terms(qtile)]
+            for s in range(2):                              # chain products: the B operand is P / dS register by register
+                regs = np.array([wb_row(8 * s + j, h) for h in range(2) for j in range(8)])   # rows in K16 order (h, j)
+                pos = slice(16 * s, 16 * s + 16)
+                res_v = (res_v + mfma6([t[:, pos] for t in do_r2], frag_terms(p[regs]))).astype(np.float32)
+                res_k = (res_k + mfma6([t[:, pos] for t in q_r2], frag_terms(ds[regs]))).astype(np.float32)
+        dv[key_rows], dk[key_rows] = res_v.T, res_k.T * np.float32(scale)
+    for got, ref in ((dv[:lw], dv_ref), (dk[:lw], dk_ref)):
+        assert np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max() < 3e-6
+    assert np.all(dv[lw:] == 0) and np.all(dk[lw:] == 0)   # rows beyond the window: nothing
