@@ -16,7 +16,7 @@ def main(root):
                 calls[k].add((path, row["Dispatch_Id"]))
     for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("FETCH_SIZE", 0))):
         if not any(s in k for s in ("decoder_kernel", "decoder_pp_kernel", "cost_volume", "window_attention", "encoder_block", "conv_kernel",
-                                    "conv_stem", "qkv_", "instance_norm")):
+                                    "conv_stem", "qkv_", "instance_norm", "wa_bwd", "gemm_", "eb_")):
             continue
         n = max(len(calls[k]), 1)
         print(f"## {k}  ({n} dispatch rows)")
