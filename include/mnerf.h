@@ -24,7 +24,13 @@
  *   - process-wide state: none that a caller can observe.  Debug / tuning knobs (MNERF_DECODER_GRID,
  *     MNERF_DECODER_STAGGER[_MODE], MNERF_CV_VARIANT, MNERF_CV_GRID, MNERF_WA_MIN4, MNERF_WA_XCD, MNERF_RENDER_FUSED) are read from the
  *     environment ONCE, when the library is loaded; the library keeps one bit per (kernel, device) to
- *     remember that the kernel's dynamic-LDS attribute has been raised on that device.
+ *     remember that the kernel's dynamic-LDS attribute has been raised on that device.  The full list of knobs: INTEGRATION.md 4.
+ *
+ * ABI history (mnerf_abi_version(); struct sizes from mnerf_struct_size()):
+ *   v6  mnerf_debug_set_knob returns the status and the previous value separately
+ *   v7  mnerf_rays gained pose_table / rays_per_pose (several target poses per launch; mnerf_render_takes_pose_table).
+ *       Added under v7 without a layout change: mnerf_debug_gemm, mnerf_window_attention_presplit_stats,
+ *       mnerf_window_attention_backward_stats.
  */
 #ifndef MNERF_H_
 #define MNERF_H_
