@@ -73,8 +73,10 @@ class Coach:
             if root and os.path.isdir(root) and kind in datasets.datas_dict:  # coach.py:52-69: the on-disk producer
                 extra = {k: cfg[k] for k in ("meta_dir", "pairs_file") if cfg.get(k)}  # where the scan / pair lists live
                 ds = datasets.datas_dict[kind](root, "test", n_views=self.n_src_views, img_wh=cfg.get("img_wh"),
-                                               max_len=cfg.get("max_len", -1),
-                                               test_views_method=cfg.get("test_views_method", "nearest"), **extra)
+                                               max_len=cfg.get("max_len", -1), scene_list=cfg.get("scene_list"),
+                                               test_views_method=cfg.get("test_views_method", "nearest"),
+                                               nf_mode=cfg.get("nf_mode", "avg"), eval_mode=cfg.get("eval_mode", "mvsnerf"),
+                                               n_add_train_views=cfg.get("n_add_train_views", 2), **extra)
                 loader = torch.utils.data.DataLoader(ds, shuffle=False, num_workers=cfg.get("num_workers", 0),
                                                      batch_size=self.opts.batch_size, pin_memory=True)
                 loader.get_name = ds.get_name

@@ -234,4 +234,7 @@ class MVSDatasetDTU(torch.utils.data.Dataset):
         return sample
 
 
-datas_dict = {"dtu": MVSDatasetDTU}  # datasets/__init__.py:9-16 (the other five producers are not rebuilt)
+from . import scene_sets as _ss  # noqa: E402  (the other five producers; they reach back into this module lazily)
+
+datas_dict = {"dtu": MVSDatasetDTU, "blender": _ss.MVSDatasetBlender, "llff": _ss.MVSDatasetRealFF, "colmap": _ss.MVSDatasetCOLMAP,
+              "ibrnet": _ss.MVSDatasetIBRNet, "tnt": _ss.MVSDatasetTNT}  # datasets/__init__.py:9-16

@@ -19,6 +19,8 @@ def load_golden(name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     if "meta_json" in d:
         d["meta"] = json.loads(bytes(d.pop("meta_json")).decode())
+    if "images_u8" in d and "images" not in d:  # decoded 8-bit photographs: float32 u8 / 255 is exactly what the loader yields
+        d["images"] = d["images_u8"].astype(np.float32) / np.float32(255.0)
     return d
 
 

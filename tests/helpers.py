@@ -7,8 +7,26 @@ from matchnerf_amd import synthetic as syn
 from oracle import matchnerf_oracle as O
 
 
+def effective_overrides(meta):
+    """The golden's dotted option overrides on top of what its yaml (meta['yaml'], default test.yaml) changes relative to
+    test.yaml — read from this repository's own option trees (pinned equal to the reference's by tests/golden/options.json)."""
+    ov = dict(meta["opt_overrides"])
+    name = meta.get("yaml", "test")
+    if name != "test":
+        from matchnerf_amd import options
+        opt = options.load_options(f"configs/{name}.yaml", verbose=False)
+        base = {"nerf.sample_intvs": opt.nerf.sample_intvs, "n_src_views": opt.n_src_views,
+                "decoder.density_maskfill": opt.decoder.density_maskfill, "decoder.raytrans_posenc": opt.decoder.raytrans_posenc,
+                "decoder.raytrans_act": opt.decoder.raytrans_act, "nerf.legacy_coord": opt.nerf.legacy_coord,
+                "nerf.wo_render_interval": opt.nerf.wo_render_interval, "nerf.depth.param": opt.nerf.depth.param,
+                "encoder.attn_splits_list": list(opt.encoder.attn_splits_list)}
+        base.update(ov)
+        ov = base
+    return ov
+
+
 def cfg_from_meta(meta):
-    ov = meta["opt_overrides"]
+    ov = effective_overrides(meta)
     return O.OracleConfig(
         sample_intvs=ov.get("nerf.sample_intvs", 128), n_src_views=ov.get("n_src_views", 3),
         density_maskfill=ov.get("decoder.density_maskfill", False),

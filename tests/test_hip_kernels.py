@@ -146,7 +146,7 @@ def test_window_attention_dtu_shape_matches_oracle(hip, math, monkeypatch):
         assert torch.isfinite(out).all() and linf(out, ref) < 2e-5 * float(ref.abs().max()), (h, w, "scaled")
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth", "demo_own_small", "demo_own"])
 def test_ray_geometry_is_bit_exact(hip, name):
     """world points and ref-view-0 NDC coordinates: identical bits to the reference CPU path."""
     g, cfg, sd, batch = golden_case(name)
@@ -172,7 +172,7 @@ def _case_on_gpu(name):
     return g, cfg, sd, batch, feats_gpu, img_gpu
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth", "demo_own_small", "demo_own"])
 def test_cost_volume_matches_reference(hip, name):
     g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu(name)
     sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
@@ -191,7 +191,7 @@ def test_cost_volume_matches_reference(hip, name):
 
 
 @pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth", "demo_own_small", "demo_own"])
 def test_decoder_chunk_matches_reference(hip, name, math):
     """All three matrix paths of the fused decoder (split-fp16 on the fp16 MFMA = the default, split-bf16 on the
     bf16 MFMA, exact-f32 MFMA) against the reference's own per-sample and per-ray outputs, same tolerances."""

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def build_model(meta, device="cuda"):
     from matchnerf_amd.models import models_dict
-    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt = options.load_options(f"configs/{meta.get('yaml', 'test')}.yaml", verbose=False)
     opt.device = device
     for k, v in meta["opt_overrides"].items():
         node = opt
@@ -33,7 +33,7 @@ def to_batch(g, device="cuda"):
     return EasyDict({k: torch.from_numpy(g[k]).to(device) for k in ("images", "extrinsics", "intrinsics", "near_fars")})
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "nonlegacy", "v4", "inverse_depth", "demo_own_small", "demo_own"])
 def test_forward_test_mode_matches_reference(name):
     g, cfg, sd, _ = golden_case(name)
     opt, model = build_model(g["meta"])
@@ -50,7 +50,7 @@ def test_forward_test_mode_matches_reference(name):
     assert mse < 1e-9 and d_psnr < 0.01  # north_star: PSNR delta < 0.01 dB
 
 
-@pytest.mark.parametrize("name", ["c1_default", "rect_wide"])
+@pytest.mark.parametrize("name", ["c1_default", "rect_wide", "demo_own"])
 def test_encoder_features_match_reference(name):
     from matchnerf_amd.gmflow import pair_major_to_view_chunks
     g, cfg, sd, _ = golden_case(name)
@@ -219,6 +219,25 @@ def test_video_mode_renders_each_pose():
         assert linf(out.rgb[i], ref["rgb"][0]) < 1e-4 and linf(out.opacity[i], ref["opacity"][0]) < 1e-4
         assert linf(out.depth[i], ref["depth"][0]) < 3e-4
     assert len({float(out.rgb[i].sum()) for i in range(6)}) == 6  # six different poses
+
+
+@pytest.mark.parametrize("name", ["demo_own_small", "demo_own"])
+def test_video_frames_of_the_real_scene_match_reference(name):
+    """configs/demo_own.yaml on the reference's own COLMAP scene: frames of the 24-pose 'interpolate' path rendered by
+    forward(render_video=True) against the REFERENCE's frames at those poses (same 1e-4 gate as the still image)."""
+    g, cfg, sd, _ = golden_case(name)
+    opt, model = build_model(g["meta"])
+    assert opt.nerf.video_n_frames == 24 and opt.nerf.sample_intvs == 128
+    batch = to_batch(g)
+    batch.c2ws_all = torch.from_numpy(g["c2ws_all"]).cuda()
+    with torch.no_grad():
+        out = model(batch, mode="test", render_video=True, render_path_mode="interpolate")
+    h, w = g["images"].shape[-2:]
+    assert out.rgb.shape == (24, h * w, 3)
+    for j, f in enumerate(g["video_frames"]):
+        assert linf(out.rgb[f], g["video_rgb"][j]) < 1e-4, (name, f)
+        assert linf(out.opacity[f], g["video_opacity"][j]) < 1e-4
+        assert linf(out.depth[f], g["video_depth"][j]) < 3e-4
 
 
 def test_batch_of_two_equals_two_batches_of_one():

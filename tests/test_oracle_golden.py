@@ -47,7 +47,7 @@ def test_full_forward_matches_reference(name):
     assert linf(out["depth"], g["depth"]) < 2e-5
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + ["demo_own_small"])
 def test_encoder_and_stages_match_reference(name):
     g, cfg, sd, batch = golden_case(name)
     v = cfg.n_src_views
@@ -69,6 +69,18 @@ def test_encoder_and_stages_match_reference(name):
     sel = g["stage_rays"]
     assert linf(st["rgb"], g["rgb"][0, sel]) < 1e-5
     assert linf(st["depth"], g["depth"][0, sel]) < 2e-5
+
+
+def test_video_path_on_real_poses_matches_reference():
+    """The reference's real COLMAP scene (docs/demo_data/printer): world->camera matrices of frames 1 and 13 of its 24-frame
+    'interpolate' path (matchnerf.py:295-323, camera.py:382-411) from rotations that are orthonormal only to fp32."""
+    from matchnerf_amd import video
+    g, cfg, _, batch = golden_case("demo_own_small")
+    sq = torch.eye(4).repeat(cfg.n_src_views, 1, 1)
+    sq[:, :3] = batch["extrinsics"][0, :-1, :3]
+    c2ws = sq.double().inverse()[:, :3].float().numpy()
+    w2c = torch.tensor(np.asarray(video.interpolate_render_path(c2ws, 24))).inverse()[:, :3].to(torch.float32).numpy()
+    assert np.array_equal(w2c[g["video_frames"]], g["video_w2c"])
 
 
 def test_backbone_matches_reference(golden):

@@ -17,6 +17,8 @@ Fixtures (all float32 unless noted):
   window_attn.npz   single_head_split_window_attention in/out, shifted and not, + full attention
   options.json      merged option trees of every shipped YAML + CLI-grammar cases
   video_paths.npz   interpolate / spiral render paths for fixed c2w inputs
+  demo_own.npz, demo_own_small.npz   the reference's real COLMAP scene (docs/demo_data/printer) through its own
+                    datasets/colmap.py and configs/demo_own.yaml, at 256x160 (as shipped) and 96x64, incl. video frames
 """
 import hashlib
 import json
@@ -61,11 +63,15 @@ def build_reference(opt_overrides, yaml_name="test", weight_seed=1):
     return opt, model, weights_digest(w)
 
 
-def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep_feats=True):
-    opt, model, digest = build_reference(opt_overrides)
+def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep_feats=True, scene=None, yaml_name="test",
+             extra=None, video_frames=None):
+    """scene: a ready batch (numpy, with the batch dimension) instead of syn.make_scene(**scene_kw);
+    video_frames: indices into the reference's own render path (forward(render_video=True)) to keep as `video_rgb`."""
+    opt, model, digest = build_reference(opt_overrides, yaml_name=yaml_name)
     model.nerf_setbg_opaque = setbg_opaque
     _, _, EasyDict = import_reference()
-    scene = syn.make_scene(**scene_kw)
+    if scene is None:
+        scene = syn.make_scene(**scene_kw)
     batch = EasyDict({k: torch.from_numpy(v) for k, v in scene.items()})
     cap = {}
 
@@ -111,10 +117,24 @@ def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep
         out = model(batch, mode="test")
     for h in hooks:
         h.remove()
+    video = None
+    if video_frames is not None:  # the reference's own path generator, thinned to the frames we keep
+        orig_path = model.get_video_rendering_path
+
+        def thin_path(*a, **k):
+            poses = orig_path(*a, **k)
+            cap["video_w2c"] = np.stack([poses[i]["extrinsics"][0].numpy() for i in video_frames])
+            return [poses[i] for i in video_frames]
+
+        model.get_video_rendering_path = thin_path
+        vb = EasyDict({k: torch.from_numpy(v) for k, v in scene.items()})
+        with torch.no_grad():
+            video = model(vb, mode="test", render_video=True,
+                          render_path_mode=(extra or {}).get("render_path_mode", "interpolate"))
 
     sel = np.asarray(stage_rays)
     data = dict(
-        images=scene["images"], extrinsics=scene["extrinsics"], intrinsics=scene["intrinsics"],
+        extrinsics=scene["extrinsics"], intrinsics=scene["intrinsics"],
         near_fars=scene["near_fars"],
         rgb=out.rgb.numpy(), depth=out.depth.numpy(), opacity=out.opacity.numpy(),
         stage_rays=sel.astype(np.int64),
@@ -123,13 +143,28 @@ def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep
         rgb_samples=cap["rgb_samples"][0, sel].numpy(), sigma=cap["sigma"][0, sel].numpy(),
         backbone=cap["backbone"].numpy(),
     )
+    u8 = np.round(scene["images"] * 255.0).astype(np.uint8)
+    if np.array_equal(u8.astype(np.float32) / np.float32(255.0), scene["images"]):
+        data["images_u8"] = u8  # 8-bit source (decoded photographs): conftest.load_golden rebuilds `images` = u8 / 255 exactly
+    else:
+        data["images"] = scene["images"]
+    if "c2ws_all" in scene:
+        data["c2ws_all"] = scene["c2ws_all"]
+    if video is not None:
+        data["video_frames"] = np.asarray(video_frames, np.int64)
+        data["video_w2c"] = cap["video_w2c"]
+        data["video_rgb"], data["video_depth"] = video.rgb.numpy(), video.depth.numpy()
+        data["video_opacity"] = video.opacity.numpy()
+    for k, v in (extra or {}).items():
+        if not isinstance(v, str):
+            data[k] = np.asarray(v)
     if keep_feats:
         for i, f in enumerate(cap["feats"]):
             data[f"feat_scale{i}"] = f[0].numpy()  # [V,(V-1)*128,h,w] reference layout
     else:  # keep a deterministic channel subset to bound fixture size
         for i, f in enumerate(cap["feats"]):
             data[f"feat_scale{i}_sub"] = f[0][:, ::16].numpy()
-    meta = dict(name=name, scene=scene_kw, opt_overrides=opt_overrides, weight_seed=1,
+    meta = dict(name=name, scene=scene_kw, opt_overrides=opt_overrides, weight_seed=1, yaml=yaml_name,
                 weights_sha256=digest, setbg_opaque=setbg_opaque,
                 torch=torch.__version__, numpy=np.__version__)
     data["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -197,6 +232,28 @@ def video_paths_case():
     print("[golden] video_paths", interp.shape, spiral.shape)
 
 
+def demo_own_case(name, img_wh, stage_rays, video_frames, rand_rays=None):
+    """The one real scene the reference ships: docs/demo_data/printer (3 photographs + LLFF-style poses_bounds.npy from COLMAP),
+    loaded by the reference's OWN datasets/colmap.py:51-173 with the dataset options of configs/demo_own.yaml:24-37 and rendered
+    by the reference model under that yaml (S = 128, density_maskfill, raytrans_posenc, ELU).  Real geometry: fx != fy after
+    the img_wh resize, rotations orthonormal only to fp32, per-view bounds merged by nf_mode 'minmax'."""
+    import_reference()
+    from datasets.colmap import MVSDatasetCOLMAP
+    opt = reference_options("demo_own")
+    cfg = opt.data_test.colmap
+    ds = MVSDatasetCOLMAP(cfg.root_dir, "test", n_views=opt.n_src_views, img_wh=list(img_wh), max_len=cfg.max_len,
+                          scene_list=cfg.scene_list, test_views_method=cfg.test_views_method, nf_mode=cfg.nf_mode)
+    assert len(ds) == 1
+    sample = ds[0]
+    scene = {k: np.asarray(sample[k], np.float32)[None] for k in ("images", "extrinsics", "intrinsics", "near_fars", "c2ws_all")}
+    extra = dict(view_ids=sample["view_ids"], img_wh=sample["img_wh"], render_path_mode=cfg.render_path_mode)
+    ov = {}
+    if rand_rays:
+        ov["nerf.rand_rays_test"] = rand_rays
+    run_case(name, dict(dataset="colmap", root="docs/demo_data", scene="printer", img_wh=list(img_wh)), ov, stage_rays,
+             keep_feats=False, scene=scene, yaml_name="demo_own", extra=extra, video_frames=video_frames)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -230,6 +287,10 @@ def main():
         run_case("inverse_depth", dict(height=32, width=32, n_src_views=3, seed=8),
                  {"nerf.sample_intvs": 32, "nerf.rand_rays_test": 1024, "nerf.depth.param": "inverse"},
                  stage_rays=list(range(0, 1024, 16)), keep_feats=False)
+    if want("demo_own_small"):  # 96x64: cheap enough for the CPU oracle tests; frames 1 and 13 of the 24-frame path
+        demo_own_case("demo_own_small", (96, 64), list(range(0, 2048, 32)), [1, 13], rand_rays=2048)
+    if want("demo_own"):  # configs/demo_own.yaml:33 as shipped: 256x160, 20 480-ray slices, S = 128
+        demo_own_case("demo_own", (256, 160), list(range(0, 20480, 320)), [5])
     if want("window_attn"):
         window_attention_case()
     if want("options"):

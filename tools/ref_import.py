@@ -23,6 +23,31 @@ def _stub(name, **attrs):
     return m
 
 
+class _Compose:
+    """Stand-in for torchvision.transforms.Compose (absent from this image): apply in order."""
+
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+class _ToTensor:
+    """Stand-in for torchvision.transforms.ToTensor on an 8-bit PIL image: HWC uint8 -> CHW float32 / 255 (its documented
+    behaviour).  The reference's dataset modules build `Compose([ToTensor()])` at construction (datasets/llff.py:95-98)."""
+
+    def __call__(self, img):
+        import numpy as np
+        import torch
+        a = np.asarray(img.convert("RGB") if img.mode != "RGB" and img.mode != "RGBA" else img, np.uint8)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255.0)
+
+
 def import_reference():
     """Returns the reference's (options, MatchNeRF, EasyDict) with cwd switched to REF_ROOT
     (its options.py opens 'configs/...' relatively, options.py:54,64)."""
@@ -40,7 +65,8 @@ def import_reference():
     sk.io = _stub("skvideo.io")
     _stub("cv2", COLORMAP_JET=2)
     tv = _stub("torchvision")
-    tv.transforms = _stub("torchvision.transforms")
+    tv.transforms = _stub("torchvision.transforms", Compose=_Compose, ToTensor=_ToTensor,
+                                Lambda=lambda fn: fn)
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     os.chdir(REF_ROOT)
