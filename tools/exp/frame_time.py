@@ -1,5 +1,5 @@
 """Frame / kernel times of one BASELINE configuration with whatever library and knobs the environment selects.
-usage: frame_time.py [c2|c3|c5] [frames]"""
+usage: frame_time.py [c2|c3|c5|s<N>|demo] [frames]     s<N>: config[1]'s frame at N samples per ray; demo: demo_own.yaml's shape"""
 import os
 import sys
 import time
@@ -20,6 +20,12 @@ if cfg == "c3":
 elif cfg == "c5":
     opt, model, _ = bench.build_model(dev, 10, 64)
     _, batch = bench.make_batch(dev, 0, 512, 640, 10, seed=32)
+elif cfg.startswith("s"):
+    opt, model, _ = bench.build_model(dev, 3, int(cfg[1:]))
+    _, batch = bench.make_batch(dev, 0)
+elif cfg == "demo":  # configs/demo_own.yaml: 256x160, S = 128, IBRNet-style decoder switches
+    opt, model, _ = bench.build_model(dev, 3, 128)
+    _, batch = bench.make_batch(dev, 0, 160, 256, 3, seed=33)
 else:
     opt, model, _ = bench.build_model(dev)
     _, batch = bench.make_batch(dev, 0)
