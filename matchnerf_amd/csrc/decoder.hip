@@ -1999,6 +1999,13 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #define PP_SYNC() PP_STAMPED(__syncthreads())
 #define PP_TSYNC() PP_STAMPED(wave_group_sync(team_ctr_lds, 4, team_epoch, lane0))
 #define PP_NOSYNC() PP_STAMPED((void)0)
+// MNERF_PP_DMA_VOFF (round 5, default 1): a stage's requests take ONE stream base (D.wstream) and add the piece's byte offset to the
+// per-lane offset in the vector ALU (glds16_sv) instead of ~200 distinct loop-invariant `stream + constant` pointers, which the
+// compiler hoisted out of the tile loop and parked in VGPR lanes (two v_readlane per request).  Bit-identical; same-box A/B
+// (gpurun_out/r5_3): 17.11 -> 16.99 ms per frame at S = 64, 36.9 -> 36.5 at S = 128.
+#ifndef MNERF_PP_DMA_VOFF
+#define MNERF_PP_DMA_VOFF 1
+#endif
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
 #ifdef MNERF_EXP_NO_DMA  // timing experiment (wrong results): what do the weight requests cost in total?
@@ -2006,12 +2013,24 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #endif
     unsigned voff = (unsigned)lane0 * 16u;
     asm volatile("" : "+v"(voff));
+#if MNERF_PP_DMA_VOFF
+    int twl = tw;  // opaque: the requests' offsets are computed where they are used (see stage_piece)
+    asm volatile("" : "+s"(twl));
+#else
+    const int twl = tw;
+#endif
     for (int i = 0; i < 2; ++i) {
-      const float* src = PP_SEG_SRC(s, i);
       const int pieces = i == 0 ? pp_p0(s, FS) : pp_p1(s);
       const unsigned base = PP_SLOT_LDS(s, i);
-      const int first = half == 2 ? tw : 2 * tw + half, step = half == 2 ? 4 : 8;
+      const int first = half == 2 ? twl : 2 * twl + half, step = half == 2 ? 4 : 8;
+#if MNERF_PP_DMA_VOFF
+      for (int p = first; p < pieces; p += step)
+        glds16_sv(D.wstream, voff, (unsigned)pp_seg_off_floats(s, i, FS) * 4u + (unsigned)p * 1024u,
+                  __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+#else
+      const float* src = PP_SEG_SRC(s, i);
       for (int p = first; p < pieces; p += step) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+#endif
     }
   };
   // ---- weight requests of a vector phase.  MNERF_PP_DMA_SPREAD = 0 (round 3): team A asks for its half of stage s (the odd

@@ -51,6 +51,26 @@ __device__ __forceinline__ void glds16_s(const float* uniform_src, unsigned lane
       : "memory");
 }
 
+// The same copy with ONE wave-uniform base for a whole stream and the piece's byte offset added to the per-lane offset in the
+// vector ALU (one v_add_u32 per request, offset in a scalar register or a literal): the ping-pong decoder's ~200 distinct
+// `stream + constant` source pointers are loop-invariant 64-bit values that the compiler hoists out of the tile loop and parks
+// in VGPR lanes (two v_readlane per request, ~120 spilled SGPRs); a 32-bit offset computed at the request is one scalar add.
+__device__ __forceinline__ void glds16_sv(const float* uniform_base, unsigned lane_off_bytes, unsigned piece_off_bytes,
+                                          unsigned lds_byte_addr) {
+  unsigned keep, vo;
+  asm volatile(
+      "v_add_u32 %1, %4, %2\n\t"
+      "s_nop 3\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&v"(vo)
+      : "v"(lane_off_bytes), "s"(uniform_base), "s"(piece_off_bytes), "s"(lds_byte_addr)
+      : "memory");
+}
+
 // glds16_s for data read exactly once (the conditioning rows): non-temporal, so that the stream does not push the weight
 // segments and the register-spill scratch out of L2 (ping-pong decoder, MI355X: FETCH_SIZE 462 -> 212 MB per 65 536-ray launch,
 // L2 misses 40 M -> 17 M, 18.27 -> 17.93 ms per frame; -DMNERF_ROWS_TEMPORAL restores the plain form).
