@@ -27,10 +27,14 @@ Also in the JSON line (N = 1):
                 (258,336 + 64 S per sample) / average launch duration measured with events on the launch
                 stream inside the timed region, against the ceiling of the matrix path IN USE (dense 16-bit
                 MFMA peak / products per MAC: 833 TFLOP/s for f16x3, 417 for bf16x6; 157.3 for the exact-f32
-                MFMA); next to it the same rate against the f32-MFMA peak that §8(d) declares binding in
-                parity mode and against the 2.5 PFLOP/s dense 16-bit peak, the measured MFMA-busy fraction and
-                HBM-side bytes per launch from the committed PMC passes (profiles/decoder_counters.json,
-                ignored when the kernel sources changed since), and the §8(d) rays/s form.
+                MFMA); next to it the same rate against the 2.5 PFLOP/s dense 16-bit peak, the measured MFMA-busy
+                fraction and HBM-side bytes per launch from the committed PMC passes (profiles/decoder_counters.json,
+                ignored when the kernel sources changed since).
+                roofline.cost_volume: the second kernel of the frame (32 %, no matrix instructions): busy fractions of
+                the units that bind it (texture-address unit / vector L1, vector ALU) from profiles/cost_volume_counters.json
+                (hash-guarded like the decoder's) and the same per-launch counts over THIS run's launch time.
+                roofline.frame: the step as a whole and its render kernels in rays/s against the matrix-path bound and
+                the vector-L1 tap bound (measured tap bytes per ray); every fraction in the line is <= 1.
   config        secondary workloads timed outside the timed region: BASELINE config[2] (Blender-like
                 800x800, 128 samples/ray) and config[4] (10 source views, 512x640).
   cpu_baseline  the CPU oracle (a port of the reference path, pinned to it by goldens) timed on this
@@ -60,25 +64,28 @@ PRODUCTS_PER_MAC = {"f16x3": 3, "bf16x6": 6, "f32": 1}
 # ceiling of each matrix path in ALGORITHMIC TFLOP/s: the pipe's dense peak / products per MAC
 PATH_CEILING_TFLOPS = {"f16x3": DENSE16_MFMA_PEAK_TFLOPS / 3, "bf16x6": DENSE16_MFMA_PEAK_TFLOPS / 6,
                        "f32": F32_MFMA_PEAK_TFLOPS}
-GATHER_BYTES_PER_SAMPLE = 24720  # §8(d): fp32 taps, no-reuse model, V = 3
+SHADER_CLOCK_HZ = 2.4e9          # ibid. ("256 CU x 2.4 GHz"); profiled passes run 1.9-2.0 GHz, so clock-based fractions are lower bounds
+L1_PEAK_BYTES = 64 * 256 * SHADER_CLOCK_HZ  # vector L1 -> registers: 64 B per clock and CU
 
 
 def flops_per_sample(s):
     return 258336 + 64 * s
 
 
-def measured_counters(kernel_prefix):
-    """PMC-derived figures of the decoder kernel from the committed rocprofv3 passes (bench.py cannot run the
-    profiler itself): HBM-side bytes per launch and MFMA-busy fraction — None when the file is missing or was
-    collected on other kernel sources than the ones in the tree (build hash)."""
-    from matchnerf_amd.csrc.build import source_hash
+def measured_counters(kernel_prefix, filename="decoder_counters.json", hash_name="source_hash"):
+    """PMC-derived figures of a kernel from the committed rocprofv3 passes (bench.py cannot run the profiler itself):
+    for the decoder HBM-side bytes per launch and the MFMA-busy fraction, for the cost volume its issue mix and the busy
+    fractions of the units that bind it — None when the file is missing, `stale` when it was collected on other kernel
+    sources than the ones in the tree (build hash)."""
+    from matchnerf_amd.csrc import build
+    now = getattr(build, hash_name)()
     try:
-        with open(os.path.join(REPO, "profiles", "decoder_counters.json")) as f:
+        with open(os.path.join(REPO, "profiles", filename)) as f:
             c = json.load(f)
     except Exception:  # noqa: BLE001
         return None
-    if c.get("build_hash") != source_hash() or not str(c.get("kernel", "")).startswith(kernel_prefix):
-        return dict(stale=True, build_hash_profiled=c.get("build_hash"), build_hash_now=source_hash())
+    if c.get("build_hash") != now or not str(c.get("kernel", "")).startswith(kernel_prefix):
+        return dict(stale=True, build_hash_profiled=c.get("build_hash"), build_hash_now=now)
     return c
 
 
@@ -178,19 +185,24 @@ def secondary_workload(device, name, n_views, n_samples, height, width, bg, **sc
             "decoder_ms": _per_frame(k, "decoder", 2), "fused_ray_chunk_ms": _per_frame(k, "render_fused", 2), "finite": ok}
 
 
-def train_step_workload(device):
-    """A `Coach.train_iteration`-shaped step (coach.py:215-243) at BASELINE config[1]'s geometry: mode='train' forward on
-    rand_rays_train = 1024 random rays of the 512x640 target, an L2 loss, backward through the HIP ray chunk
-    (mnerf_composite_backward -> mnerf_decoder_backward -> mnerf_cost_volume_backward) and the encoder (torch autograd over the
-    ROCm libraries), no optimizer step.  Outside the timed region; device events around the decoder's backward."""
+def train_step_workload(device, n_samples=S):
+    """A `Coach.train_iteration` (coach.py:215-243) at BASELINE config[1]'s geometry: zero_grad, mode='train' forward on
+    rand_rays_train = 1024 random rays of the 512x640 target with `n_samples` stratified samples per ray (configs/train.yaml
+    inherits sample_intvs 128 from base.yaml:48; 64 is the bench's inference count), an L2 loss, backward through the HIP ray
+    chunk (mnerf_composite_backward -> mnerf_decoder_backward -> mnerf_cost_volume_backward) and the encoder (HIP transformer
+    layers; the CNN's backward on the ROCm libraries), gradient clipping of the encoder and an Adam step — so the timed
+    iteration includes re-packing every weight stream the forward kernels read (packing.py).  Outside the bench's timed region;
+    device events around the decoder's backward."""
     import torch
     from matchnerf_amd import hip
-    opt, model, _ = build_model(device)
+    opt, model, _ = build_model(device, V, n_samples)
     model.train()
     opt.nerf.rand_rays_train = 1024
     opt.nerf.sample_stratified = True
     _, batch = make_batch(device, 0)
     params = [p for p in model.parameters() if p.requires_grad]
+    optim = torch.optim.AdamW([dict(params=model.feat_enc.parameters(), lr=1e-7), dict(params=model.nerf_dec.parameters(), lr=1e-7)],
+                              weight_decay=1e-4)  # configs/train.yaml: AdamW, weight_decay 1e-4 (tiny rates: the timing scene stays put)
     spans = []
     inner = hip.decoder_backward
 
@@ -203,19 +215,20 @@ def train_step_workload(device):
         return r
 
     def iteration():
-        for p in params:
-            p.grad = None
+        optim.zero_grad(set_to_none=True)
         out = model(batch, mode="train")
         gt = batch.images[:, -1].reshape(1, 3, -1).permute(0, 2, 1)[:, out.ray_idx]
         loss = ((out.rgb - gt) ** 2).mean()
         loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.feat_enc.parameters(), 1.0)
+        optim.step()
         return loss
 
     hip.decoder_backward = timed_backward
     try:
         torch.manual_seed(0)
         for _ in range(2):
-            iteration()  # warm-up: MIOpen immediate-mode solver pick (cudnn.benchmark is off: no exhaustive find), weight packing
+            iteration()  # warm-up: MIOpen immediate-mode solver pick (cudnn.benchmark is off: no exhaustive find), optimizer state
         spans.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -228,12 +241,14 @@ def train_step_workload(device):
         hip.decoder_backward = inner
     dec_ms = sum(a.elapsed_time(b) for a, b in spans) / max(len(spans), 1)
     grads_ok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
-    del model, batch
+    del model, batch, optim
     torch.cuda.empty_cache()
-    return {"workload": "train_iteration-shaped step: 1024 random rays x 64 stratified samples of a 512x640 target, 3 source views, "
-                        "forward + L2 loss + backward of encoder and decoder, no optimizer step",
-            "ms_per_iteration": round(ms, 3), "decoder_backward_ms": round(dec_ms, 3),
-            "decoder_backward": "mnerf_decoder_backward (HIP: exact-fp32 MFMA GEMMs + per-ray attention / LayerNorm kernel)",
+    return {"workload": f"train_iteration: 1024 random rays x {n_samples} stratified samples of a 512x640 target, 3 source views; "
+                        "zero_grad + forward + L2 loss + backward of encoder and decoder + encoder gradient clipping + Adam step "
+                        "(weight streams re-packed every iteration)",
+            "sample_intvs": n_samples, "ms_per_iteration": round(ms, 3), "decoder_backward_ms": round(dec_ms, 3),
+            "decoder_backward": "mnerf_decoder_backward (HIP: fp32-grade split-bf16 MFMA GEMMs by default, exact f32 with "
+                                "MNERF_GEMM_MATH=f32, + per-ray attention / LayerNorm kernel)",
             "loss": float(loss.detach()), "all_gradients_finite": grads_ok}
 
 
@@ -421,7 +436,8 @@ def main():
         guarded("BASELINE config[4]", secondary_workload, device,
                 "BASELINE config[4]: 10 source views 512x640, 64 samples/ray (45 view pairs, 1.18 GB of feature maps), "
                 "full frame incl. encoder", 10, 64, 512, 640, False, seed=32)
-        guarded("train_iteration-shaped step", train_step_workload, device)
+        guarded("train_iteration, sample_intvs 64", train_step_workload, device, 64)
+        guarded("train_iteration, sample_intvs 128 (configs/train.yaml)", train_step_workload, device, 128)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -440,8 +456,57 @@ def main():
         render_rate = n_rays / (render_ms * 1e-3)
         counters = measured_counters("decoder_") if math == decoder_math() else None
         fresh = bool(counters) and not counters.get("stale")
-        mfma_bound = F32_MFMA_PEAK_TFLOPS * 1e12 / (S * flops_per_sample(S))
-        gather_bound = HBM_PEAK_BYTES / (S * GATHER_BYTES_PER_SAMPLE)
+        # ---- the cost volume (no matrix instructions): what binds it, from the committed counter passes + the live launch time
+        cv_entry = None
+        cvc = measured_counters("cost_volume", "cost_volume_counters.json", "cost_volume_source_hash")
+        cv_fresh = bool(cvc) and not cvc.get("stale")
+        if not fused:
+            cvk = ksum["cost_volume"]
+            cv_secs = cvk["avg_ms"] * 1e-3
+            cv_entry = {
+                "kernel": "cost_volume_lean_kernel<8,false,false> (epipolar register-quad walk, group cosines, colours, masks; 0 MFMA)",
+                "bound": "vector-memory pipeline (texture-address unit / vector L1 -> registers) and vector ALU, co-bound",
+                "avg_launch_ms": round(cvk["avg_ms"], 4), "launch_rays": int(cvk["rays"] / cvk["launches"]),
+                "counters_source": cvc.get("source") if cv_fresh else
+                "profiles/cost_volume_counters.json is stale or absent: re-run tools/profile_round.sh",
+            }
+            if cv_fresh:
+                valu, l1b = cvc.get("valu_insts_per_launch"), cvc.get("l1_bytes_per_launch")
+                cv_entry.update({
+                    "ta_busy_frac_measured": cvc.get("ta_busy_frac"), "valu_busy_frac_measured": cvc.get("valu_busy_frac"),
+                    "what": "busy fractions from the profiled pass: TA_TA_BUSY_sum / (256 CUs x launch cycles), 4 x "
+                            "SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x launch cycles); the *_vs_clock forms divide the "
+                            "profiled per-launch counts by THIS run's launch time at the nominal 2.4 GHz",
+                    "valu_insts_per_launch": valu, "vmem_rd_insts_per_launch": cvc.get("vmem_rd_insts_per_launch"),
+                    "valu_issue_frac_vs_clock": round(4 * valu / (cv_secs * 1024 * SHADER_CLOCK_HZ), 4) if valu else None,
+                    "l1_bytes_per_launch": l1b,
+                    "l1_achieved_TBps": round(l1b / cv_secs / 1e12, 2) if l1b else None, "l1_peak_TBps": round(L1_PEAK_BYTES / 1e12, 2),
+                    "l1_frac_vs_clock": round(l1b / cv_secs / L1_PEAK_BYTES, 4) if l1b else None,
+                    "traffic": cvc.get("hbm_bytes_per_launch"),
+                    "traffic_algorithmic_bytes": int(cvk["rays"] / cvk["launches"] * S * 96),  # the rows it writes (the maps stay in cache)
+                })
+        # ---- the frame: rays/s against the bounds of the units the kernels actually run on
+        f_ray = S * flops_per_sample(S)
+        mfma_bound = PATH_CEILING_TFLOPS[math] * 1e12 / f_ray
+        frame_entry = {
+            "what": "rays/s of the timed step (full frame incl. encoder, per GPU) and of its render kernels alone against (i) the "
+                    "ceiling of the matrix path in use / FLOPs per ray (SURVEY.md 8d: S x (258336 + 64 S)) and (ii) the vector-L1 "
+                    "bound: 64 B/clk/CU x 256 CUs x 2.4 GHz / MEASURED tap bytes per ray of the cost volume (TCP accesses x 64 B, "
+                    "not the no-reuse model)",
+            "full_frame_rays_per_s_per_gpu": round(n_rays / (ms_per_step * 1e-3), 1),
+            "render_only_rays_per_s": round(render_rate, 1),
+            "flops_per_ray": f_ray, "mfma_path_bound_rays_per_s": round(mfma_bound, 1),
+            "render_only_frac_of_mfma_bound": round(render_rate / mfma_bound, 4),
+            "full_frame_frac_of_mfma_bound": round(n_rays / (ms_per_step * 1e-3) / mfma_bound, 4),
+        }
+        if cv_entry and cv_entry.get("l1_bytes_per_launch"):
+            tap_bytes_ray = cv_entry["l1_bytes_per_launch"] / cv_entry["launch_rays"]
+            l1_bound = L1_PEAK_BYTES / tap_bytes_ray
+            frame_entry.update({"cost_volume_l1_bytes_per_ray": int(tap_bytes_ray), "l1_tap_bound_rays_per_s": round(l1_bound, 1),
+                                "render_only_frac_of_l1_tap_bound": round(render_rate / l1_bound, 4),
+                                # the two stages are serial on the same CUs: time per ray at each stage's bound adds up
+                                "serial_bound_rays_per_s": round(1.0 / (1.0 / mfma_bound + 1.0 / l1_bound), 1),
+                                "render_only_frac_of_serial_bound": round(render_rate * (1.0 / mfma_bound + 1.0 / l1_bound), 4)})
         line = {
             "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -484,9 +549,6 @@ def main():
                         "of the matrix path the kernel runs on: dense 16-bit MFMA peak / products per MAC (f16x3: "
                         "2500/3 = 833, bf16x6: 2500/6 = 417) or the f32-MFMA peak 157.3 (f32)",
                 "math": math, "algorithmic_tflops": round(algorithmic, 2),
-                "frac_of_f32_mfma_peak": round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
-                "frac_of_f32_mfma_peak_what": "the same rate against the f32-MFMA peak that SURVEY.md 8d declares binding in "
-                                              "fp32 parity mode (secondary: the split paths do not run on that instruction)",
                 "frac_of_dense_16bit_peak": round(algorithmic / DENSE16_MFMA_PEAK_TFLOPS, 4),
                 "mfma_pipe_frac": round(issued_launch / secs / 1e12 / DENSE16_MFMA_PEAK_TFLOPS, 4) if math != "f32"
                 else round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
@@ -501,14 +563,8 @@ def main():
                                      counters is None or counters.get("stale") else None)),
                 "avg_launch_ms": round(dec["avg_ms"], 4), "flops_per_launch": flops_launch,
                 "issued_flops_per_launch": issued_launch,
-                "rays_form": {
-                    "what": "SURVEY.md 8d: render-only rays/s / min(MFMA_peak / F_ray, HBM_BW / B_ray), fp32 parity mode",
-                    "render_only_rays_per_s": round(render_rate, 1),
-                    "mfma_f32_bound_rays_per_s": round(mfma_bound, 1),
-                    "gather_hbm_no_reuse_bound_rays_per_s": round(gather_bound, 1),
-                    "frac_of_mfma_bound": round(render_rate / mfma_bound, 4),
-                    "frac_of_min_bound": round(render_rate / min(mfma_bound, gather_bound), 4),
-                },
+                "cost_volume": cv_entry,
+                "frame": frame_entry,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

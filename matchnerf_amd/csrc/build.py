@@ -59,6 +59,25 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+COST_VOLUME_SOURCES = ["cost_volume.hip", "cv_walk.hpp", "common.hpp"]  # what cost_volume_lean_kernel is compiled from
+
+
+def cost_volume_source_hash():
+    """The same for the stand-alone cost-volume kernel (profiles/cost_volume_counters.json)."""
+    import hashlib
+    import re
+    h = hashlib.sha256(" ".join(FLAGS + EXTRA_FLAGS.get("cost_volume.hip", [])).encode())
+    for name in sorted(COST_VOLUME_SOURCES):
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(PKG, "..", "include", "mnerf.h")) as f:
+        header = f.read()
+    for st in ("mnerf_view", "mnerf_rays", "mnerf_scene"):
+        m = re.search(r"typedef struct %s \{.*?\} %s;" % (st, st), header, re.S)
+        h.update(m.group(0).encode())
+    return h.hexdigest()[:16]
+
+
 def _compile(cmd):
     """Run one hipcc compile.  The x86 host pass of a .hip file prints "'-packed-fp32-ops' is not a recognized feature for this
     target (ignoring feature)" for NO_PACKED_F32 (clang has no device-only spelling for -Xclang options; the gfx950 pass honours

@@ -257,27 +257,65 @@ class TransformerLayer(nn.Module):
                                      nn.Linear(2 * d_model * ffn_dim_expansion, d_model, bias=False))
             self.norm2 = nn.LayerNorm(d_model)
 
-    def _packed_block(self, device):
-        """(wstream, ln, ews) of the post-attention chain for the K7 kernel; re-packed when a parameter changed"""
+    def _block_params(self):
         ps = [self.merge.weight, self.norm1.weight, self.norm1.bias]
         if not self.no_ffn:
             ps += [self.mlp[0].weight, self.mlp[2].weight, self.norm2.weight, self.norm2.bias]
-        key = (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(device))
+        return ps
+
+    def _qkv_params(self):
+        return [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
+
+    @staticmethod
+    def _pack_key(ps, device):
+        return (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(device))
+
+    def _block_weights(self):
+        return [self.merge.weight] + ([] if self.no_ffn else [self.mlp[0].weight, self.mlp[2].weight])
+
+    def _packed_block(self, device, ews=None):
+        """(wstream, ln, ews) of the post-attention chain for the K7 kernel; re-packed when a parameter changed.  Parameters on
+        a GPU are packed THERE (packing.py: a gather + the fp16 split as device ops; `ews`: the scale exponents if the caller
+        already fetched them — FeatureTransformer.refresh_packs does that for all layers with one device->host copy), host
+        parameters through the numpy packer."""
+        ps = self._block_params()
+        key = self._pack_key(ps, device)
         if getattr(self, "_blk", None) is None or self._blk[0] != key:
-            ws, ews = pack_encoder_block(self.merge.weight, None if self.no_ffn else self.mlp[0].weight,
-                                         None if self.no_ffn else self.mlp[2].weight)
+            w0, w2 = (None, None) if self.no_ffn else (self.mlp[0].weight, self.mlp[2].weight)
+            if self.merge.weight.is_cuda:
+                from . import packing
+                ws, ews = packing.pack_encoder_block(self.merge.weight, w0, w2, ews)
+                ws = ws.to(device)
+            else:
+                ws, ews = pack_encoder_block(self.merge.weight, w0, w2)
+                ws = torch.from_numpy(ws).to(device)
             n2 = (self.norm1 if self.no_ffn else self.norm2)
             ln = torch.stack([self.norm1.weight, self.norm1.bias, n2.weight, n2.bias], 0).detach().float().contiguous()
-            self._blk = (key, torch.from_numpy(ws).to(device), ln.to(device), ews)
+            self._blk = (key, ws, ln.to(device), ews)
         return self._blk[1:]
 
-    def _packed_qkv(self, device):
-        ps = [self.q_proj.weight, self.k_proj.weight, self.v_proj.weight]
-        key = (tuple(int(p._version) for p in ps), tuple(int(p.data_ptr()) for p in ps), str(device))
+    def _packed_qkv(self, device, ews=None):
+        ps = self._qkv_params()
+        key = self._pack_key(ps, device)
         if getattr(self, "_qkv", None) is None or self._qkv[0] != key:
-            ws, ews = pack_qkv(*ps)
-            self._qkv = (key, torch.from_numpy(ws).to(device), ews)
+            if ps[0].is_cuda:
+                from . import packing
+                ws, ews = packing.pack_qkv(*ps, ews=ews)
+                ws = ws.to(device)
+            else:
+                ws, ews = pack_qkv(*ps)
+                ws = torch.from_numpy(ws).to(device)
+            self._qkv = (key, ws, ews)
         return self._qkv[1:]
+
+    def stale_packs(self, device):
+        """which of ('qkv', 'block') would be re-packed by the next forward on `device`"""
+        out = []
+        if getattr(self, "_qkv", None) is None or self._qkv[0] != self._pack_key(self._qkv_params(), device):
+            out.append("qkv")
+        if getattr(self, "_blk", None) is None or self._blk[0] != self._pack_key(self._block_params(), device):
+            out.append("block")
+        return out
 
     _warned_eval_grad = False
 
@@ -346,9 +384,31 @@ class FeatureTransformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def refresh_packs(self, device):
+        """Re-pack the operand streams of ALL layers when any layer's parameters changed (an optimizer step bumps every one of
+        them): packing.TransformerPacker — one concatenation, one gather, the fp16 split, about ten launches and ONE
+        device->host copy (the kernels take each stream's power-of-two scale as an integer argument) for the whole
+        transformer.  Returns the number of streams re-packed (0: nothing was stale)."""
+        layers = [l for blk in self.layers for l in (blk.self_attn, blk.cross_attn_ffn)]
+        device = torch.device(device)
+        if not any(l.stale_packs(device) for l in layers) or any(p.device != device for l in layers for p in l._qkv_params()):
+            return 0
+        from . import packing
+        pk = getattr(self, "_packer", None)
+        if pk is None or pk.device != device or not pk.matches(self):
+            pk = self._packer = packing.TransformerPacker(self, device)
+        for layer, ((q_ws, q_ews), (b_ws, b_ews)) in zip(layers, pk.pack()):
+            layer._qkv = (layer._pack_key(layer._qkv_params(), device), q_ws, q_ews)
+            n2 = layer.norm1 if layer.no_ffn else layer.norm2
+            ln = torch.stack([layer.norm1.weight, layer.norm1.bias, n2.weight, n2.bias], 0).detach().float().contiguous()
+            layer._blk = (layer._pack_key(layer._block_params(), device), b_ws, ln, b_ews)
+        return 2 * len(layers)
+
     def forward(self, src, n_pairs, h, w, splits, wo_self_attn=False):
         """src [2P, h*w, C] (first P = pair member a, last P = member b) -> same shape."""
         assert src.shape[0] == 2 * n_pairs
+        if src.is_cuda:
+            self.refresh_packs(src.device)
         for i, blk in enumerate(self.layers):
             shifted = (i % 2 == 1) and splits > 1
             blk_in = src  # the cross attention's keys / values come from the block INPUT of the other pair member:

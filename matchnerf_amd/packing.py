@@ -1,0 +1,183 @@
+"""Device-side packing of the GMFlow transformer's weights into the split-fp16 MFMA operand streams — the training path's twin
+of the numpy packers in gmflow.py (`pack_qkv`, `pack_encoder_block`), bit-identical to them (tests/test_packing_cpu.py).
+
+Two forms: per stream (`pack_qkv`, `pack_encoder_block`: a handful of device ops per fragment) and, what training uses, the
+whole transformer in one go (`TransformerPacker`: ONE concatenation of all weights, ONE gather through an index built once, the
+fp16 split — about ten launches and one device->host copy per optimizer step for all 24 streams of the 12 layers).
+
+Why: the training forward of every transformer layer runs the inference kernels, which read host-packed weight streams cached
+on the parameters' `_version`.  After each `optimizer.step()` all 12 layers re-packed on the HOST: `.detach().cpu().numpy()` on
+every weight (a blocking device sync each), numpy fragment building for the [1024,256] / [128,1024] FFN weights, a pageable
+host->device copy — dozens of syncs per training step that the torch-Linear path did not have (advisor, round 4).  Here a
+stream is ONE gather of the weight (index tensor built once per layer shape and kept on the device), a power-of-two scale and
+the fp16 hi | lo split, all as device ops on the caller's stream; the only host round trip is the per-tensor scale exponent the
+kernels take as an integer argument, and `FeatureTransformer.refresh_packs` fetches the exponents of ALL stale layers with
+one device->host copy per step.
+
+A fragment stream [T, nmb, 2, 64, 8] fp16 (cond_nerf._fragments_h): element (t, m, part, lane, j) = hi | lo part of
+2^ew * W[32 m + lane % 32, cols[t, lane // 32, j]] (zero outside W, or where cols < 0)."""
+import numpy as np
+import torch
+
+from . import cond_nerf as CN
+
+_INDEX_CACHE = {}
+
+
+def fragment_index(n_out, n_in, cols, nmb, device):
+    """int64 [T, nmb, 64, 8] on `device`: positions in the zero-extended weight ext [(nmb*32) x (n_in+1)] (flattened) that the
+    fragment stream gathers — the addressing of cond_nerf._fragments_h, cached per (shape, cols, device)."""
+    cols = np.asarray(cols)
+    key = (int(n_out), int(n_in), int(nmb), cols.shape, cols.tobytes(), str(device))
+    if key not in _INDEX_CACHE:
+        c = np.where(cols < 0, n_in, cols)
+        lane = np.arange(64)
+        col = c[:, lane >> 5, :]                                                      # [T, 64, 8]
+        row = (lane & 31)[None, None, :, None] + 32 * np.arange(nmb)[None, :, None, None]
+        t_n = c.shape[0]
+        flat = np.broadcast_to(row, (t_n, nmb, 64, 8)) * (n_in + 1) + np.broadcast_to(col[:, None], (t_n, nmb, 64, 8))
+        _INDEX_CACHE[key] = torch.from_numpy(np.ascontiguousarray(flat)).to(device)
+    return _INDEX_CACHE[key]
+
+
+def exponent_of_absmax(m):
+    """cond_nerf.f16_weight_exponent for a host float: ew with max|w| * 2^ew in [2^13, 2^14); 0 for zero / non-finite."""
+    if m == 0.0 or not np.isfinite(m):
+        return 0
+    return int(CN.F16_TARGET_EXP - np.frexp(np.float32(m))[1])
+
+
+def weight_exponents(tensors):
+    """Scale exponents of several weight tensors with ONE device->host copy."""
+    if not tensors:
+        return []
+    amax = torch.stack([t.detach().abs().max() for t in tensors]).tolist()
+    return [exponent_of_absmax(float(m)) for m in amax]
+
+
+def fragments_h(weight, cols, nmb, ew):
+    """fp16 [T, nmb, 2, 64, 8] on weight's device; `ew` a host integer.  Same bits as cond_nerf._fragments_h."""
+    w = weight.detach().to(torch.float32)
+    n_out, n_in = w.shape
+    ext = w.new_zeros(nmb * 32, n_in + 1)
+    ext[:n_out, :n_in] = w * float(2.0 ** int(ew))  # exact (a power of two as a host scalar; torch.ldexp goes through pow() on the device)
+    g = ext.reshape(-1)[fragment_index(n_out, n_in, cols, nmb, w.device)]
+    hi = g.to(torch.float16)
+    lo = (g - hi.to(torch.float32)).to(torch.float16)
+    return torch.stack([hi, lo], 2)
+
+
+def _as_float_words(halfs):
+    return torch.cat([h.reshape(-1) for h in halfs]).view(torch.float32)
+
+
+_NATURAL = np.arange(128).reshape(8, 2, 8)
+
+
+def pack_qkv(wq, wk, wv, ews=None):
+    """gmflow.pack_qkv on the weights' device -> (wstream float32 words, (ew_q, ew_k, ew_v))."""
+    from .gmflow import K_ROW_ORDER
+    rows = torch.from_numpy(K_ROW_ORDER).to(wk.device)
+    ws = [wq.detach(), wk.detach()[rows], wv.detach()]
+    if ews is None:
+        ews = weight_exponents(ws)
+    return _as_float_words([fragments_h(w, _NATURAL, 4, e) for w, e in zip(ws, ews)]), tuple(int(e) for e in ews)
+
+
+def pack_encoder_block(merge_w, mlp0_w=None, mlp2_w=None, ews=None):
+    """gmflow.pack_encoder_block on the weights' device -> (wstream float32 words, (ew_merge, ew_w1, ew_w2))."""
+    from .gmflow import EB_CHUNK, EB_SEG_FLOATS
+    acc_order = CN._reg_cols16(4)
+    ffn = mlp0_w is not None
+    if ews is None:
+        e = weight_exponents([merge_w] + ([mlp0_w, mlp2_w] if ffn else []))
+        ews = (e[0], e[1], e[2]) if ffn else (e[0], 0, 0)
+    parts = [fragments_h(merge_w, _NATURAL, 4, ews[0])]
+    if ffn:
+        assert tuple(mlp0_w.shape) == (1024, 256) and tuple(mlp2_w.shape) == (128, 1024)
+        cols1 = np.concatenate([_NATURAL, 128 + acc_order], 0)
+        for c in range(1024 // EB_CHUNK):
+            parts.append(fragments_h(mlp0_w[EB_CHUNK * c:EB_CHUNK * (c + 1)], cols1, 4, ews[1]))
+            parts.append(fragments_h(mlp2_w[:, EB_CHUNK * c:EB_CHUNK * (c + 1)], acc_order, 4, ews[2]))
+    ws = _as_float_words(parts)
+    assert ws.numel() % EB_SEG_FLOATS == 0
+    return ws, tuple(int(e) for e in ews)
+
+
+class TransformerPacker:
+    """All operand streams of a gmflow.FeatureTransformer (12 layers: q|k|v streams + post-attention streams) from one gather.
+    The index (int32, ~3.1 M entries for the shipped 6-block transformer) maps every fragment element to its position in the
+    concatenation of the layers' scaled weight matrices (one trailing zero serves the padding); it depends on the layer shapes
+    only and is built once per device."""
+
+    def __init__(self, ft, device):
+        from .gmflow import EB_CHUNK, K_ROW_ORDER
+        self.device = torch.device(device)
+        self.layers = [l for blk in ft.layers for l in (blk.self_attn, blk.cross_attn_ffn)]
+        acc_order = CN._reg_cols16(4)
+        cols1 = np.concatenate([_NATURAL, 128 + acc_order], 0)
+        rows128 = np.arange(128)
+        self.tensors, self.spans, chunks, off, pos = [], [], [], 0, 0
+
+        def add_tensor(t):
+            nonlocal off
+            self.tensors.append(t)
+            base, off = off, off + t.numel()
+            return base
+
+        def frag(base, n_cols_total, rows, cols):
+            """[T * 4 units, 512] flat positions of one fragment: stream row r of block m <- weight row rows[32 m + r]"""
+            c = np.asarray(cols)
+            lane = np.arange(64)
+            col = c[:, lane >> 5, :]                                                     # [T, 64, 8]
+            row = rows[(lane & 31)[None, None, :, None] + 32 * np.arange(4)[None, :, None, None]]  # [1, 4, 64, 1]
+            flat = base + np.broadcast_to(row, (c.shape[0], 4, 64, 8)) * n_cols_total + np.broadcast_to(col[:, None], (c.shape[0], 4, 64, 8))
+            return flat.reshape(-1, 512)
+
+        for layer in self.layers:
+            start = pos
+            for i, w in enumerate(layer._qkv_params()):
+                chunks.append(frag(add_tensor(w), 128, K_ROW_ORDER if i == 1 else rows128, _NATURAL))
+                pos += chunks[-1].shape[0]
+            qkv_span = (start, pos)
+            start = pos
+            chunks.append(frag(add_tensor(layer.merge.weight), 128, rows128, _NATURAL))
+            pos += chunks[-1].shape[0]
+            if not layer.no_ffn:
+                b0, b2 = add_tensor(layer.mlp[0].weight), add_tensor(layer.mlp[2].weight)
+                assert tuple(layer.mlp[0].weight.shape) == (1024, 256) and tuple(layer.mlp[2].weight.shape) == (128, 1024)
+                for c in range(1024 // EB_CHUNK):
+                    chunks.append(frag(b0, 256, EB_CHUNK * c + rows128, cols1))
+                    chunks.append(frag(b2, 1024, rows128, EB_CHUNK * c + acc_order))
+                    pos += chunks[-2].shape[0] + chunks[-1].shape[0]
+            self.spans.append((qkv_span, (start, pos)))
+        idx = np.concatenate(chunks, 0)
+        assert idx.max() < off < 2 ** 31
+        self.index = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+        self.n_units = pos
+
+    def matches(self, ft):
+        layers = [l for blk in ft.layers for l in (blk.self_attn, blk.cross_attn_ffn)]
+        return len(layers) == len(self.layers) and all(a is b for a, b in zip(layers, self.layers))
+
+    def pack(self):
+        """-> per layer ((qkv stream, (ew_q, ew_k, ew_v)), (block stream, (ew_merge, ew_w1, ew_w2))); streams are float32-word
+        views of one fresh buffer.  One device->host copy (the exponents)."""
+        ts = [t.detach() for t in self.tensors]
+        ews = [exponent_of_absmax(float(m)) for m in torch.stack(torch._foreach_norm(ts, float("inf"))).tolist()]
+        scaled = torch._foreach_mul(ts, [float(2.0 ** e) for e in ews])
+        flat = torch.cat([t.reshape(-1) for t in scaled])
+        g = flat[self.index.long()]                                   # [units, 512]
+        hi = g.to(torch.float16)
+        lo = (g - hi.to(torch.float32)).to(torch.float16)
+        words = torch.stack([hi, lo], 1).reshape(-1).view(torch.float32)  # [units][hi | lo][512] halves = 512 words per unit
+        out, k = [], 0
+        for layer, (qs, bs) in zip(self.layers, self.spans):
+            e_qkv = tuple(ews[k:k + 3])
+            k += 3
+            if layer.no_ffn:
+                e_blk, k = (ews[k], 0, 0), k + 1
+            else:
+                e_blk, k = (ews[k], ews[k + 1], ews[k + 2]), k + 3
+            out.append(((words[qs[0] * 512:qs[1] * 512], e_qkv), (words[bs[0] * 512:bs[1] * 512], e_blk)))
+        return out

@@ -1,0 +1,73 @@
+"""Device-side weight packing (matchnerf_amd/packing.py) is the numpy packers' bit-for-bit twin — checked with torch CPU tensors
+(the same torch ops run on the GPU), plus the one-copy refresh of a whole transformer."""
+import numpy as np
+import pytest
+import torch
+
+from matchnerf_amd import cond_nerf as CN, gmflow, packing
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.7e-3, 260.0])
+def test_fragments_equal_the_numpy_builder(scale):
+    w = rnd((100, 77), 1, scale)
+    cols = np.arange(80).reshape(5, 2, 8)
+    cols = np.where(cols < 77, cols, -1)
+    ew = CN.f16_weight_exponent(w.numpy())
+    want = CN._fragments_h(w.numpy(), cols, 4, ew)
+    got = packing.fragments_h(w, cols, 4, ew)
+    assert got.dtype == torch.float16 and tuple(got.shape) == want.shape
+    assert np.array_equal(got.numpy().view(np.uint16), want.view(np.uint16))
+    assert packing.weight_exponents([w]) == [ew]
+
+
+def test_zero_and_nonfinite_exponents():
+    assert packing.weight_exponents([torch.zeros(4, 4), torch.full((2, 2), float("inf"))]) == [0, 0]
+    assert packing.weight_exponents([]) == []
+
+
+def test_qkv_stream_equals_numpy_packer():
+    wq, wk, wv = rnd((128, 128), 2, 0.09), rnd((128, 128), 3, 0.4), rnd((128, 128), 4, 2.0)
+    want, ews = gmflow.pack_qkv(wq, wk, wv)
+    got, ews_t = packing.pack_qkv(wq, wk, wv)
+    assert ews_t == ews and np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("ffn", [False, True])
+def test_encoder_block_stream_equals_numpy_packer(ffn):
+    m = rnd((128, 128), 5, 0.1)
+    w0, w2 = (rnd((1024, 256), 6, 0.05), rnd((128, 1024), 7, 0.03)) if ffn else (None, None)
+    want, ews = gmflow.pack_encoder_block(m, w0, w2)
+    got, ews_t = packing.pack_encoder_block(m, w0, w2)
+    assert ews_t == ews and np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_whole_transformer_in_one_gather_equals_the_per_layer_packers():
+    torch.manual_seed(11)
+    ft = gmflow.FeatureTransformer(num_layers=3)
+    with torch.no_grad():
+        for i, p in enumerate(ft.parameters()):
+            p.mul_(0.3 + 0.17 * i)  # different scale exponents per tensor
+    assert ft.refresh_packs("cpu") == 12
+    assert ft.refresh_packs("cpu") == 0
+    for blk in ft.layers:
+        for layer in (blk.self_attn, blk.cross_attn_ffn):
+            ws, ews = layer._qkv[1:]
+            want, ews_n = gmflow.pack_qkv(layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight)
+            assert ews == ews_n and np.array_equal(ws.numpy().view(np.uint32), want.view(np.uint32))
+            ws, ln, ews = layer._blk[1:]
+            want, ews_n = gmflow.pack_encoder_block(layer.merge.weight, None if layer.no_ffn else layer.mlp[0].weight,
+                                                    None if layer.no_ffn else layer.mlp[2].weight)
+            assert ews == ews_n and np.array_equal(ws.numpy().view(np.uint32), want.view(np.uint32))
+            assert layer.stale_packs(torch.device("cpu")) == []
+    layer = ft.layers[1].cross_attn_ffn
+    old = layer._qkv[2]
+    with torch.no_grad():
+        layer.q_proj.weight.mul_(2.0)   # what an optimizer step does to the version counter
+    assert layer.stale_packs(torch.device("cpu")) == ["qkv"]
+    assert ft.refresh_packs("cpu") == 12
+    assert layer._qkv[2][0] == old[0] - 1 and layer._qkv[2][1:] == old[1:]

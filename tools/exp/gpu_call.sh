@@ -1,0 +1,45 @@
+#!/bin/bash
+# One parameterised GPU call instead of a script per call (the round-4 r4_run*.sh notebook is in the history):
+#   gpurun -- 'bash tools/exp/gpu_call.sh TAG step [step ...]'      -> everything under gpurun_out/TAG/
+# steps:
+#   tests[=EXPR]        python -m pytest tests -m gpu -q [-k EXPR]            -> tests.log
+#   bench[=STEPS]       python bench.py --steps STEPS (default 10)            -> bench.json, key figures on stdout
+#   frames=C1,C2,..     tools/exp/frame_time.py per configuration (c2 c3 c5 s<N> demo); MNERF_LIB_VARIANTS="a b" runs every
+#                       configuration with libmnerf_hip.so and libmnerf_hip_<a>.so ... in turn (same-box A/B)  -> frames.log
+#   profile             tools/profile_round.sh TAG (kernel stats, bench trace, PMC passes, counter json files)
+#   py=SCRIPT[,ARG..]   python tools/exp/SCRIPT ARGS                           -> SCRIPT.log
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+for step in "$@"; do
+  name=${step%%=*}; arg=""; [[ $step == *=* ]] && arg=${step#*=}
+  case $name in
+    tests)
+      timeout 1800 python -m pytest tests -m gpu -q ${arg:+-k "$arg"} > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/tests.log
+      tail -4 $O/tests.log;;
+    bench)
+      timeout 900 python bench.py --steps ${arg:-10} --warmup 2 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+      python - "$O/bench.json" <<'PY'
+import json, sys
+l = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = l["roofline"]
+print("value", l["value"], "ms_per_step", l["ms_per_step"], "frac", r["frac"], "traffic", r.get("traffic"))
+print("cost_volume", json.dumps(r.get("cost_volume"))[:900])
+print("frame", json.dumps({k: v for k, v in r.get("frame", {}).items() if k != "what"}))
+for w in l["config"].get("secondary_workloads") or []:
+    print({k: w.get(k) for k in ("workload", "ms_per_frame", "encoder_ms", "cost_volume_ms", "decoder_ms", "ms_per_iteration", "sample_intvs", "error") if k in w})
+print("cpu_baseline", l.get("cpu_baseline", {}).get("value"))
+PY
+      ;;
+    frames)
+      for rep in 1 2; do for v in "" $MNERF_LIB_VARIANTS; do for c in ${arg//,/ }; do
+        MNERF_LIB=$PWD/matchnerf_amd/libmnerf_hip${v:+_$v}.so timeout 300 python tools/exp/frame_time.py $c 6 2>&1 | tail -1 | sed "s/^/[${v:-base}] /" | tee -a $O/frames.log
+      done; done; done;;
+    profile)
+      bash tools/profile_round.sh $TAG; ls $O;;
+    py)
+      IFS=, read -r script rest <<< "$arg"
+      timeout 900 python tools/exp/$script ${rest//,/ } 2>&1 | grep -v "amdgpu.ids" | tee $O/${script%.py}.log;;
+    *) echo "unknown step $step";;
+  esac
+done
