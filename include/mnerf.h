@@ -244,8 +244,10 @@ int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_rays* rays,
 /* Test / diagnosis hook: set one tuning knob after load (the lower-case name of its MNERF_* environment variable without the
  * prefix: "decoder_pp", "cv_variant", ...).  Returns MNERF_OK and the previous value through *old_value (may be NULL), or
  * MNERF_E_RANGE + a message for an unknown name (ABI v6: the status no longer shares the return value with the old value,
- * whose legitimate range includes -1).  Knobs are plain ints read by later launches; the hook is not a synchronisation
- * point for launches in flight on other threads. */
+ * whose legitimate range includes -1).  The table is the library's only mutable process-wide state besides the thread-local
+ * error string; this hook is its only writer.  Writes and the launches' reads are serialised by a lock and every launch works
+ * on a copy of the table, so a launch on another thread sees the value from before or after the call, never a torn table;
+ * kernels already enqueued are not affected. */
 int mnerf_debug_set_knob(const char* name, int value, int* old_value);
 
 /* K3+K4 backward — gradients of the conditional MLP + ray transformer (CondNeRF.forward, cond_nerf.py:52-100;

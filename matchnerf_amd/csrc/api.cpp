@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.hpp"
 
 static thread_local char g_err[512] = "";
@@ -60,12 +62,20 @@ static mnerf_tuning read_tuning() {
   return t;
 }
 
+// The table is read-only in production (filled from the environment at load).  The one writer is the test hook below; it and
+// every reader go through g_tuning_lock, and a reader takes a COPY: a launch on another thread sees the table before or after a
+// knob change, never a torn one (13 ints under an uncontended mutex per launch).
 static mnerf_tuning g_tuning = read_tuning();
-const mnerf_tuning& mnerf_tune() { return g_tuning; }
+static std::mutex g_tuning_lock;
+mnerf_tuning mnerf_tune() {
+  std::lock_guard<std::mutex> hold(g_tuning_lock);
+  return g_tuning;
+}
 
 // Test / diagnosis hook: change one knob of the table after load (what its environment variable would have set); the previous
-// value comes back through *old_value, the return value is only the status.  Not synchronised with launches on other threads.
+// value comes back through *old_value, the return value is only the status.  Serialised with the launches' reads (above).
 extern "C" int mnerf_debug_set_knob(const char* name, int value, int* old_value) {
+  std::lock_guard<std::mutex> hold(g_tuning_lock);
   struct Knob { const char* name; int* slot; };
   const Knob knobs[] = {{"decoder_pp", &g_tuning.decoder_pp}, {"decoder_pp_grid", &g_tuning.decoder_pp_grid},
                         {"decoder_pp_max_s", &g_tuning.decoder_pp_max_s}, {"decoder_grid", &g_tuning.decoder_grid},

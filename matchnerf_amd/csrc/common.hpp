@@ -45,7 +45,7 @@ struct mnerf_tuning {
   int decoder_pp_grid;  // MNERF_DECODER_PP_GRID (default 256): its persistent grid, one 8-wave workgroup per CU
   int decoder_pp_max_s; // MNERF_DECODER_PP_MAX_S (default 128, values above 128 are clamped): largest padded sample count per ray that takes the ping-pong form
 };
-const mnerf_tuning& mnerf_tune();
+mnerf_tuning mnerf_tune();  // a snapshot (api.cpp: copied under the table lock)
 // true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device
 bool mnerf_once_per_device(std::atomic<unsigned long long>& mask);
 // argument checks of the scene / rays structs (cost_volume.hip)

@@ -41,7 +41,7 @@ def _worker(rank, world, port, height, width, q):
         pass
     # view sharding (weak scaling): each rank owns whole frames
     v0, vn = mdist.shard_range(5, r, w)
-    frames = torch.cat([_fake_render(v * 7, 7) for v in range(v0, v0 + vn)], 0)
+    frames = torch.cat([_fake_render(v * 7, 7) for v in range(v0, v0 + vn)] + [torch.zeros(0, 5)], 0)  # a rank may own no view
     vcounts = [mdist.shard_range(5, i, w)[1] * 7 for i in range(w)]
     allf = mdist.gather_tiles(frames, vcounts)
     ok = ok and torch.equal(allf, torch.cat([_fake_render(v * 7, 7) for v in range(5)], 0))
@@ -64,6 +64,28 @@ def test_two_rank_gloo_shard_and_gather(height, width):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def test_eight_rank_gloo_shard_and_gather_of_the_dtu_frame():
+    """The first 8-GPU run should not also be the first 8-rank run of the host logic: BASELINE config[3]'s row sharding and tile
+    gather at world size 8 (512 rows -> 64 per rank; a 509-row frame for the ragged case), over gloo on the CPU."""
+    for height, width in ((512, 20), (509, 3)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 8, port, height, width, q)) for r in range(8)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted(q.get(timeout=120) for _ in procs)
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.terminate()
+        assert res == [(r, True) for r in range(8)]
+    spans = [mdist.shard_rows(512, 640, r, 8) for r in range(8)]
+    assert [n for _, n in spans] == [64 * 640] * 8 and [f for f, _ in spans] == [64 * 640 * r for r in range(8)]
 
 
 def test_shard_range_partitions_exactly():
