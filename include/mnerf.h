@@ -451,7 +451,9 @@ int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const
 
 /* Backward of a transformer layer around the window attention (what `loss.backward()` does to
  * models/gmflow/transformer.py:108-185 in coach.py:215-243; round 4).  Parameters in torch's layouts, gradients ACCUMULATED
- * into the g_* tensors (a NULL g_* skips that parameter).  Exact-fp32 matrix products (csrc/gemm_f32.hpp). */
+ * into the g_* tensors (a NULL g_* skips that parameter).  Matrix products with I, J >= 128 run fp32-grade in split-bf16 (three bf16 terms per operand,
+ * six products per MAC on the bf16 MFMA) by default, exact f32 (v_mfma_f32_32x32x2_f32) with MNERF_GEMM_MATH=f32 or for smaller products
+ * (csrc/gemm_f32.hpp). */
 typedef struct mnerf_encoder_layer_train {
   int32_t ffn;            /* 0: self-attention layer (merge + norm1 only), 1: + cat / mlp / norm2 */
   int32_t pad_;

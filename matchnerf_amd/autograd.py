@@ -1,17 +1,21 @@
-"""Autograd bridges for training through the HIP path (first step).
+"""Autograd bridges for training through the HIP path.
 
 The reference trains by back-propagating through its eager op chain
 (/root/reference/coach.py:215-243).  Here the FORWARD values of ``mode='train'`` come from
-the same HIP kernels as inference (K1-K6); the BACKWARD uses hand-written HIP
-kernels for the whole ray chunk (compositing, conditional MLP + ray transformer, cost volume) and for the window attention;
-where a backward kernel does not exist yet (the rest of the encoder: projections, K7 chain, convolutions) that op runs as
-differentiable PyTorch-ROCm ops on the GPU and back-propagates through them:
+the same HIP kernels as inference; the BACKWARD is hand-written HIP for the whole ray chunk and for the
+GMFlow transformer:
 
-* ``window_attention``  — K6 forward; backward = mnerf_window_attention_backward (flash style, no score tensor)
 * ``render_ray_chunk``  — K1..K5 forward in HIP; backward = K5 backward kernel (mnerf_composite_backward) ->
   K3+K4 backward (mnerf_decoder_backward: forward re-evaluated from the saved conditioning rows with sample coordinates
-  from mnerf_ray_samples — the forward's bits —, exact-fp32 MFMA products) -> K1+K2 backward kernel
-  (mnerf_cost_volume_backward, atomic scatter-add into the feature-map gradients)
+  from mnerf_ray_samples — the forward's bits; GEMMs fp32-grade in split-bf16 by default, exact fp32 with
+  MNERF_GEMM_MATH=f32) -> K1+K2 backward kernel (mnerf_cost_volume_backward, walking, atomic adds into the map gradients)
+* ``transformer_layer`` — a whole TransformerLayer (q|k|v projections, K6 window attention, K7 merge / LayerNorm / FFN /
+  residual) as ONE autograd node: inference kernels forward (their weight streams are re-packed on the device after an
+  optimizer step: packing.py), mnerf_encoder_layer_backward -> mnerf_window_attention_backward_stats -> mnerf_qkv_backward
+* ``window_attention``  — K6 alone with its flash-style HIP backward (no score tensor)
+
+What still back-propagates through PyTorch-ROCm library ops: the CNN backbone, the up-sampler and their InstanceNorms
+(convolution dgrad / wgrad on MIOpen) — gmflow.py's ``forward`` of those modules under autograd.
 
 This module is only entered when gradients are required; inference never touches it, and it
 is not a fallback: the forward pass still fails loudly without ``libmnerf_hip.so``.

@@ -8,7 +8,8 @@
 // Training chunks are small (rand_rays_train rays: 65 536 samples) and their activations fit HBM thousands of times over, so this
 // is not one fused tile kernel like the forward: the forward is re-evaluated layer by layer from the saved conditioning rows
 // with every pre-activation kept in a workspace (2 604 floats = 10.4 KB per sample), then walked backwards.  All matrix products — Y = X W^T,
-// dX = dY W, dW = dY^T X — run through ONE exact-fp32 MFMA GEMM (`gemm_f32_kernel`, v_mfma_f32_32x32x2_f32, 64x64 tiles staged in
+// dX = dY W, dW = dY^T X — run through ONE strided MFMA GEMM (gemm_f32.hpp: fp32-grade split-bf16 `gemm_b6_kernel` for products with I, J >= 128 by default,
+// the exact-fp32 `gemm_f32_kernel` with MNERF_GEMM_MATH=f32 and for the small ones; v_mfma_f32_32x32x2_f32, 64x64 tiles staged in
 // LDS, strided operands so that transposes / column slices / the row stride of the conditioning rows cost nothing, split-K with
 // float atomics for the weight gradients whose reduction runs over all samples).  What is not a matrix product is a handful
 // of elementwise kernels, and everything 16 wide — alpha activation, q|k|v, the S x S attention of a ray with its softmax,

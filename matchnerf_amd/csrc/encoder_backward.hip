@@ -8,7 +8,7 @@
 //
 // Like the decoder's backward (decoder_backward.hip) this is deliberately NOT one fused tile kernel: the chain is re-evaluated
 // from the layer's inputs with every pre-activation kept in a workspace (3 970 floats per token), then walked backwards.  Every
-// matrix product — Y = X W^T, dX = dY W, dW = dY^T X — is the exact-fp32 MFMA GEMM of gemm_f32.hpp (strided operands: the
+// matrix product — Y = X W^T, dX = dY W, dW = dY^T X — is the strided MFMA GEMM of gemm_f32.hpp (fp32-grade split-bf16 by default for I, J >= 128, exact fp32 with MNERF_GEMM_MATH=f32; strided operands: the
 // column halves of mlp.0's [1024, 256] weight cost nothing; split-K with float atomics for the weight gradients).  What is not a
 // matrix product: LayerNorm forward / backward (a half-wave per 128-feature row), exact-erf GELU and its derivative.
 // Parameters travel in torch's own layouts (mnerf_encoder_layer_train); parameter gradients are ACCUMULATED.

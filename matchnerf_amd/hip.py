@@ -437,17 +437,34 @@ _BWD_WS = {}
 
 
 def _grow_only_workspace(dev, n_floats, stream=None):
-    """The decoder backward's scratch (10.4 KB per sample: 0.7 GB for 1 024 rays x 64 samples) is kept per device and only ever
-    grown: one allocation per process instead of one torch.empty per chunk and batch element.  The kernels of a call are
-    enqueued on one stream in order and the next call's kernels follow them on that stream, so reuse needs no extra
-    synchronisation (a caller that alternates streams gets a fresh buffer per (device, stream))."""
+    """Scratch of the backward kernels, kept per (device, stream) and only ever grown: one allocation per process instead of one
+    torch.empty per chunk and batch element.  SHARED by mnerf_decoder_backward (10.4 KB per sample: 0.7 GB for 1 024 rays x 64
+    samples) and mnerf_encoder_layer_backward (about 0.5 GB at the DTU shape): the kernels of a call are enqueued on one stream
+    in order and the next call's kernels follow them on that stream, so reuse needs no extra synchronisation.
+    An explicit `stream` is not torch's current stream: the buffer is then allocated UNDER that stream and every use is recorded
+    on it (Tensor.record_stream), so a buffer dropped when the scratch grows is not handed to another stream's allocation while
+    kernels on `stream` still use it.  `release_workspaces()` frees the cache (it also goes with torch.cuda.empty_cache() once
+    released); MNERF_BWD_WS_CAP_MB caps what is KEPT between calls (a larger request is served by a one-off buffer)."""
     import torch
-    key = (torch.device(dev), (stream if stream is not None else torch.cuda.current_stream(dev)).cuda_stream)
+    cur = torch.cuda.current_stream(dev)
+    st = stream if stream is not None else cur
+    key = (torch.device(dev), st.cuda_stream)
     buf = _BWD_WS.get(key)
     if buf is None or buf.numel() < n_floats:
-        buf = torch.empty(n_floats, device=dev)
-        _BWD_WS[key] = buf
+        with torch.cuda.stream(st):
+            buf = torch.empty(n_floats, device=dev)
+        cap = float(os.environ.get("MNERF_BWD_WS_CAP_MB", "0") or 0)
+        if cap <= 0 or n_floats * 4 <= cap * 2 ** 20:
+            _BWD_WS[key] = buf
+    if st.cuda_stream != cur.cuda_stream:
+        buf.record_stream(st)
     return buf
+
+
+def release_workspaces():
+    """Drop the cached backward scratch buffers (they return to torch's caching allocator; torch.cuda.empty_cache() then
+    gives the memory back to the driver)."""
+    _BWD_WS.clear()
 
 
 def cost_volume(scene, rays, cond_stride, out=None, device=None, stream=None):

@@ -162,9 +162,15 @@ class MatchNeRF(torch.nn.Module):
         enc = self.feat_enc
         splits = tuple(attn_splits_list) if isinstance(attn_splits_list, (list, tuple)) else (attn_splits_list,)
         wkey = tuple((int(p._version), int(p.data_ptr())) for p in enc.parameters())
-        key = (tuple(imgs.shape), str(imgs.device), splits, bool(self.opts.encoder.wo_self_attn), hash(wkey))
+        # what the captured kernels depend on besides the input: the attention arithmetic (MNERF_WA_MATH picks other kernels) and
+        # the encoder's tuning knobs; a graph of other WEIGHTS is dead (its key can never match again): dropped, not kept
+        shape_key = (tuple(imgs.shape), str(imgs.device), splits, bool(self.opts.encoder.wo_self_attn), hip.wa_math(),
+                     os.environ.get("MNERF_WA_MIN4"), os.environ.get("MNERF_WA_XCD"))
+        key = shape_key + (hash(wkey),)
         entry = self._enc_graphs.get(key)
         if entry is None:
+            for stale in [k for k in self._enc_graphs if k[:-1] == shape_key]:
+                del self._enc_graphs[stale]
             run = lambda x: enc(imgs=x, attn_splits_list=attn_splits_list, wo_self_attn=self.opts.encoder.wo_self_attn)
             static_in = imgs.clone()
             run(static_in)  # eager warm-up: weight packing, LDS attributes, cached index / position tensors
