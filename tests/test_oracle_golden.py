@@ -83,6 +83,25 @@ def test_video_path_on_real_poses_matches_reference():
     assert np.array_equal(w2c[g["video_frames"]], g["video_w2c"])
 
 
+def test_float32_posenc_arguments_are_a_bounded_relaxation_of_the_float64_oracle(monkeypatch):
+    """advisor, round 4: the float64 oracle forms the non-legacy positional-encoding ARGUMENT in float32 (what the reference
+    and the kernels do).  Both forms exist; here the relaxation is measured: the arguments reach 2^9 pi ~ 1608 rad, rounding x
+    and the product to float32 costs up to 2 x 2^-24 of that = 1.9e-4 rad, so sin / cos move by < 2e-4 (observed 1.1e-4); float32
+    inputs do not see the switch."""
+    cfg = O.OracleConfig(legacy_coord=False)
+    g = torch.Generator().manual_seed(2)
+    x64 = torch.rand(4096, 3, generator=g, dtype=torch.float64)
+    aligned = O.posenc_3d(cfg, x64, 10)
+    monkeypatch.setattr(O, "POSENC_EXACT_ARGS", True)
+    exact = O.posenc_3d(cfg, x64, 10)
+    d = float((aligned - exact).abs().max())
+    assert 0 < d < 2e-4
+    x32 = x64.float()
+    a32 = O.posenc_3d(cfg, x32, 10)
+    monkeypatch.setattr(O, "POSENC_EXACT_ARGS", False)
+    assert torch.equal(a32, O.posenc_3d(cfg, x32, 10))
+
+
 def test_backbone_matches_reference(golden):
     g, cfg, sd, batch = golden_case("c1_default")
     x = (batch["images"][0, :3] - O._IMAGENET_MEAN) / O._IMAGENET_STD
