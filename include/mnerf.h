@@ -87,7 +87,7 @@ typedef struct mnerf_rays {
    * renders pixel g % rays_per_pose of pose g / rays_per_pose, and kinv / c2w / near_ / far_ above are ignored in favour
    * of row `pose` of the table: [kinv 9 | c2w 12 | near | far | pad] = MNERF_POSE_FLOATS fp32.  rays_per_pose must be a
    * multiple of 64 (so that a wavefront never straddles two poses); ray_idx and strat_u must be NULL.  Accepted by
-   * mnerf_cost_volume (<= 5 views), mnerf_decoder_chunk (split-fp16 stream, S <= 64, <= 5 views) and mnerf_render_chunk
+   * mnerf_cost_volume (<= 5 views), mnerf_decoder_chunk (split-fp16 stream, S <= 128, <= 5 views) and mnerf_render_chunk
    * (staged form) where mnerf_render_takes_pose_table() returns 1; MNERF_E_UNSUPPORTED everywhere else. */
   const float* pose_table;
   int32_t rays_per_pose;
@@ -218,7 +218,7 @@ int64_t mnerf_render_workspace_bytes(int32_t n_rays, int32_t n_samples, int32_t 
 int32_t mnerf_render_chunk_is_fused(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays);
 /* 1 if mnerf_render_chunk accepts a mnerf_rays.pose_table for this scene / decoder / sample count / frame size (rays_per_pose
  * = H*W): the kernel instances that take a table are the ones of the shipped shape (<= 5 source views, split-fp16 stream,
- * sample_intvs <= 64, H*W a multiple of 64).  A caller renders pose by pose otherwise. */
+ * sample_intvs <= 128, H*W a multiple of 64).  A caller renders pose by pose otherwise. */
 int32_t mnerf_render_takes_pose_table(const mnerf_scene* scene, const mnerf_decoder* dec, int32_t n_samples,
                                       int32_t rays_per_pose);
 int mnerf_render_chunk(const mnerf_scene* scene, const mnerf_decoder* dec, const mnerf_rays* rays,

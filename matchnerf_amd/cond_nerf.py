@@ -618,8 +618,13 @@ class CondNeRF(nn.Module):
         parameter changed (load_state_dict / optimizer step), S or MNERF_DECODER_MATH changed."""
         key = self._pack_key(n_samples)
         if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
-            sd = {"nerf_dec." + k: v for k, v in self.state_dict().items()}
             math = self.math_for(n_samples)
+            if math == "f16x3" and self.pts_bias.weight.is_cuda and self.pts_bias.weight.device == torch.device(device):
+                # parameters on the GPU (every training iteration re-packs after the optimizer step): the stream is assembled
+                # THERE, without a device->host copy (packing.DecoderPacker, bit-identical to pack_wstream_h)
+                self._packed = (key,) + self._packed_on_device(n_samples, torch.device(device)) + (WSTREAM_FORMATS[math],)
+                return self._packed[1], self._packed[2], self._packed[3], self._packed[4]
+            sd = {"nerf_dec." + k: v for k, v in self.state_dict().items()}
             ws, cond_dim, cond_stride = pack_for_math(math)(sd, self.opt.n_src_views, list(self.opt.encoder.cos_n_group),
                                                             self.L_3D, bool(self.opt.nerf.legacy_coord))
             assert cond_dim == self.cond_dim
@@ -632,6 +637,26 @@ class CondNeRF(nn.Module):
             self._packed = (key, torch.from_numpy(ws).to(device), torch.from_numpy(small).to(device), cond_stride,
                             WSTREAM_FORMATS[math])
         return self._packed[1], self._packed[2], self._packed[3], self._packed[4]
+
+    def _packed_on_device(self, n_samples, device):
+        from . import packing
+        legacy = bool(self.opt.nerf.legacy_coord)
+        pkey = (self.opt.n_src_views, tuple(self.opt.encoder.cos_n_group), self.L_3D, legacy, str(device))
+        if getattr(self, "_packer", None) is None or self._packer[0] != pkey:
+            self._packer = (pkey, packing.DecoderPacker(self, self.opt.n_src_views, list(self.opt.encoder.cos_n_group), self.L_3D,
+                                                        legacy, device), {})
+        _, pk, tables = self._packer
+        assert pk.cond_dim == self.cond_dim
+        if pk.cond_stride > 96:  # MNERF_COND_STRIDE_MAX
+            raise NotImplementedError(f"cond_dim={pk.cond_dim} (n_src_views={self.opt.n_src_views}) needs {pk.cond_stride} floats "
+                                      f"per sample; the f16x3 decoder stream supports 96")
+        ln = self.ray_attention.layer_norm
+        parts = [ln.weight.detach().float().reshape(-1), ln.bias.detach().float().reshape(-1)]
+        if bool(self.opt.decoder.raytrans_posenc):
+            if n_samples not in tables:
+                tables[n_samples] = torch.from_numpy(raytrans_table(n_samples).reshape(-1)).to(device)
+            parts.append(tables[n_samples])
+        return pk.pack(), torch.cat(parts), pk.cond_stride
 
     def decoder_struct(self, n_samples, device, setbg_opaque=False):
         """C-ABI ``mnerf_decoder`` for S samples per ray (the packed tensors stay cached on the module)."""

@@ -3032,13 +3032,15 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
                        opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
   } while (0)
 #define MNERF_LAUNCH_PP(SP_, FS_) MNERF_LAUNCH_PP_(SP_, FS_, false)
-    if (poses) {  // the instances that exist with a pose table: the shipped 3-view shape at S <= 64
-      MNERF_REQUIRE(fs == 2 && (Sp == 32 || Sp == 64), MNERF_E_UNSUPPORTED,
-                    "%s: pose tables are built for <= 5 source views and sample_intvs <= 64", who);
+    if (poses) {  // the instances that exist with a pose table: the shipped 3-view shape (<= 5 views) at S <= 128
+      MNERF_REQUIRE(fs == 2 && (Sp == 32 || Sp == 64 || Sp == 128), MNERF_E_UNSUPPORTED,
+                    "%s: pose tables are built for <= 5 source views and sample_intvs <= 128", who);
       if (Sp == 32)
         MNERF_LAUNCH_PP_(32, 2, true);
-      else
+      else if (Sp == 64)
         MNERF_LAUNCH_PP_(64, 2, true);
+      else  // round 5: configs/demo_own.yaml renders its video at the reference's default 128 samples per ray
+        MNERF_LAUNCH_PP_(128, 2, true);
     } else if (fs == 3)
       MNERF_LAUNCH_PP(64, 3);
     else if (fs == 4)
@@ -3055,7 +3057,7 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   }
 #endif
   MNERF_REQUIRE(!poses, MNERF_E_UNSUPPORTED, "%s: a pose table needs the ping-pong decoder (split-fp16 stream, <= 5 source views, "
-                "sample_intvs <= 64, MNERF_DECODER_PP on)", who);
+                "sample_intvs <= 128, MNERF_DECODER_PP on)", who);
 #if MNERF_DECODER_PART == 1
   MNERF_REQUIRE(fused_scene, MNERF_E_NULL, "%s: the one-launch form needs the scene", who);
 #define MNERF_LAUNCH_DECODER_FMT(NW_, SP_) MNERF_LAUNCH_DECODER(NW_, SP_, 2, 1)
@@ -3130,7 +3132,7 @@ bool mnerf_decoder_takes_pose_table(const mnerf_decoder* dec, int n_samples) {
   DecSched sch;
   if (build_schedule(dec, &sch) <= 0) return false;
   const int Sp = pick_padded_samples(n_samples);
-  return (Sp == 32 || Sp == 64) && pp_film_steps(dec, sch, Sp) == 2;
+  return (Sp == 32 || Sp == 64 || Sp == 128) && pp_film_steps(dec, sch, Sp) == 2;
 }
 
 extern "C" int mnerf_decoder_chunk(const mnerf_decoder* dec, const mnerf_view* view0,

@@ -30,6 +30,10 @@ from .gmflow import GMFlow, pair_major_to_view_chunks
 # ``nerf.rand_rays_{val,test}`` only bounds its temporaries (README.md:132); results are
 # chunk-invariant (tests/test_hip_kernels.py), so larger launches are used here.
 MAX_RAYS_PER_LAUNCH = int(os.environ.get("MNERF_MAX_RAYS_PER_LAUNCH", "65536"))
+# a pose-table launch (render_poses) may carry more: frames of a video are rendered back to back anyway, and with 288 GB of HBM
+# the conditioning hand-off of a quarter of a million rays (3 GB at 128 samples per ray) is no constraint.  What it buys is fewer,
+# fuller launches: configs/demo_own.yaml's 24 frames of 256 x 160 at S = 128 go out as 4 launches of 6 poses instead of 24 x 2.
+MAX_RAYS_PER_POSE_LAUNCH = int(os.environ.get("MNERF_MAX_RAYS_PER_POSE_LAUNCH", "262144"))
 # rays per autograd node when gradients are required (bounds the temporaries of the re-evaluated backward)
 GRAD_RAYS_PER_CALL = 8192
 
@@ -303,17 +307,17 @@ class MatchNeRF(torch.nn.Module):
 
     def render_poses(self, opt, poses, ref_poses=None, ref_images=None, ref_feats_list=None):
         """Full frames of SEVERAL target poses of one source set (the video loop of matchnerf.py:42-71) with as many poses per
-        launch as fit MAX_RAYS_PER_LAUNCH rays: the poses' camera constants travel as a table in HBM (mnerf_rays.pose_table,
+        launch as fit MAX_RAYS_PER_POSE_LAUNCH rays: the poses' camera constants travel as a table in HBM (mnerf_rays.pose_table,
         include/mnerf.h) instead of by value in the kernel arguments.  A 128 x 160 frame is 20 480 rays = 80 decoder tiles, a
         third of the 256 workgroups the decoder keeps resident; three poses per launch fill them.  Results are bit-identical
         to ``render`` pose by pose (tests/test_model_gpu.py).
         -> edict(rgb [n_poses,B,N,3], depth [n_poses,B,N,1], opacity [n_poses,B,N,1]) on the device, or None when a table does
-        not apply (one pose per launch already fills it, H*W not a multiple of 64, more than 5 source views, sample_intvs >
-        64, a non-default decoder form: ``hip.render_takes_pose_table``)."""
+        not apply (a single frame exceeds half a pose launch, H*W not a multiple of 64, more than 5 source views, sample_intvs >
+        128, a non-default decoder form: ``hip.render_takes_pose_table``)."""
         batch_size, _, _, img_h, img_w = ref_images.shape
         device = ref_images.device
         n_pix = img_h * img_w
-        per_launch = MAX_RAYS_PER_LAUNCH // n_pix
+        per_launch = MAX_RAYS_PER_POSE_LAUNCH // n_pix
         if per_launch < 2 or len(poses) < 2 or not ref_images.is_cuda or self.fused_render:
             return None
         n_samples = int(opt.nerf.sample_intvs)

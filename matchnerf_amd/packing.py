@@ -181,3 +181,119 @@ class TransformerPacker:
                 e_blk, k = (ews[k], ews[k + 1], ews[k + 2]), k + 3
             out.append(((words[qs[0] * 512:qs[1] * 512], e_qkv), (words[bs[0] * 512:bs[1] * 512], e_blk)))
         return out
+
+
+class DecoderPacker:
+    """The conditional-NeRF decoder's split-fp16 weight stream (cond_nerf.pack_wstream_h) assembled on the device, with NO
+    device->host copy at all: this stream carries its scale exponents in the stage headers (float [128] = 2^-ew, [129] = ew), so
+    they are computed where the weights are (frexp of the tensor's absmax).  Built once per decoder shape: index maps from the
+    numpy packer's own helpers, evaluated on position-valued stand-ins for the parameters (every fp32 word of the stream that is
+    not a fragment half is a plain copy of one parameter element: the bias headers and the resident tail segment)."""
+
+    def __init__(self, dec, n_views, cos_n_group, L_3D, legacy, device, prefix="nerf_dec."):
+        self.device = torch.device(device)
+        sd = {prefix + k: v for k, v in dec.state_dict().items()}
+        self.names = [k for k in sd if not k.endswith("num_batches_tracked")]
+        self.params = [dict(dec.named_parameters())[k[len(prefix):]] for k in self.names]
+        base, pos_sd = {}, {}
+        off = 0
+        for k, p in zip(self.names, self.params):
+            base[k] = off
+            pos_sd[k] = (off + 1 + np.arange(p.numel(), dtype=np.float64)).reshape(tuple(p.shape)).astype(np.float32)
+            off += p.numel()
+        assert off + 1 < 2 ** 24, "position-valued stand-ins must be exact in float32"
+        self.zero_pos = off  # flat = cat(params) + [0]
+
+        def to_pos(a):  # position + 1 (0 = padding) -> flat index
+            a = np.asarray(a).astype(np.int64)
+            return np.where(a == 0, self.zero_pos, a - 1)
+
+        cond_dim = int(sum(cos_n_group)) + 4 * n_views
+        self.cond_dim, self.cond_stride = cond_dim, ((cond_dim + 1 + 7) // 8) * 8
+        d_enc = 3 + 6 * L_3D
+        tf = (cond_dim + 15) // 16
+        film_cols = np.arange(16 * tf).reshape(tf, 2, 8)
+        film_cols = np.where(film_cols < cond_dim, film_cols, CN.ZERO)
+        e_cols, h_cols = CN._enc_cols16(L_3D, legacy), CN._reg_cols16(4)
+        dir_cols = np.full((1, 2, 8), CN.ZERO, np.int64)
+        dir_cols[0, 0, :3] = [128, 129, 130]
+        w5 = prefix + "pts_linears.5.weight"
+        # stage -> (weight tensor, first column of the slice, columns in the slice, bias tensor or None, cols, scale tensor)
+        stages = {"film": (prefix + "pts_bias.weight", 0, None, prefix + "pts_bias.bias", film_cols),
+                  "l0": (prefix + "pts_linears.0.weight", 0, None, prefix + "pts_linears.0.bias", e_cols),
+                  "l5e": (w5, 0, d_enc, prefix + "pts_linears.5.bias", e_cols),
+                  "l5h": (w5, d_enc, 128, None, h_cols),
+                  "feature": (prefix + "feature_linear.weight", 0, None, prefix + "feature_linear.bias", h_cols),
+                  "views": (prefix + "views_linears.0.weight", 0, None, prefix + "views_linears.0.bias", np.concatenate([h_cols, dir_cols], 0)),
+                  "rgb": (prefix + "rgb_linear.weight", 0, None, prefix + "rgb_linear.bias", CN._reg_cols16(2)),
+                  "alpha": (prefix + "alpha_linear.0.weight", 0, None, prefix + "alpha_linear.0.bias", h_cols)}
+        for i in range(1, 5):
+            stages[f"l{i}"] = (prefix + f"pts_linears.{i}.weight", 0, None, prefix + f"pts_linears.{i}.bias", h_cols)
+        segs, total = CN.decoder_schedule_h(cond_dim, L_3D)
+        self.total = total
+        tensor_id = {k: i for i, k in enumerate(self.names)}
+        frag_src, frag_dst, frag_tensor = [], [], []
+        word_src, word_dst, hdr_dst, hdr_tensor = [], [], [], []
+        frag_cache = {}
+        for name, first, steps, m, off_w, fl, hdr in segs:
+            if name == "tail":
+                continue
+            wname, c0, ncols, bname, cols = stages[name]
+            wt = pos_sd[wname]
+            n_out, n_in_total = wt.shape
+            n_in = n_in_total - c0 if ncols is None else ncols
+            if name not in frag_cache:
+                c = np.where(np.asarray(cols) < 0, -1, np.asarray(cols))
+                lane = np.arange(64)
+                col = c[:, lane >> 5, :]                                                       # [T, 64, 8]
+                row = (lane & 31)[None, None, :, None] + 32 * np.arange(m)[None, :, None, None]  # [1, m, 64, 1]
+                t_n = c.shape[0]
+                colb = np.broadcast_to(col[:, None], (t_n, m, 64, 8))
+                rowb = np.broadcast_to(row, (t_n, m, 64, 8))
+                valid = (rowb < n_out) & (colb >= 0) & (colb < n_in)
+                flat = base[wname] + rowb * n_in_total + c0 + np.where(valid, colb, 0)
+                frag_cache[name] = np.where(valid, flat, self.zero_pos).reshape(t_n * m, 512)
+            if hdr:
+                b = np.zeros(0, np.float32) if bname is None else pos_sd[bname]
+                word_src.append(to_pos(CN._bias_fragment(b if bname is not None else None, m)[:128]))
+                word_dst.append(off_w + np.arange(128))
+                hdr_dst.append(off_w + 128)
+                hdr_tensor.append(tensor_id[wname])
+                off_w += CN.FRAG_FLOATS
+            units = frag_cache[name][first * m:(first + steps) * m]
+            frag_src.append(units)
+            frag_dst.append(off_w + 512 * np.arange(units.shape[0])[:, None] + np.arange(512)[None, :])
+            frag_tensor.append(np.full(units.shape[0], tensor_id[wname]))
+        # the resident tail segment: plain fp32 copies, taken from the fp32-format packer run on the stand-ins
+        tail_words = ((CN.TAIL_FLOATS + 255) // 256) * 256
+        f32_stream = CN.pack_wstream(pos_sd, n_views, cos_n_group, L_3D, legacy, prefix)[0]
+        word_src.append(to_pos(f32_stream[-tail_words:]))
+        word_dst.append(segs[-1][4] + np.arange(tail_words))
+        assert segs[-1][0] == "tail"
+        dev = self.device
+        self.frag_src = torch.from_numpy(np.concatenate(frag_src, 0).astype(np.int64)).to(dev)
+        self.frag_dst = torch.from_numpy(np.concatenate(frag_dst, 0).astype(np.int64)).to(dev)
+        self.frag_tensor = torch.from_numpy(np.concatenate(frag_tensor).astype(np.int64)).to(dev)
+        self.word_src = torch.from_numpy(np.concatenate(word_src).astype(np.int64)).to(dev)
+        self.word_dst = torch.from_numpy(np.concatenate(word_dst).astype(np.int64)).to(dev)
+        self.hdr_dst = torch.tensor(hdr_dst, dtype=torch.int64, device=dev)
+        self.hdr_tensor = torch.tensor(hdr_tensor, dtype=torch.int64, device=dev)
+
+    def pack(self):
+        """-> wstream (float32 words [total]) on the parameters' device; same bits as cond_nerf.pack_wstream_h."""
+        ts = [p.detach().to(torch.float32) for p in self.params]
+        amax = torch.stack(torch._foreach_norm(ts, float("inf")))
+        _, e = torch.frexp(amax)
+        ew = torch.where((amax == 0) | ~torch.isfinite(amax), torch.zeros_like(e), CN.F16_TARGET_EXP - e).to(torch.int32)
+        scale = ((ew + 127) << 23).view(torch.float32)          # 2^ew, exact
+        inv = ((127 - ew) << 23).view(torch.float32)            # 2^-ew
+        flat = torch.cat([t.reshape(-1) for t in ts] + [amax.new_zeros(1)])
+        g = flat[self.frag_src] * scale[self.frag_tensor][:, None]
+        hi = g.to(torch.float16)
+        lo = (g - hi.to(torch.float32)).to(torch.float16)
+        out = flat.new_zeros(self.total)
+        out[self.frag_dst.reshape(-1)] = torch.stack([hi, lo], 1).reshape(-1).view(torch.float32)
+        out[self.word_dst] = flat[self.word_src]
+        out[self.hdr_dst] = inv[self.hdr_tensor]
+        out[self.hdr_dst + 1] = ew[self.hdr_tensor].to(torch.float32)
+        return out

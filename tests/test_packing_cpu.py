@@ -71,3 +71,25 @@ def test_whole_transformer_in_one_gather_equals_the_per_layer_packers():
     assert layer.stale_packs(torch.device("cpu")) == ["qkv"]
     assert ft.refresh_packs("cpu") == 12
     assert layer._qkv[2][0] == old[0] - 1 and layer._qkv[2][1:] == old[1:]
+
+
+@pytest.mark.parametrize("legacy,n_views,posenc", [(True, 3, False), (False, 3, True), (True, 5, False)])
+def test_decoder_stream_assembled_with_torch_ops_equals_the_numpy_packer(legacy, n_views, posenc):
+    """packing.DecoderPacker (what a GPU-resident decoder uses after every optimizer step: no host copy, exponents from frexp
+    on the device) against cond_nerf.pack_wstream_h, incl. an all-zero tensor (exponent 0) and the small block."""
+    from matchnerf_amd import options
+    opt = options.load_options("configs/test.yaml", verbose=False)
+    opt.device = "cpu"
+    opt.nerf.legacy_coord, opt.n_src_views, opt.decoder.raytrans_posenc = legacy, n_views, posenc
+    dec = CN.CondNeRF(opt)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        for i, p in enumerate(dec.parameters()):
+            p.copy_(torch.randn_like(p) * (0.02 + 0.3 * (i % 5)))
+        dec.feature_linear.bias.zero_()
+        dec.pts_linears[2].weight.zero_()
+    sd = {"nerf_dec." + k: v for k, v in dec.state_dict().items()}
+    want, cond_dim, cond_stride = CN.pack_wstream_h(sd, n_views, list(opt.encoder.cos_n_group), dec.L_3D, legacy)
+    ws, small, cs = dec._packed_on_device(64, torch.device("cpu"))
+    assert cs == cond_stride and np.array_equal(ws.numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(small.numpy(), CN.pack_small(sd, 64, posenc))

@@ -54,7 +54,7 @@ def test_ragged_last_group_and_nonzero_first_pose(monkeypatch):
     batch = to_batch(g)
     h, w = g["images"].shape[-2:]
     one = video(model, batch, False, 9)
-    monkeypatch.setattr(mn, "MAX_RAYS_PER_LAUNCH", 4 * h * w + 100)
+    monkeypatch.setattr(mn, "MAX_RAYS_PER_POSE_LAUNCH", 4 * h * w + 100)
     tab = video(model, batch, True, 9)
     assert same_bits(one, tab)
 
@@ -104,7 +104,8 @@ def test_c_abi_refuses_what_a_table_cannot_do():
         dec = model._decoder(S, ref_images.device)
     assert hip.render_takes_pose_table(sc, dec, S, h * w)
     assert not hip.render_takes_pose_table(sc, dec, S, h * w + 1)  # frames must be whole wavefronts
-    assert not hip.render_takes_pose_table(sc, dec, 128, h * w)    # S <= 64
+    assert hip.render_takes_pose_table(sc, dec, 128, h * w)        # round 5: the S = 128 instance (configs/demo_own.yaml)
+    assert not hip.render_takes_pose_table(sc, dec, 129, h * w)    # S <= 128
     ex, it, nf = model._tgt_host(tgt)
     kinv, c2w = camera.target_ray_consts(ex[0], it[0], True)
     table = torch.from_numpy(hip.pose_table_rows([(kinv, c2w, nf[0, 0], nf[0, 1])] * 2)).cuda()
@@ -146,3 +147,25 @@ def test_small_frame_video_at_the_size_the_table_is_for():
     tab = video(model, batch, True, 9)
     assert same_bits(one, tab)
     assert torch.isfinite(tab["rgb"]).all() and float(tab["opacity"].min()) >= 0.0
+
+
+def test_demo_own_video_goes_through_the_pose_table():
+    """configs/demo_own.yaml on the reference's own scene: 24 frames of 256 x 160 at 128 samples per ray (40 960 rays per frame)
+    leave as 4 launches of 6 poses (decoder_pp_kernel<128, 2, true>), bit-identical to pose by pose; frame 5 is the reference
+    model's frame within the 1e-4 gate (tests/golden/demo_own.npz)."""
+    from helpers import linf
+    g, *_ = golden_case("demo_own")
+    opt, model = build_model(g["meta"])
+    batch = to_batch(g)
+    one = video(model, batch, False, 24)
+    calls = []
+    orig = hip.render_chunk
+    try:
+        hip.render_chunk = lambda sc, dec, rays, *a, **k: (calls.append((rays.n_rays, rays.rays_per_pose)), orig(sc, dec, rays, *a, **k))[1]
+        tab = video(model, batch, True, 24)
+    finally:
+        hip.render_chunk = orig
+    assert calls == [(6 * 40960, 40960)] * 4
+    assert same_bits(one, tab)
+    f = int(g["video_frames"][0])
+    assert linf(tab["rgb"][f], g["video_rgb"][0]) < 1e-4 and linf(tab["opacity"][f], g["video_opacity"][0]) < 1e-4

@@ -1,5 +1,5 @@
 """Video of a small frame (the reference's render_video loop, models/matchnerf.py:42-71): poses per launch through the pose
-table (mnerf_rays.pose_table) against one pose per launch.  usage: video_time.py [H W] [n_poses] [reps]"""
+table (mnerf_rays.pose_table) against one pose per launch.  usage: video_time.py [H W] [n_poses] [reps] [sample_intvs]     (VT_MAX_RAYS: rays per pose-table launch)"""
 import os
 import sys
 import time
@@ -16,8 +16,8 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 dev = torch.device("cuda:0")
 if os.environ.get("VT_MAX_RAYS"):  # experiment: launch size (e.g. two 512 x 640 poses in one launch)
     import matchnerf_amd.matchnerf as mn
-    mn.MAX_RAYS_PER_LAUNCH = int(os.environ["VT_MAX_RAYS"])
-opt, model, _ = bench.build_model(dev)
+    mn.MAX_RAYS_PER_POSE_LAUNCH = int(os.environ["VT_MAX_RAYS"])
+opt, model, _ = bench.build_model(dev, 3, int(sys.argv[5]) if len(sys.argv) > 5 else 64)
 opt.nerf.video_n_frames = n_poses
 _, batch = bench.make_batch(dev, 0, h, w, seed=41)
 res = {}
