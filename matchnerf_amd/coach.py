@@ -86,15 +86,20 @@ class Coach:
 
     @torch.no_grad()
     def test_model(self, save_images=False, **kwargs):
-        """coach.py:368-453 -> {dataset: {image_id: psnr}}; the results file also lists SSIM (LPIPS needs weights we do not have)."""
+        """coach.py:368-453 -> {dataset: {image_id: psnr}}; the results file also lists SSIM and, when the two weight files of the
+        `lpips` package are on disk (metrics.load_lpips: $MNERF_LPIPS_VGG16 / $MNERF_LPIPS_LIN or torch hub's cache), LPIPS."""
         self.model.eval()
+        try:
+            lpips_fn = metrics.load_lpips(device=self.opts.device)
+        except FileNotFoundError:
+            lpips_fn = None
         out_root = os.path.join(self.opts.output_path, "test")
         os.makedirs(out_root, exist_ok=True)
         report = {}
         for loader in self.test_loaders:
             name = loader.get_name()
             report[name] = {}
-            ssims = []
+            ssims, lpipss = [], []
             self.model.nerf_setbg_opaque = (name == "blender")  # coach.py:382-383
             for bi, batch in enumerate(loader):
                 var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
@@ -106,9 +111,11 @@ class Coach:
                 for i in range(b):
                     mask = None if gt_depth is None else (gt_depth[i].cpu().numpy() == 0)
                     report[name][f"{name}_{bi:03d}_{i}"] = metrics.psnr(pred[i], gt[i], mask)
-                    tools = metrics.EvalTools()
+                    tools = metrics.EvalTools(lpips_fn=lpips_fn)
                     tools.set_inputs(pred[i], gt[i], mask)
-                    ssims.append(tools.get_metrics(["SSIM"])["SSIM"])
+                    got = tools.get_metrics(["SSIM"] + (["LPIPS"] if lpips_fn else []))
+                    ssims.append(got["SSIM"])
+                    lpipss.append(got.get("LPIPS"))
                     if save_images:
                         from PIL import Image
                         vis = np.concatenate([pred[i], gt[i]], 1)
@@ -117,9 +124,10 @@ class Coach:
             self.model.nerf_setbg_opaque = False
             vals = list(report[name].values())
             with open(os.path.join(out_root, f"0results_{name}.txt"), "w") as f:
-                for (k, v), sv in zip(report[name].items(), ssims):
-                    f.write(f"{k}: PSNR {v:.4f} SSIM {sv:.4f}\n")
-                f.write(f"mean PSNR {np.mean(vals):.4f} SSIM {np.mean(ssims):.4f}\n")
+                for (k, v), sv, lv in zip(report[name].items(), ssims, lpipss):
+                    f.write(f"{k}: PSNR {v:.4f} SSIM {sv:.4f}" + (f" LPIPS {lv:.4f}" if lv is not None else "") + "\n")
+                f.write(f"mean PSNR {np.mean(vals):.4f} SSIM {np.mean(ssims):.4f}" +
+                        (f" LPIPS {np.mean(lpipss):.4f}" if lpips_fn else "") + "\n")
             print(f"[coach] {name}: mean PSNR {np.mean(vals):.2f} over {len(vals)} images")
         return report
 

@@ -3,8 +3,12 @@ ground-truth depth != 0) or, without a mask, over the 80 % centre crop; SSIM as 
 `structural_similarity(pred, gt, channel_axis=-1)` (the version requirements.txt pins) — restated here because scikit-image is
 not part of this image: 7x7 uniform window, sample covariance, K1 = 0.01, K2 = 0.03 and, for FLOAT images with no
 `data_range` given, data_range = 2 (that version takes the dtype's nominal range [-1, 1]; the reference passes none).
-LPIPS needs the `lpips` package and its pretrained VGG weights, neither available offline: `EvalTools` takes it as an optional
-callable.  PARITY: PSNR is checked against the reference's formula; the SSIM restatement against a direct per-window evaluation of the
+LPIPS: the reference calls `lpips.LPIPS(net='vgg')` (misc/metrics.py:16,48-52).  Neither the `lpips` package nor the two weight
+files it downloads (torchvision's ImageNet VGG-16 and the learned linear heads, `vgg.pth` of lpips v0.1) are available offline, so
+`LPIPSVGG` below restates the published network (Zhang et al. 2018, lpips v0.1 'vgg' variant) and loads those two files from
+where the user put them (`load_lpips`); PARITY UNPINNED — without the weights there is no number to compare, the tests check the
+structure against an independent functional evaluation with the files' key names and shapes.  `EvalTools` takes any callable.
+PARITY (rest): PSNR is checked against the reference's formula; the SSIM restatement against a direct per-window evaluation of the
 published definition and against hand-derived closed-form vectors (tests/golden/ssim_hand_derived.json, generator
 tools/gen_ssim_golden.py; tests/test_datasets.py) — not against scikit-image itself, which this image does not have."""
 from collections import OrderedDict
@@ -92,3 +96,83 @@ class EvalTools:
             if return_full:
                 out[f"{metric}_Full"] = self._eval(metric, self.full_pred, self.full_gt, False)
         return out
+
+
+# ----------------------------------------------------------------------------- LPIPS (VGG-16 variant of lpips v0.1)
+
+LPIPS_VGG_SLICES = ((0, 4), (4, 9), (9, 16), (16, 23), (23, 30))      # torchvision vgg16.features up to relu1_2 .. relu5_3
+LPIPS_VGG_CONVS = {0: (3, 64), 2: (64, 64), 5: (64, 128), 7: (128, 128), 10: (128, 256), 12: (256, 256), 14: (256, 256),
+                   17: (256, 512), 19: (512, 512), 21: (512, 512), 24: (512, 512), 26: (512, 512), 28: (512, 512)}
+LPIPS_VGG_POOLS = (4, 9, 16, 23)
+LPIPS_CHANNELS = (64, 128, 256, 512, 512)
+
+
+def _lpips_module():
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    class LPIPSVGG(nn.Module):
+        """d(x, y) = sum_l mean_hw( w_l . (unit(f_l(x)) - unit(f_l(y)))^2 ) over the five VGG-16 stages, inputs RGB in [-1, 1]
+        [N,3,H,W] shifted / scaled by the package's ScalingLayer constants; unit() divides by the channel norm + 1e-10; w_l are
+        the learned non-negative 1x1 heads (`lin{l}.model.1.weight`, [1,C_l,1,1]).  Parameters carry torchvision's and lpips's own
+        key names so that their files load with strict=True: `features.<i>.{weight,bias}` and `lin<l>.model.1.weight`."""
+
+        def __init__(self):
+            super().__init__()
+            self.features = nn.ModuleDict({str(i): nn.Conv2d(ci, co, 3, padding=1) for i, (ci, co) in LPIPS_VGG_CONVS.items()})
+            for l, c in enumerate(LPIPS_CHANNELS):
+                head = nn.Module()
+                head.model = nn.ModuleDict({"1": nn.Conv2d(c, 1, 1, bias=False)})
+                setattr(self, f"lin{l}", head)
+            self.register_buffer("shift", torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1), persistent=False)
+            self.register_buffer("scale", torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1), persistent=False)
+
+        def stages(self, x):
+            out = []
+            for lo, hi in LPIPS_VGG_SLICES:
+                for i in range(lo, hi):
+                    if i in LPIPS_VGG_CONVS:
+                        x = F.relu(self.features[str(i)](x))
+                    elif i in LPIPS_VGG_POOLS:
+                        x = F.max_pool2d(x, 2, 2)
+                out.append(x)
+            return out
+
+        def forward(self, x, y):
+            fx, fy = self.stages((x - self.shift) / self.scale), self.stages((y - self.shift) / self.scale)
+            total = 0.0
+            for l, (a, b) in enumerate(zip(fx, fy)):
+                a = a / (a.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+                b = b / (b.pow(2).sum(1, keepdim=True).sqrt() + 1e-10)
+                total = total + getattr(self, f"lin{l}").model["1"]((a - b) ** 2).mean((2, 3), keepdim=True)
+            return total
+
+    return LPIPSVGG
+
+
+def load_lpips(vgg16_path=None, lin_path=None, device="cpu"):
+    """-> callable `lpips_fn(pred, gt) -> float` on [H,W,3] float arrays in [0,1] (what `EvalTools(lpips_fn=...)` takes), built
+    from the two files the `lpips` package would have downloaded: torchvision's `vgg16-397923af.pth` (or any state dict with
+    `features.*` keys) and lpips v0.1's `vgg.pth`.  Paths default to $MNERF_LPIPS_VGG16 / $MNERF_LPIPS_LIN and torch hub's cache."""
+    import os
+    import torch
+    hub = os.path.join(os.path.expanduser(os.environ.get("TORCH_HOME", "~/.cache/torch")), "hub", "checkpoints")
+    vgg16_path = vgg16_path or os.environ.get("MNERF_LPIPS_VGG16") or os.path.join(hub, "vgg16-397923af.pth")
+    lin_path = lin_path or os.environ.get("MNERF_LPIPS_LIN") or os.path.join(hub, "lpips_vgg.pth")
+    for what, path in (("torchvision VGG-16 weights", vgg16_path), ("lpips v0.1 linear heads (vgg.pth)", lin_path)):
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"LPIPS: {what} not found at {path}; there is no network here — copy the file and point "
+                                    "MNERF_LPIPS_VGG16 / MNERF_LPIPS_LIN at it (the reference downloads both through the lpips package)")
+    net = _lpips_module()()
+    sd = {k: v for k, v in torch.load(vgg16_path, map_location="cpu", weights_only=True).items() if k.startswith("features.")}
+    sd.update(torch.load(lin_path, map_location="cpu", weights_only=True))
+    net.load_state_dict(sd, strict=True)
+    net = net.to(device).eval()
+
+    @torch.no_grad()
+    def lpips_fn(pred, gt):
+        to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None].permute(0, 3, 1, 2).float().to(device) * 2 - 1.0
+        return float(net(to_t(pred), to_t(gt)).item())
+
+    return lpips_fn

@@ -226,3 +226,55 @@ def test_missing_list_files_are_named_and_coach_passes_the_overrides(tmp_path, m
     assert len(c.test_loaders) == 1 and c.test_loaders[0].get_name() == "dtu"
     batch = next(iter(c.test_loaders[0]))
     assert batch["images"].shape == (1, 4, 3, 32, 64)
+
+
+def test_lpips_network_structure_and_weight_files(tmp_path, monkeypatch):
+    """metrics.LPIPSVGG (PARITY UNPINNED: no lpips weights offline): files with torchvision's / lpips's key names and shapes load
+    strictly, the forward equals an independent functional evaluation of the published network, d(x, x) = 0, and a missing file
+    is a clear error."""
+    import torch
+    import torch.nn.functional as F
+    from matchnerf_amd import metrics as M
+    g = torch.Generator().manual_seed(0)
+    vgg = {}
+    for i, (ci, co) in M.LPIPS_VGG_CONVS.items():
+        vgg[f"features.{i}.weight"] = torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5
+        vgg[f"features.{i}.bias"] = torch.randn(co, generator=g) * 0.01
+    vgg["classifier.0.weight"] = torch.zeros(2, 2)  # the torchvision file also holds the classifier: ignored
+    lin = {f"lin{l}.model.1.weight": torch.rand(1, c, 1, 1, generator=g) for l, c in enumerate(M.LPIPS_CHANNELS)}
+    torch.save(vgg, tmp_path / "vgg16.pth")
+    torch.save(lin, tmp_path / "lin.pth")
+    fn = M.load_lpips(str(tmp_path / "vgg16.pth"), str(tmp_path / "lin.pth"))
+    rng = np.random.default_rng(1)
+    a, b = rng.random((40, 48, 3), dtype=np.float32), rng.random((40, 48, 3), dtype=np.float32)
+    assert fn(a, a) == 0.0 and fn(a, b) > 0.0 and abs(fn(a, b) - fn(b, a)) < 1e-6
+
+    def direct(x, y):  # independent evaluation: a plain layer list, features at the published taps
+        taps, feats = {3, 8, 15, 22, 29}, ([], [])
+        shift, scale = torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1), torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1)
+        for k, t in enumerate((x, y)):
+            t = (t - shift) / scale
+            for i in range(30):
+                if f"features.{i}.weight" in vgg:
+                    t = F.conv2d(t, vgg[f"features.{i}.weight"], vgg[f"features.{i}.bias"], padding=1)
+                elif i in (4, 9, 16, 23):
+                    t = F.max_pool2d(t, 2)
+                else:
+                    t = F.relu(t)
+                if i in taps:
+                    feats[k].append(t)
+        d = 0.0
+        for l, (fa, fb) in enumerate(zip(*feats)):
+            na = fa / (fa.norm(dim=1, keepdim=True) + 1e-10)
+            nb = fb / (fb.norm(dim=1, keepdim=True) + 1e-10)
+            d += float((((na - nb) ** 2) * lin[f"lin{l}.model.1.weight"]).sum(1).mean())
+        return d
+
+    to_t = lambda z: torch.from_numpy(z)[None].permute(0, 3, 1, 2) * 2 - 1
+    assert abs(fn(a, b) - direct(to_t(a), to_t(b))) < 1e-5 * max(1.0, fn(a, b))
+    tools = M.EvalTools(lpips_fn=fn)
+    tools.set_inputs(a, b)
+    assert set(tools.get_metrics()) == {"PSNR", "SSIM", "LPIPS"}
+    monkeypatch.delenv("MNERF_LPIPS_VGG16", raising=False)
+    with pytest.raises(FileNotFoundError, match="no network"):
+        M.load_lpips(str(tmp_path / "absent.pth"), str(tmp_path / "lin.pth"))
