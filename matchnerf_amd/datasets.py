@@ -6,10 +6,13 @@ numpy + PIL only — OpenCV and torchvision are not part of this image, so the t
 out: `T.ToTensor()` is uint8 HWC -> float CHW / 255, and `cv2.resize(.., fx=0.5, fy=0.5, INTER_NEAREST)` of an even-sized map
 picks every second row and column (source index floor(dst * 2)).
 
-PARITY UNPINNED: the reference's dataset modules cannot be imported here (they need cv2, torchvision, ipdb, skvideo) and there
-is no DTU data in the image, so the tests check this file against hand-built files with known answers, not against the
-reference.  The list files themselves (`configs/dtu_meta/*.txt`, `configs/pairs.th`) are the user's data and are read from the
-paths the reference reads them from, relative to the working directory, unless `meta_dir` / `pairs_file` say otherwise."""
+PARITY: the reference's own `MVSDatasetDTU` imports in the build container (tools/ref_import.py: in-memory stand-ins for the
+absent cv2 / torchvision modules), so `tools/gen_dataset_golden.py` runs it on a seeded MVSNet-layout tree (tests/dataset_trees.py:
+camera files, list files, 7-light images, 1200x1600 PFM depth maps with holes) for the test, val and train splits and
+`tests/test_scene_sets.py` demands the same samples from this class bit for bit.  The one thing that pin cannot reach is OpenCV's
+INTER_NEAREST rule itself: the reference run uses `nearest_resize` below as its `cv2.resize` (there is no OpenCV here), so that
+function is checked against hand-built arrays only.  The list files themselves (`configs/dtu_meta/*.txt`, `configs/pairs.th`) are
+the user's data and are read from the paths the reference reads them from, relative to the working directory, unless `meta_dir` / `pairs_file` say otherwise."""
 import os
 import re
 

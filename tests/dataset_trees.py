@@ -82,7 +82,52 @@ def write_tnt_scene(rng, scene_dir, view_ids, wh=(96, 54)):
         Image.fromarray(_image(rng, *size)).save(os.path.join(scene_dir, "images", f"{v:08d}.jpg"), quality=95)
 
 
+def write_dtu_tree(rng, root, scans_train, scans_val, ref_views, n_cams, wh=(80, 64), depth_for=()):
+    """MVSNet-style DTU layout (datasets/dtu.py): Cameras/train/%08d_cam.txt, Rectified/<scan>_train/rect_%03d_<light>_r5000.png
+    (view ids count from 1 in the file names, 7 lights), Depths/<scan>/depth_map_%04d.pfm at 1200 x 1600 for the (scan, view)
+    pairs of `depth_for`, and the list files the reference keeps under configs/dtu_meta/."""
+    from matchnerf_amd.datasets import write_pfm
+    meta = os.path.join(root, "configs", "dtu_meta")
+    os.makedirs(meta, exist_ok=True)
+    os.makedirs(os.path.join(root, "dtu", "Cameras", "train"), exist_ok=True)
+    with open(os.path.join(meta, "train_all.txt"), "w") as f:
+        f.write("".join(s + "\n" for s in scans_train))
+    with open(os.path.join(meta, "val_all.txt"), "w") as f:
+        f.write("".join(s + "\n" for s in scans_val))
+    with open(os.path.join(meta, "view_pairs.txt"), "w") as f:
+        f.write(f"{len(ref_views)}\n")
+        for ref, srcs in ref_views:
+            f.write(f"{ref}\n{len(srcs)} " + " ".join(f"{s} {1000.0 / (j + 1):.3f}" for j, s in enumerate(srcs)) + " \n")
+    for v in range(n_cams):
+        rot = Rotation.from_euler("xyz", rng.normal(0, 0.25, 3)).as_matrix()
+        t = rng.normal(0, 120.0, 3) + np.array([0.0, 0.0, 600.0])
+        k = np.array([[361.5 + rng.normal(), 0, 82.9 + rng.normal()], [0, 360.7 + rng.normal(), 66.4 + rng.normal()], [0, 0, 1]])
+        with open(os.path.join(root, "dtu", "Cameras", "train", f"{v:08d}_cam.txt"), "w") as f:
+            f.write("extrinsic\n")
+            for r in range(3):
+                f.write(" ".join(f"{x:.9g}" for x in [*rot[r], t[r]]) + " \n")
+            f.write("0.0 0.0 0.0 1.0\n\nintrinsic\n")
+            for r in range(3):
+                f.write(" ".join(f"{x:.9g}" for x in k[r]) + " \n")
+            f.write(f"\n{425.0 + rng.random() * 10:.9g} {2.5 + rng.random() * 0.1:.9g}\n")
+    for scan in sorted({*scans_train, *scans_val}):
+        d = os.path.join(root, "dtu", "Rectified", f"{scan}_train")
+        os.makedirs(d, exist_ok=True)
+        for v in range(n_cams):
+            for light in range(7):
+                Image.fromarray(_image(rng, *wh)).save(os.path.join(d, f"rect_{v + 1:03d}_{light}_r5000.png"))
+    for scan, v in depth_for:
+        d = os.path.join(root, "dtu", "Depths", scan)
+        os.makedirs(d, exist_ok=True)
+        depth = (600.0 + 200.0 * rng.random((1200, 1600))).astype(np.float32)
+        depth[rng.random((1200, 1600)) < 0.3] = 0.0  # holes: the evaluation mask
+        write_pfm(os.path.join(d, f"depth_map_{v:04d}.pfm"), depth)
+
+
+DTU_REF_VIEWS = [(0, [10, 1, 9, 12, 11, 13, 2, 8, 14, 5]), (24, [3, 7, 1, 0, 13, 12, 9, 5, 6, 11]), (6, [5, 7, 13, 0, 1, 2, 3, 4, 8, 9])]
+
 PAIRS = {
+    "dtu_train": [3, 7, 1, 0, 13, 12, 9], "dtu_test": [24, 5], "dtu_val": [24, 5],
     "fernlike_train": [7, 2, 9, 0, 4, 11, 5], "fernlike_val": [3, 8], "fernlike_test": [3, 8],
     "roomlike_train": [1, 0, 6, 4, 8], "roomlike_val": [5], "roomlike_test": [5],
     "legolike_train": [6, 3, 1, 8, 0, 9], "legolike_val": [2, 7], "legolike_test": [2, 7],
@@ -104,12 +149,17 @@ def build_trees(root, seed=11):
     write_blender_scene(rng, os.path.join(root, "blender", "legolike"), 10, 3)
     write_tnt_scene(rng, os.path.join(root, "tnt", "Yard"), sorted({*PAIRS["TNT_Yard_train"], *PAIRS["TNT_Yard_val"]}))
     write_tnt_scene(rng, os.path.join(root, "tnt", "Lot"), list(range(10)))  # contiguous ids: the hold-out protocol counts images
+    write_dtu_tree(rng, root, ["scanA", "scanB"], ["scanB"], DTU_REF_VIEWS, 25,
+                   depth_for=[("scanA", 24), ("scanB", 24), ("scanB", 5)])
     return root
 
 
 # (case name, registry key, root below the tree, split, constructor keywords) — the same list drives the golden generator
 # (reference classes) and the tests (this repository's producers)
 CASES = [
+    ("dtu_test_nearest", "dtu", "dtu", "test", dict(img_wh=[64, 32], test_views_method="nearest")),
+    ("dtu_val", "dtu", "dtu", "val", dict(img_wh=[64, 32])),
+    ("dtu_train_first6", "dtu", "dtu", "train", dict(img_wh=[32, 32], max_len=6, n_add_train_views=2)),
     ("llff_nearest", "llff", "llff", "test", dict(img_wh=[48, 32], test_views_method="nearest", eval_mode="mvsnerf")),
     ("llff_fixed_one_scene", "llff", "llff", "test", dict(img_wh=[40, 32], scene_list=["fernlike"], test_views_method="fixed")),
     ("llff_gpnr", "llff", "llff", "test", dict(img_wh=[48, 32], scene_list=["roomlike"], eval_mode="gpnr")),
@@ -123,4 +173,4 @@ CASES = [
     ("tnt_gpnr_minmax", "tnt", "tnt", "test", dict(img_wh=[48, 32], scene_list=["Lot"], eval_mode="gpnr", nf_mode="minmax",
                                                    test_views_method="fixed")),
 ]
-FIELDS = ("images", "extrinsics", "intrinsics", "near_fars", "view_ids", "img_wh", "c2ws_all")
+FIELDS = ("images", "extrinsics", "intrinsics", "near_fars", "view_ids", "img_wh", "c2ws_all", "depth")

@@ -4,7 +4,8 @@
 
 Runs the reference's own dataset classes (/root/reference/datasets/{llff,colmap,ibrnet,blender,tnt}.py, imported in place with
 the torchvision stand-in of tools/ref_import.py) on
-  * the seeded on-disk trees of tests/dataset_trees.py (test input written by code), every case of its CASES list, and
+  * the seeded on-disk trees of tests/dataset_trees.py (test input written by code), every case of its CASES list — the DTU
+    cases with a stand-in for the one OpenCV call of that loader (cv2_nearest_resize below) —, and
   * the one real scene the reference ships, docs/demo_data/printer, with the dataset options of configs/demo_own.yaml —
     its three photographs and poses_bounds.npy are DATA and are copied next to the goldens so that the producer test and
     `python test.py --yaml=demo_own --data_test.colmap.root_dir=tests/golden/demo_data` run wherever the repository is,
@@ -42,6 +43,10 @@ def record(store, case, ds, seed=None):
             if k not in s:
                 continue
             v = np.asarray(s[k])
+            if k == "depth":  # 512 x 640 floats per sample: a digest of all of it + every 8th pixel
+                store[f"{case}/{i}/depth_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(v).tobytes()).digest(), np.uint8)
+                store[f"{case}/{i}/depth_sub8"] = v[::8, ::8].copy()
+                continue
             if k == "images":
                 store[f"{case}/{i}/images_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(v).tobytes()).digest(), np.uint8)
                 if i >= FULL_SAMPLES:
@@ -50,8 +55,20 @@ def record(store, case, ds, seed=None):
         store[f"{case}/{i}/scene"] = np.frombuffer(str(s["scene"]).encode(), np.uint8)
 
 
+def cv2_nearest_resize(src, dsize, fx=None, fy=None, interpolation=None):
+    """Stand-in for the ONE OpenCV call of the reference's DTU loader (datasets/dtu.py:126-129, `cv2.resize(depth, None, fx, fy,
+    INTER_NEAREST)`), which this image lacks: OpenCV's nearest rule (destination size round(size * f), source index
+    floor(dst / f) clamped) as matchnerf_amd.datasets.nearest_resize states it.  So the DTU goldens pin everything of that loader
+    EXCEPT this rule itself (camera files, list files, view selection, image decoding / resizing, the depth crop and scale)."""
+    from matchnerf_amd.datasets import nearest_resize
+    assert dsize is None and interpolation == 0
+    return nearest_resize(src, fx, fy)
+
+
 def main():
     import_reference()
+    sys.modules["cv2"].resize = cv2_nearest_resize
+    sys.modules["cv2"].INTER_NEAREST = 0
     import datasets as ref_datasets  # the reference's package (cwd and sys.path point into /root/reference)
     store = {}
     tmp = tempfile.mkdtemp(prefix="mnerf_trees_")
