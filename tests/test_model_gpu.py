@@ -165,8 +165,8 @@ def test_train_mode_gradients_match_oracle_autograd(monkeypatch):
     # (attention backward, split-bf16 GEMMs), but every encoder gradient still passes through the up-sampler's and the backbone's
     # convolutions on MIOpen.  With benchmark mode ON the SAME code measured 7e-5 ... 1.2e-4 on most boxes, 1.3e-3 with Winograd
     # backward-data solvers and 3.7e-3 with one weight-gradient solver of the 7x7 stem (round 3's 5e-3 gate); with the solver
-    # choice pinned above the gate is 2e-3 and the figures are printed.
-    assert checked == 9 and worst < 1e-3 and worst_enc < 2e-3, (worst, worst_enc)
+    # choice pinned above the gate was 2e-3 in round 4 (observed <= 1.2e-4 on five boxes) and is 1e-3 now, the figures are printed.
+    assert checked == 9 and worst < 1e-3 and worst_enc < 1e-3, (worst, worst_enc)
 
 
 def test_stratified_depths_match_oracle():
