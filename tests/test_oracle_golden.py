@@ -81,6 +81,9 @@ def test_video_path_on_real_poses_matches_reference():
     c2ws = sq.double().inverse()[:, :3].float().numpy()
     w2c = torch.tensor(np.asarray(video.interpolate_render_path(c2ws, 24))).inverse()[:, :3].to(torch.float32).numpy()
     assert np.array_equal(w2c[g["video_frames"]], g["video_w2c"])
+    # the spiral path (camera.py:415-468) around the same cameras: all 24 poses, `video_rads_scale` 0.3 (demo_own.yaml)
+    sp = video.spiral_render_path(g["c2ws_all"][0], g["near_fars"][0, -1].tolist(), rads_scale=0.3, n_views=24)
+    assert np.array_equal(torch.tensor(np.asarray(sp)).inverse()[:, :3].to(torch.float32).numpy(), g["spiral_w2c"])
 
 
 def test_float32_posenc_arguments_are_a_bounded_relaxation_of_the_float64_oracle(monkeypatch):

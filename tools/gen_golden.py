@@ -126,6 +126,11 @@ def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep
             cap["video_w2c"] = np.stack([poses[i]["extrinsics"][0].numpy() for i in video_frames])
             return [poses[i] for i in video_frames]
 
+        if "c2ws_all" in scene:  # the other path generator of the reference on the same real cameras (poses only, not rendered)
+            vb0 = EasyDict({k: torch.from_numpy(v) for k, v in scene.items()})
+            tgt0, ref0 = model.extract_poses(vb0)
+            sp = orig_path(tgt0, ref0, "spiral", model.opts.nerf.video_n_frames, vb0)
+            cap["spiral_w2c"] = np.stack([p_["extrinsics"][0].numpy() for p_ in sp])
         model.get_video_rendering_path = thin_path
         vb = EasyDict({k: torch.from_numpy(v) for k, v in scene.items()})
         with torch.no_grad():
@@ -155,6 +160,8 @@ def run_case(name, scene_kw, opt_overrides, stage_rays, setbg_opaque=False, keep
         data["video_w2c"] = cap["video_w2c"]
         data["video_rgb"], data["video_depth"] = video.rgb.numpy(), video.depth.numpy()
         data["video_opacity"] = video.opacity.numpy()
+        if "spiral_w2c" in cap:
+            data["spiral_w2c"] = cap["spiral_w2c"]
     for k, v in (extra or {}).items():
         if not isinstance(v, str):
             data[k] = np.asarray(v)
