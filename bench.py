@@ -13,7 +13,8 @@ accumulation everywhere; the decoder's matrix products run, by MNERF_DECODER_MAT
   f16x3  (default) fp32 operands as two range-managed fp16 terms, 3 products per MAC on the fp16 MFMA,
   bf16x6 fp32 operands as three bf16 terms, 6 products per MAC on the bf16 MFMA,
   f32    the exact-f32 MFMA;
-all three are checked against the reference to the same tolerances.
+all three are checked against the reference to the same tolerances.  A fourth, opt-in `f16` (one fp16 product per
+MAC: the reduced-precision FAST mode, RGB L-inf ~4e-3 against the fp32 path) is timed under config.other_decoder_math only.
 
 N > 1: one process per GPU over RCCL.  Started WITHOUT a launcher (``python bench.py --gpus N``)
 the script re-executes itself under ``torch.distributed.run`` with N ranks on 127.0.0.1; started
@@ -60,10 +61,10 @@ F32_MFMA_PEAK_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, chip-l
 DENSE16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16 (same table)
 HBM_PEAK_BYTES = 8.0e12
 MLP_FLOPS_PER_SAMPLE = 258336   # the Linear layers of SURVEY.md §8(d); they run as 3 (f16x3) / 6 (bf16x6) products per MAC
-PRODUCTS_PER_MAC = {"f16x3": 3, "bf16x6": 6, "f32": 1}
+PRODUCTS_PER_MAC = {"f16x3": 3, "bf16x6": 6, "f32": 1, "f16": 1}
 # ceiling of each matrix path in ALGORITHMIC TFLOP/s: the pipe's dense peak / products per MAC
 PATH_CEILING_TFLOPS = {"f16x3": DENSE16_MFMA_PEAK_TFLOPS / 3, "bf16x6": DENSE16_MFMA_PEAK_TFLOPS / 6,
-                       "f32": F32_MFMA_PEAK_TFLOPS}
+                       "f32": F32_MFMA_PEAK_TFLOPS, "f16": DENSE16_MFMA_PEAK_TFLOPS}
 SHADER_CLOCK_HZ = 2.4e9          # ibid. ("256 CU x 2.4 GHz"); profiled passes run 1.9-2.0 GHz, so clock-based fractions are lower bounds
 L1_PEAK_BYTES = 64 * 256 * SHADER_CLOCK_HZ  # vector L1 -> registers: 64 B per clock and CU
 
@@ -368,7 +369,7 @@ def main():
         rgb_default = full[:, :3].clone()
         keep = os.environ.get("MNERF_DECODER_MATH")
         try:
-            for m in ("f16x3", "bf16x6", "f32"):
+            for m in ("f16x3", "bf16x6", "f32", "f16"):  # "f16": the reduced-precision fast mode (outside the parity gate)
                 if m == math:
                     continue
                 os.environ["MNERF_DECODER_MATH"] = m
@@ -510,7 +511,8 @@ def main():
         line = {
             "metric": "rendered rays/sec (3-view, 64 samples/ray)", "value": round(value, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
+            "dtype": "f16" if math == "f16" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE config[1]: DTU-shape 3-view 512x640, 64 samples/ray, full frame "
@@ -519,7 +521,9 @@ def main():
                                           "fp16 MFMA, fp32 accumulate (DESIGN.md section 4)",
                                  "bf16x6": "bf16x6: fp32 operands as 3 bf16 terms, 6 products per MAC on the bf16 MFMA, "
                                            "fp32 accumulate",
-                                 "f32": "f32: exact-f32 MFMA"}[math],
+                                 "f32": "f32: exact-f32 MFMA",
+                                 "f16": "f16: REDUCED PRECISION fast mode - one fp16 product per MAC, fp32 accumulate; outside the "
+                                        "1e-4 parity gate (not the default; a headline measured in it is not the parity-mode figure)"}[math],
                 "other_decoder_math": other_math or None,
                 "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(launch_rays),
                 "parallelism": (f"row bands of one frame x{world} (strong scaling)" if rows_mode else

@@ -31,6 +31,8 @@
  *   v7  mnerf_rays gained pose_table / rays_per_pose (several target poses per launch; mnerf_render_takes_pose_table).
  *       Added under v7 without a layout change: mnerf_debug_gemm, mnerf_window_attention_presplit_stats,
  *       mnerf_window_attention_backward_stats.
+ *   v8  no layout change: mnerf_decoder.wstream_format accepts MNERF_WSTREAM_F16X1 (one-product fp16 fast mode); pose tables at
+ *       sample_intvs <= 128 (was 64); mnerf_debug_set_knob serialised with the launches' reads.
  */
 #ifndef MNERF_H_
 #define MNERF_H_
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 7
+#define MNERF_ABI_VERSION 8
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
@@ -128,6 +130,10 @@ typedef struct mnerf_scene {
 #define MNERF_WSTREAM_F32 0
 #define MNERF_WSTREAM_BF16X3 1
 #define MNERF_WSTREAM_F16X2 2
+#define MNERF_WSTREAM_F16X1 3 /* ABI v8: the F16X2 stream read as plain fp16 weights (hi terms only), ONE product per MAC on fp16
+                                * activations, fp32 accumulation: the reduced-precision FAST mode (RGB L-inf ~4e-3 against the
+                                * fp32 path: outside the 1e-4 parity gate, never the default).  Ping-pong decoder only (<= 5
+                                * source views, sample_intvs <= 128, no pose table); MNERF_E_UNSUPPORTED elsewhere. */
 
 typedef struct mnerf_decoder {
   const float* wstream;

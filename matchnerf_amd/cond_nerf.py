@@ -496,14 +496,16 @@ def pack_wstream_h(sd, n_views, cos_n_group, L_3D=10, legacy=True, prefix="nerf_
     return out, cond_dim, cond_stride
 
 
-WSTREAM_FORMATS = {"f32": 0, "bf16x6": 1, "f16x3": 2}
+WSTREAM_FORMATS = {"f32": 0, "bf16x6": 1, "f16x3": 2, "f16": 3}
 
 
 def decoder_math():
     """Matrix arithmetic of the fused decoder, chosen with MNERF_DECODER_MATH:
     'f16x3' (default) fp32 operands as two range-managed fp16 terms, three products per MAC on the fp16 MFMA;
     'bf16x6' fp32 operands as three bf16 terms, six products per MAC (strict: error of an fp32 FMA chain);
-    'f32' the exact-f32 MFMA."""
+    'f32' the exact-f32 MFMA;
+    'f16' (opt-in FAST mode, reduced precision: outside the 1e-4 parity gate) the f16x3 stream read as plain fp16 weights, one
+    product per MAC on fp16 activations with per-sample gains, fp32 accumulation (ping-pong decoder only)."""
     import os
     m = os.environ.get("MNERF_DECODER_MATH", "f16x3")
     if m not in WSTREAM_FORMATS:
@@ -512,7 +514,7 @@ def decoder_math():
 
 
 def pack_for_math(math):
-    return {"f32": pack_wstream, "bf16x6": pack_wstream16, "f16x3": pack_wstream_h}[math]
+    return {"f32": pack_wstream, "bf16x6": pack_wstream16, "f16x3": pack_wstream_h, "f16": pack_wstream_h}[math]
 
 
 def raytrans_table(n_samples, d_hid=16):
@@ -619,7 +621,7 @@ class CondNeRF(nn.Module):
         key = self._pack_key(n_samples)
         if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
             math = self.math_for(n_samples)
-            if math == "f16x3" and self.pts_bias.weight.is_cuda and self.pts_bias.weight.device == torch.device(device):
+            if math in ("f16x3", "f16") and self.pts_bias.weight.is_cuda and self.pts_bias.weight.device == torch.device(device):
                 # parameters on the GPU (every training iteration re-packs after the optimizer step): the stream is assembled
                 # THERE, without a device->host copy (packing.DecoderPacker, bit-identical to pack_wstream_h)
                 self._packed = (key,) + self._packed_on_device(n_samples, torch.device(device)) + (WSTREAM_FORMATS[math],)

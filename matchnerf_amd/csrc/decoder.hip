@@ -1888,7 +1888,9 @@ __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float
 // POSES: the launch carries a pose table (mnerf_rays.pose_table: several target poses of a small frame in one launch); a team's
 // rays of a tile belong to one pose (rays_per_pose is a multiple of 64), whose camera constants replace the launch-wide ones
 // once per tile.  A separate instance so that the default kernel's scalar-register budget is untouched.
-template <int SP, int FS = 2, bool POSES = false>
+// NPK: products per MAC of the trunk (3 = the fp32-grade parity path; 1 = the reduced-precision fast mode MNERF_WSTREAM_F16X1: fp16
+// operands with per-sample gains, fp32 accumulation — same stream, same schedule, the lo halves unused).
+template <int SP, int FS = 2, bool POSES = false, int NPK = 3>
 __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     mnerf_decoder D, DecSched sch, PPSched pps, mnerf_view view0, mnerf_rays Rl, const float* __restrict__ cond,
     float* __restrict__ out_rgb, float* __restrict__ out_depth, float* __restrict__ out_opacity,
@@ -2176,14 +2178,14 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #elif MNERF_PP_PAIRS
 #define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
 #else
-#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
+#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2<NMB_, NS0_, NS1_, NPK>(acc_, base0_, base1_, lane, hs_)
 #endif
 #if defined(MNERF_EXP_NO_MFMA) || MNERF_PP_PAIRS
 #define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
   PP_MFMA_(NMB_, NS0_, NS1_, acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), hs_)
 #else
 #define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                      \
-  ksteps_presplit2<NMB_, NS0_, NS1_>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_,             \
+  ksteps_presplit2<NMB_, NS0_, NS1_, NPK>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_,        \
                                      [&](int i_, unsigned la_, unsigned lb_) { pp_m_dma(s_, ((NS0_) + (NS1_)) * (NMB_), i_, la_, lb_); })
 #endif
 #define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                   \
@@ -2846,7 +2848,7 @@ static int build_schedule_split(const mnerf_decoder* D, DecSched* sch, int parts
 // rest; every segment is padded to a multiple of 256 floats.
 static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
   if (D->wstream_format == MNERF_WSTREAM_BF16X3) return build_schedule_split(D, sch, 3);
-  if (D->wstream_format == MNERF_WSTREAM_F16X2) return build_schedule_split(D, sch, 2);
+  if (D->wstream_format == MNERF_WSTREAM_F16X2 || D->wstream_format == MNERF_WSTREAM_F16X1) return build_schedule_split(D, sch, 2);
   const int fs = D->cond_stride / 2, es = 3 * D->L_3D + 2;
   // film, l0, l1..l4, l5-enc, l5-h, feature, views, rgb, alpha (+ the resident tail segment)
   const int T[12] = {fs, es, 65, 65, 65, 65, es, 64, 65, 66, 33, 65};
@@ -2883,7 +2885,7 @@ static int build_schedule(const mnerf_decoder* D, DecSched* sch) {
 }
 
 static bool known_format(int f) {
-  return f == MNERF_WSTREAM_F32 || f == MNERF_WSTREAM_BF16X3 || f == MNERF_WSTREAM_F16X2;
+  return f == MNERF_WSTREAM_F32 || f == MNERF_WSTREAM_BF16X3 || f == MNERF_WSTREAM_F16X2 || f == MNERF_WSTREAM_F16X1;
 }
 
 #if MNERF_DECODER_PART == 0
@@ -2908,7 +2910,8 @@ static int pp_film_steps(const mnerf_decoder* dec, const DecSched& sch, int Sp) 
   const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
   // FiLM stages of 2 K16-steps (<= 5 views) at every S; of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
   const int fs = sch.film_steps;
-  const bool ok = dec->wstream_format == MNERF_WSTREAM_F16X2 && Sp > 0 && Sp <= pp_max_s && dec->L_3D == 10 &&
+  const bool f16 = dec->wstream_format == MNERF_WSTREAM_F16X2 || dec->wstream_format == MNERF_WSTREAM_F16X1;
+  const bool ok = f16 && Sp > 0 && Sp <= pp_max_s && dec->L_3D == 10 &&
                   (fs == 2 || ((fs == 3 || fs == 4) && Sp == 64)) && dec->cond_stride <= 16 * fs && sch.enc_steps == 4 &&
                   sch.n_seg == 20 && mnerf_tune().decoder_pp;
   return ok ? fs : 0;
@@ -3032,7 +3035,26 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
                        opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
   } while (0)
 #define MNERF_LAUNCH_PP(SP_, FS_) MNERF_LAUNCH_PP_(SP_, FS_, false)
-    if (poses) {  // the instances that exist with a pose table: the shipped 3-view shape (<= 5 views) at S <= 128
+    if (dec->wstream_format == MNERF_WSTREAM_F16X1) {  // reduced-precision fast mode: the shipped shape only
+      MNERF_REQUIRE(fs == 2 && !poses, MNERF_E_UNSUPPORTED,
+                    "%s: the one-product fp16 mode (MNERF_WSTREAM_F16X1) is built for <= 5 source views without a pose table", who);
+#define MNERF_LAUNCH_PP1(SP_)                                                                                          \
+  do {                                                                                                                \
+    const size_t lds = SmemPP<SP_>::TOTAL_FLOATS * sizeof(float);                                                     \
+    static std::atomic<unsigned long long> attr_set{0};                                                               \
+    if (mnerf_once_per_device(attr_set))                                                                              \
+      (void)hipFuncSetAttribute((const void*)decoder_pp_kernel<SP_, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((decoder_pp_kernel<SP_, 2, false, 1>), dim3(grid), dim3(512), lds, st, *dec, sch, pps, *view0, *rays, cond, rgb, depth, \
+                       opacity, rgb_s, sigma, ext_ndc, ext_dir);                                                      \
+  } while (0)
+      if (Sp == 32)
+        MNERF_LAUNCH_PP1(32);
+      else if (Sp == 64)
+        MNERF_LAUNCH_PP1(64);
+      else
+        MNERF_LAUNCH_PP1(128);
+#undef MNERF_LAUNCH_PP1
+    } else if (poses) {  // the instances that exist with a pose table: the shipped 3-view shape (<= 5 views) at S <= 128
       MNERF_REQUIRE(fs == 2 && (Sp == 32 || Sp == 64 || Sp == 128), MNERF_E_UNSUPPORTED,
                     "%s: pose tables are built for <= 5 source views and sample_intvs <= 128", who);
       if (Sp == 32)
@@ -3056,6 +3078,9 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     return mnerf_check_launch(who);
   }
 #endif
+  MNERF_REQUIRE(dec->wstream_format != MNERF_WSTREAM_F16X1, MNERF_E_UNSUPPORTED,
+                "%s: the one-product fp16 mode (MNERF_WSTREAM_F16X1) exists in the ping-pong decoder only (<= 5 source views, "
+                "sample_intvs <= 128, MNERF_DECODER_PP on, not the one-launch form)", who);
   MNERF_REQUIRE(!poses, MNERF_E_UNSUPPORTED, "%s: a pose table needs the ping-pong decoder (split-fp16 stream, <= 5 source views, "
                 "sample_intvs <= 128, MNERF_DECODER_PP on)", who);
 #if MNERF_DECODER_PART == 1
@@ -3128,7 +3153,7 @@ int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, c
 #else  // MNERF_DECODER_PART == 0
 // the pose-table instances of the decoder: the ping-pong form with a 2-step FiLM stage (<= 5 source views) at S <= 64
 bool mnerf_decoder_takes_pose_table(const mnerf_decoder* dec, int n_samples) {
-  if (!known_format(dec->wstream_format) || dec->L_3D < 0 || dec->L_3D > 16) return false;
+  if (!known_format(dec->wstream_format) || dec->wstream_format == MNERF_WSTREAM_F16X1 || dec->L_3D < 0 || dec->L_3D > 16) return false;
   DecSched sch;
   if (build_schedule(dec, &sch) <= 0) return false;
   const int Sp = pick_padded_samples(n_samples);

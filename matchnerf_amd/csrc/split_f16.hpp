@@ -345,7 +345,10 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
 struct KstepsNoHook {
   __device__ __forceinline__ void operator()(int, unsigned, unsigned) const {}
 };
-template <int NMB, int NS0, int NS1, class Hook = KstepsNoHook>
+// NP: products per MAC.  3 = hi.lo + lo.hi + hi.hi (fp32-grade, the parity path); 1 = hi.hi only — plain fp16 operands with
+// fp32 accumulation, the reduced-precision fast mode (MNERF_WSTREAM_F16X1): the lo fragments are then never read and the
+// operands' lo halves never used, so the compiler drops their LDS reads and their split arithmetic with them.
+template <int NMB, int NS0, int NS1, int NP = 3, class Hook = KstepsNoHook>
 __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned base0_lds, unsigned base1_lds, int lane,
                                                  const PartsH* b, Hook hook = Hook()) {
   constexpr int N0 = NS0 * NMB, N = (NS0 + NS1) * NMB, DEP = MNERF_PP_DEPTH, NB = DEP + 1;
@@ -355,10 +358,10 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
   auto fetch = [&](int i, int slot) {
     if (i < N0) {
       fh[slot] = a0[i * 128];
-      fl[slot] = a0[i * 128 + 64];
+      if constexpr (NP == 3) fl[slot] = a0[i * 128 + 64];
     } else {
       fh[slot] = a1[(i - N0) * 128];
-      fl[slot] = a1[(i - N0) * 128 + 64];
+      if constexpr (NP == 3) fl[slot] = a1[(i - N0) * 128 + 64];
     }
   };
 #pragma unroll
@@ -372,10 +375,13 @@ __device__ __forceinline__ void ksteps_presplit2(f32x16 (&acc)[NMB], unsigned ba
     // both fragments are waited for BEFORE the first of the three dependent matrix instructions: hipcc otherwise puts
     // the s_waitcnt of the lo fragment between the first and the second, and an extra issue slot between two MFMAs on the
     // same accumulator costs ~40 cycles (measured: 3.9 k cycles for the 96 instructions of a layer against 3.1 k)
-    asm volatile("" : "+v"(fh[i % NB]), "+v"(fl[i % NB]));
-    const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % NB]), al = __builtin_bit_cast(f16x8, fl[i % NB]);
-    acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
-    acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
+    if constexpr (NP == 3) asm volatile("" : "+v"(fh[i % NB]), "+v"(fl[i % NB]));
+    else asm volatile("" : "+v"(fh[i % NB]));
+    const f16x8 ah = __builtin_bit_cast(f16x8, fh[i % NB]), al = __builtin_bit_cast(f16x8, NP == 3 ? fl[i % NB] : fh[i % NB]);
+    if constexpr (NP == 3) {
+      acc[m] = MFMA16H_CROSS(ah, b[u].lo, acc[m]);
+      acc[m] = MFMA16H_CROSS(al, b[u].hi, acc[m]);
+    }
     acc[m] = mfma16h(ah, b[u].hi, acc[m]);
     __builtin_amdgcn_sched_barrier(0);
     hook(i, (unsigned)(size_t)a0, base0_lds);

@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 7
+MNERF_ABI_VERSION = 8
 MNERF_POSE_FLOATS = 24  # floats of one row of mnerf_rays.pose_table
 MNERF_OK, MNERF_E_NULL, MNERF_E_RANGE, MNERF_E_UNSUPPORTED, MNERF_E_ALIGN = 0, -1, -2, -3, -4  # include/mnerf.h
 MNERF_MAX_VIEWS = 16
@@ -91,7 +91,7 @@ class EncoderLayerTrain(C.Structure):
                                           "g_w_merge", "g_ln1_w", "g_ln1_b", "g_w_mlp0", "g_w_mlp2", "g_ln2_w", "g_ln2_b")]
 
 
-WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2 = 0, 1, 2
+WSTREAM_F32, WSTREAM_BF16X3, WSTREAM_F16X2, WSTREAM_F16X1 = 0, 1, 2, 3
 WA_SPLIT_BF16, WA_EXACT_F32, WA_SPLIT_F16 = 0, 1, 2
 WA_PRESPLIT_F16 = 3  # host-side selector only: routed to mnerf_window_attention_presplit
 ABSMAX_FLOATS = 64 * 32  # floats of one absmax region (MNERF_ABSMAX_FLOATS)

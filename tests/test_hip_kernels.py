@@ -212,6 +212,37 @@ def test_decoder_chunk_matches_reference(hip, name, math):
     assert linf(depth, g["depth"][0, sel, 0]) < 3e-4
 
 
+@pytest.mark.parametrize("name", ["c1_default", "v4", "demo_own_small"])
+def test_fast_fp16_mode_is_reduced_precision_and_says_so(hip, name):
+    """MNERF_WSTREAM_F16X1 (MNERF_DECODER_MATH=f16, ABI 8): the f16x3 stream read as plain fp16 weights, one product per MAC. An
+    opt-in FAST mode: it must be CLOSE to the reference (per-sample colours 2e-2, rendered RGB 2e-2) and measurably NOT the parity
+    path (it differs from f16x3 by more than the parity gate somewhere), so that nobody mistakes one for the other; what it
+    cannot do is refused by name."""
+    g, cfg, sd, batch, _, _ = _case_on_gpu(name)
+    idx = torch.from_numpy(g["stage_rays"]).int().cuda()
+    cond = cond_with_stride(torch.from_numpy(g["cond"]).reshape(-1, g["cond"].shape[-1]),
+                            ((g["cond"].shape[-1] + 1 + 7) // 8) * 8).cuda()
+    out = {}
+    for math in ("f16x3", "f16"):
+        dec, keep = make_decoder_struct(cfg, sd, setbg_opaque=g["meta"]["setbg_opaque"], math=math)
+        rays = make_rays_struct(cfg, batch, idx.numel(), ray_idx_gpu=idx)
+        view0 = hip.make_view(batch["extrinsics"][0, 0, :3].numpy(), batch["intrinsics"][0, 0].numpy(),
+                              float(batch["near_fars"][0, 0, 0]), float(batch["near_fars"][0, 0, 1]))
+        out[math] = hip.decoder_chunk(dec, view0, rays, cond, want_samples=True)
+    rgb, depth, opacity, rgb_s, sigma = out["f16"]
+    sel = g["stage_rays"]
+    assert linf(rgb_s.reshape(g["rgb_samples"].shape), g["rgb_samples"]) < 2e-2
+    assert linf(rgb, g["rgb"][0, sel]) < 2e-2 and linf(opacity, g["opacity"][0, sel, 0]) < 2e-2
+    assert linf(rgb_s, out["f16x3"][3]) > 1e-5  # one product is not three
+    if name == "c1_default":
+        table = torch.zeros(2, hip.MNERF_POSE_FLOATS, device="cuda")
+        n = idx.numel() - idx.numel() % 64
+        rays = make_rays_struct(cfg, batch, n)
+        rays.pose_table, rays.rays_per_pose = table.data_ptr(), 64
+        with pytest.raises(hip.MnerfError, match="F16X1"):
+            hip.decoder_chunk(dec, view0, rays, cond)
+
+
 @pytest.mark.parametrize("name", ["c1_default", "v4"])
 def test_decoder_math_variants_agree(hip, name):
     """The split paths are fp32-grade: bf16x6 (three bf16 terms per operand, six products) and f16x3 (two
