@@ -8,6 +8,7 @@
 #                       configuration with libmnerf_hip.so and libmnerf_hip_<a>.so ... in turn (same-box A/B)  -> frames.log
 #   profile             tools/profile_round.sh TAG (kernel stats, bench trace, PMC passes, counter json files)
 #   trace=SCRIPT[,ARG..] rocprofv3 --kernel-trace --stats over python tools/exp/SCRIPT ARGS -> SCRIPT_kernel_stats.md
+#                       (TRACE_PERIODS=K: only the last K periods between decoder launches, e.g. training iterations)
 #   py=SCRIPT[,ARG..]   python tools/exp/SCRIPT ARGS                           -> SCRIPT.log
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 TAG=$1; shift
@@ -41,7 +42,7 @@ PY
     trace)
       IFS=, read -r script rest <<< "$arg"
       R=$PWD; rm -rf /tmp/trace_$TAG; ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- python $R/tools/exp/$script ${rest//,/ } > $R/$O/${script%.py}_trace.log 2>&1 )
-      python tools/rocpd_stats.py $(find /tmp/trace_$TAG -name '*.db' | head -1) 40 > $O/${script%.py}_kernel_stats.md 2>&1
+      python tools/rocpd_stats.py $(find /tmp/trace_$TAG -name '*.db' | head -1) 45 ${TRACE_PERIODS:+--periods $TRACE_PERIODS} > $O/${script%.py}_kernel_stats.md 2>&1
       head -14 $O/${script%.py}_kernel_stats.md | cut -c1-160;;
     py)
       IFS=, read -r script rest <<< "$arg"

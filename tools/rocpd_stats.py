@@ -5,12 +5,14 @@ the same content `rocprofv3 --stats` prints as kernel_stats.csv in older release
     python tools/rocpd_stats.py x_results.db 40 --last-frame 5   # only the dispatches after the 6th-from-last
                                                                  # decoder_kernel launch: the steady-state frame
                                                                  # (5 ray-chunk launches), without MIOpen's find pass
+    python tools/rocpd_stats.py x_results.db 40 --periods 3      # the last 3 full periods between decoder launches (training
+                                                                 # iterations launch the decoder once each)
 """
 import sqlite3
 import sys
 
 
-def main(path, top=40, last_frame=0):
+def main(path, top=40, last_frame=0, periods=0):
     db = sqlite3.connect(path)
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -21,6 +23,11 @@ def main(path, top=40, last_frame=0):
         if len(dec) > last_frame:
             t0 = dec[-last_frame - 1]
             rows = [r for r in rows if r[1] > t0]
+    if periods:  # exactly `periods` repetitions of a loop that launches the decoder once per repetition (training iterations): from
+        # the (periods+1)-th from last decoder launch up to, not including, the last one — warm-up (MIOpen's solver search) left out
+        dec = sorted(s for n, s, e in rows if "decoder_kernel" in n or "decoder_pp_kernel" in n)
+        if len(dec) > periods:
+            rows = [r for r in rows if dec[-periods - 1] <= r[1] < dec[-1]]
     agg = {}
     for name, s, e in rows:
         d = (e - s) / 1e3  # ns -> us
@@ -40,4 +47,5 @@ def main(path, top=40, last_frame=0):
 
 if __name__ == "__main__":
     lf = int(sys.argv[sys.argv.index("--last-frame") + 1]) if "--last-frame" in sys.argv else 0
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 40, lf)
+    pe = int(sys.argv[sys.argv.index("--periods") + 1]) if "--periods" in sys.argv else 0
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 40, lf, pe)
