@@ -22,6 +22,7 @@ import torch
 from . import cond_nerf as CN
 
 _INDEX_CACHE = {}
+_TRANSFORMER_INDEX = {}  # (layer kinds, device) -> (int32 index [units, 512], per-layer unit spans, units)
 
 
 def fragment_index(n_out, n_in, cols, nmb, device):
@@ -111,17 +112,27 @@ class TransformerPacker:
     only and is built once per device."""
 
     def __init__(self, ft, device):
-        from .gmflow import EB_CHUNK, K_ROW_ORDER
         self.device = torch.device(device)
         self.layers = [l for blk in ft.layers for l in (blk.self_attn, blk.cross_attn_ffn)]
+        self.tensors = []
+        for layer in self.layers:
+            self.tensors += layer._qkv_params() + layer._block_weights()
+        # the index depends on the layers' SHAPES only: shared by every transformer of that shape on the device (nn.DataParallel
+        # makes a new replica object per forward; rebuilding 3 M index entries each time would cost half a second)
+        sig = (tuple(bool(l.no_ffn) for l in self.layers), str(self.device))
+        if sig not in _TRANSFORMER_INDEX:
+            _TRANSFORMER_INDEX[sig] = self._build_index()
+        self.index, self.spans, self.n_units = _TRANSFORMER_INDEX[sig]
+
+    def _build_index(self):
+        from .gmflow import EB_CHUNK, K_ROW_ORDER
         acc_order = CN._reg_cols16(4)
         cols1 = np.concatenate([_NATURAL, 128 + acc_order], 0)
         rows128 = np.arange(128)
-        self.tensors, self.spans, chunks, off, pos = [], [], [], 0, 0
+        spans, chunks, off, pos = [], [], 0, 0
 
         def add_tensor(t):
             nonlocal off
-            self.tensors.append(t)
             base, off = off, off + t.numel()
             return base
 
@@ -150,11 +161,10 @@ class TransformerPacker:
                     chunks.append(frag(b0, 256, EB_CHUNK * c + rows128, cols1))
                     chunks.append(frag(b2, 1024, rows128, EB_CHUNK * c + acc_order))
                     pos += chunks[-2].shape[0] + chunks[-1].shape[0]
-            self.spans.append((qkv_span, (start, pos)))
+            spans.append((qkv_span, (start, pos)))
         idx = np.concatenate(chunks, 0)
         assert idx.max() < off < 2 ** 31
-        self.index = torch.from_numpy(idx.astype(np.int32)).to(self.device)
-        self.n_units = pos
+        return torch.from_numpy(idx.astype(np.int32)).to(self.device), spans, pos
 
     def matches(self, ft):
         layers = [l for blk in ft.layers for l in (blk.self_attn, blk.cross_attn_ffn)]
