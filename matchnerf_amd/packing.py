@@ -22,6 +22,7 @@ import torch
 from . import cond_nerf as CN
 
 _INDEX_CACHE = {}
+_DECODER_PLAN = {}       # (decoder shape, device) -> the index tensors of DecoderPacker
 _TRANSFORMER_INDEX = {}  # (layer kinds, device) -> (int32 index [units, 512], per-layer unit spans, units)
 
 
@@ -205,6 +206,15 @@ class DecoderPacker:
         sd = {prefix + k: v for k, v in dec.state_dict().items()}
         self.names = [k for k in sd if not k.endswith("num_batches_tracked")]
         self.params = [dict(dec.named_parameters())[k[len(prefix):]] for k in self.names]
+        # the plan depends on the decoder's shape only: shared by every decoder of that shape on the device (DataParallel replicas)
+        key = (int(n_views), tuple(int(g) for g in cos_n_group), int(L_3D), bool(legacy), str(self.device),
+               tuple((k, tuple(p.shape)) for k, p in zip(self.names, self.params)))
+        if key not in _DECODER_PLAN:
+            _DECODER_PLAN[key] = self._build_plan(n_views, cos_n_group, L_3D, legacy, prefix)
+        (self.zero_pos, self.cond_dim, self.cond_stride, self.total, self.frag_src, self.frag_dst, self.frag_tensor, self.word_src,
+         self.word_dst, self.hdr_dst, self.hdr_tensor) = _DECODER_PLAN[key]
+
+    def _build_plan(self, n_views, cos_n_group, L_3D, legacy, prefix):
         base, pos_sd = {}, {}
         off = 0
         for k, p in zip(self.names, self.params):
@@ -281,13 +291,10 @@ class DecoderPacker:
         word_dst.append(segs[-1][4] + np.arange(tail_words))
         assert segs[-1][0] == "tail"
         dev = self.device
-        self.frag_src = torch.from_numpy(np.concatenate(frag_src, 0).astype(np.int64)).to(dev)
-        self.frag_dst = torch.from_numpy(np.concatenate(frag_dst, 0).astype(np.int64)).to(dev)
-        self.frag_tensor = torch.from_numpy(np.concatenate(frag_tensor).astype(np.int64)).to(dev)
-        self.word_src = torch.from_numpy(np.concatenate(word_src).astype(np.int64)).to(dev)
-        self.word_dst = torch.from_numpy(np.concatenate(word_dst).astype(np.int64)).to(dev)
-        self.hdr_dst = torch.tensor(hdr_dst, dtype=torch.int64, device=dev)
-        self.hdr_tensor = torch.tensor(hdr_tensor, dtype=torch.int64, device=dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(dev)
+        return (self.zero_pos, self.cond_dim, self.cond_stride, self.total, t(np.concatenate(frag_src, 0)), t(np.concatenate(frag_dst, 0)),
+                t(np.concatenate(frag_tensor)), t(np.concatenate(word_src)), t(np.concatenate(word_dst)),
+                torch.tensor(hdr_dst, dtype=torch.int64, device=dev), torch.tensor(hdr_tensor, dtype=torch.int64, device=dev))
 
     def pack(self):
         """-> wstream (float32 words [total]) on the parameters' device; same bits as cond_nerf.pack_wstream_h."""
