@@ -437,6 +437,9 @@ def main():
         guarded("BASELINE config[4]", secondary_workload, device,
                 "BASELINE config[4]: 10 source views 512x640, 64 samples/ray (45 view pairs, 1.18 GB of feature maps), "
                 "full frame incl. encoder", 10, 64, 512, 640, False, seed=32)
+        guarded("config[1] at 256 samples per ray", secondary_workload, device,
+                "BASELINE config[1]'s frame at 256 samples per ray (configs/test_video_own.yaml: sample_intvs 256; "
+                "decoder_pp_kernel<256>), full frame incl. encoder", 3, 256, 512, 640, False)
         guarded("train_iteration, sample_intvs 64", train_step_workload, device, 64)
         guarded("train_iteration, sample_intvs 128 (configs/train.yaml)", train_step_workload, device, 128)
 

@@ -58,7 +58,7 @@ static mnerf_tuning read_tuning() {
   t.render_fused = env_int("MNERF_RENDER_FUSED", 0);  // 1: mnerf_render_chunk takes the one-launch form where it applies
   t.decoder_pp = env_int("MNERF_DECODER_PP", 1);
   t.decoder_pp_grid = env_int("MNERF_DECODER_PP_GRID", 256);
-  t.decoder_pp_max_s = env_int("MNERF_DECODER_PP_MAX_S", 128);
+  t.decoder_pp_max_s = env_int("MNERF_DECODER_PP_MAX_S", 256);
   return t;
 }
 

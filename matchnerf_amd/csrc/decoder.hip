@@ -1622,7 +1622,13 @@ __global__ __launch_bounds__(NW * 64, MNERF_DECODER_MINBLOCKS) void decoder_kern
 // and the 1-KiB headers (biases, weight scales) of all stages, so that a V phase can also load the next accumulators.
 // The conditioning rows of the next tile are copied to LDS during the tail phases (half of ring slot 1 per team).
 // Same arithmetic in the same order as decoder_kernel<.., 2, 0>: results are bit-identical (tests).
-// Scope: the shipped decoder shape (L_3D = 10, <= 32 conditioning inputs, S <= 128); anything else takes the kernel above.
+// Scope: the shipped decoder shape (L_3D = 10, <= 32 conditioning inputs, S <= 256); anything else takes the kernel above.
+// S in (128, 256] (round 5, `WIDE`): ONE ray per 256-sample tile, team A its samples 0..127, team B 128..255.  The trunk is per
+// sample; the tail meets across the teams: each team's ray attention reads its own 128 keys at once and the other team's when
+// that team's waves have all arrived at the sync behind their q|k|v phase (ray_attention_pp256: two key halves merged flash
+// style), and the whole ray is composited by team B's first wave once team A's densities are there.  No extra LDS: a team still
+// keeps only its own keys / values (in the 128-sample layout) and reads the other team's scratch in place; "arrived" is read off
+// the other team's monotonic sync counter (3 team syncs per tile for A, 4 for B), so the teams keep running their tails freely.
 #define PP_STAGES 12
 #define PP_PHASES 28
 struct PPSched {
@@ -1881,6 +1887,111 @@ __device__ __forceinline__ void ray_attention_pp(const float* q_lds, const float
   }
 }
 
+// Ray attention for S in (128, 256] (decoder_pp_kernel<256>): a ray spans BOTH teams — team A owns samples 0..127, team B 128..255 — so
+// a wave's 64 queries (of its own team) meet the keys in two halves of 128: k0 / vt0 = team A's scratch, k1 / vt1 = team B's, each in
+// the 128-sample layout of ray_attention_pp<128>.  Per half the arithmetic is that function's (scores of 4 keys per 4x4x1 group, four
+// partial maxima, numerators of a group pair in front of its output products); the halves are merged flash style: running maximum
+// m, sum l and un-normalised output o per head, the older part rescaled by 2^(m_old - m_new).  `first` is the half this team can
+// read at once (its own: the other team's q|k|v phase may still be running), `wait_other()` returns when the other half is there.
+template <bool PADDED, class Wait>
+__device__ __forceinline__ void ray_attention_pp256(const float* q_lds, const float* k0, const float* vt0, const float* k1,
+                                                    const float* vt1, float* o_lds, int a_hp, int s_q, int lane, int S, int first,
+                                                    Wait wait_other) {
+  constexpr int HS = 128, G = HS / 4;
+  // four parts = (half, head) in the order (first, h0), (first, h1), (other, h0), (other, h1): ONE copy of the code in a loop that is
+  // not unrolled (two heads' score sets — 128 registers each — must never be live together); the two heads' running (m, l, o)
+  // are selected by the part's parity.
+  float m0 = -3.0e38f, m1 = -3.0e38f, l0 = 0.f, l1 = 0.f;
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    if (it == 2) wait_other();
+    const int half = it < 2 ? first : 1 - first;
+    const int hsel = it & 1;
+    const int head = 2 * a_hp + hsel;
+    const float* kh = half == 0 ? k0 : k1;
+    const float* vh = half == 0 ? vt0 : vt1;
+    int n_keys = S - half * HS;  // valid keys of this half (PADDED: S < 256)
+    n_keys = n_keys < 0 ? 0 : (n_keys > HS ? HS : n_keys);
+    const float m_run = hsel ? m1 : m0, l_run = hsel ? l1 : l0;
+    const float4 q4 = *reinterpret_cast<const float4*>(q_lds + s_q * 16 + head * 4);
+    const float* kb = kh + (head * HS + (lane & 3)) * 4;
+    const float* vb = vh + (head * 4 + (lane & 3)) * HS;
+    f32x4 sc[G];
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+      const float4 ka = *reinterpret_cast<const float4*>(kb + g * 16);
+      const float4 kc = *reinterpret_cast<const float4*>(kb + g * 16 + 16);
+      f32x4 ta = mfma4(ka.x, q4.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+      f32x4 tc = mfma4(kc.x, q4.x, (f32x4){0.f, 0.f, 0.f, 0.f});
+      ta = mfma4(ka.y, q4.y, ta);
+      tc = mfma4(kc.y, q4.y, tc);
+      ta = mfma4(ka.z, q4.z, ta);
+      tc = mfma4(kc.z, q4.z, tc);
+      sc[g] = mfma4(ka.w, q4.w, ta);
+      sc[g + 1] = mfma4(kc.w, q4.w, tc);
+    }
+    float mx4[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    if constexpr (!PADDED) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx4[r] = fmaxf(mx4[r], sc[g][r]);
+    } else {
+      int s_keys = __builtin_amdgcn_readfirstlane(n_keys);  // wave-uniform; opaque: see decoder_kernel
+      asm volatile("" : "+s"(s_keys));
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (4 * g + r < s_keys) ? sc[g][r] : -3.0e38f;
+          sc[g][r] = v;
+          mx4[r] = fmaxf(mx4[r], v);
+        }
+    }
+    const float m_new = fmaxf(m_run, fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3])));
+    float ls4[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+      const float4 va = *reinterpret_cast<const float4*>(vb + 4 * g);
+      const float4 vc = *reinterpret_cast<const float4*>(vb + 4 * g + 4);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(sc[g + u][r] - m_new);
+          sc[g + u][r] = pr;
+          ls4[r] += pr;
+        }
+      oa = mfma4(va.x, sc[g][0], oa);
+      ob = mfma4(vc.x, sc[g + 1][0], ob);
+      oa = mfma4(va.y, sc[g][1], oa);
+      ob = mfma4(vc.y, sc[g + 1][1], ob);
+      oa = mfma4(va.z, sc[g][2], oa);
+      ob = mfma4(vc.z, sc[g + 1][2], ob);
+      oa = mfma4(va.w, sc[g][3], oa);
+      ob = mfma4(vc.w, sc[g + 1][3], ob);
+    }
+    // merge with what the other half left (first half: m_run = -3e38, l_run = o_run = 0: the factor is exp2(-huge) = 0)
+    const float f_old = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float l_new = l_run * f_old + ((ls4[0] + ls4[1]) + (ls4[2] + ls4[3]));
+    f32x4 o_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o_new[d] = (hsel ? o1[d] : o0[d]) * f_old + (oa[d] + ob[d]);
+    if (hsel) {
+      m1 = m_new, l1 = l_new, o1 = o_new;
+    } else {
+      m0 = m_new, l0 = l_new, o0 = o_new;
+    }
+  }
+  {
+    const float i0 = 1.0f / l0, i1 = 1.0f / l1;
+    *reinterpret_cast<float4*>(o_lds + s_q * 16 + (2 * a_hp) * 4) = make_float4(o0[0] * i0, o0[1] * i0, o0[2] * i0, o0[3] * i0);
+    *reinterpret_cast<float4*>(o_lds + s_q * 16 + (2 * a_hp + 1) * 4) = make_float4(o1[0] * i1, o1[1] * i1, o1[2] * i1, o1[3] * i1);
+  }
+}
+
 // FS: K16-steps of the FiLM stage = ceil(conditioning inputs / 16): 2 up to 5 source views (the shipped 3-view case), 3 for
 // 6-7, 4 for 8-11 (BASELINE config[4]: 10 views, 50 inputs).  Only the first stage, its operands and its place in the weight
 // stream depend on it; with FS > 2 a team's rows of the next tile (128 x cond_stride floats) no longer fit its half of ring
@@ -1913,7 +2024,11 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   const int team = wave >> 2, tw = wave & 3;
   const mnerf_rays& R = Rl;  // launch-wide fields (counts, sizes); the camera constants are read through Rt inside the tile loop
   const int S = R.n_samples;
-  const int rays_per_team = TEAM / Sp, rays_per_tile = 2 * rays_per_team;
+  // WIDE (SP = 256, round 5): ONE ray per tile — team A owns its samples 0..127, team B 128..255; the trunk is per sample and does not
+  // care, the tail meets across the teams (ray attention in two key halves, compositing of the whole ray by team B).
+  constexpr bool WIDE = SP == 256;
+  static_assert(!WIDE || (!POSES && FS == 2), "the 256-sample instance exists for the shipped shape without a pose table");
+  const int rays_per_team = WIDE ? 0 : TEAM / Sp, rays_per_tile = WIDE ? 1 : 2 * rays_per_team;
   const int n_tiles = (R.n_rays + rays_per_tile - 1) / rays_per_tile;
   const int CS = D.cond_stride;
   const float freq_mul = R.legacy_coord ? 1.0f : 3.14159265358979323846f;
@@ -1925,6 +2040,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   float* vt_lds = att + TEAM * 16;
   float* q_lds = att + TEAM * 32;
   float* o_lds = att + TEAM * 48;
+  // WIDE: the OTHER team's keys / values and arrival counter (a wave polls it where it needs the other team's phase to be over)
+  const float* k_other = smem + (team == 0 ? 2 : 3) * SEG_CAP_FLOATS;
+  const float* vt_other = k_other + TEAM * 16;
   // the team's conditioning rows of the NEXT tile: half of ring slot 1 (free between the views stage and layer 1 of the next tile)
   float* rows_lds = smem + 1 * SEG_CAP_FLOATS + team * 4096;
   const unsigned rows_lds_addr = ring_lds + (unsigned)(1 * SEG_CAP_FLOATS + team * 4096) * 4u;
@@ -1939,6 +2057,17 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   // this wave's team counter: LDS byte address and the number of arrivals it has made (wave-uniform)
   const unsigned team_ctr_lds = hdr_lds + (unsigned)(SM::HDR_FLOATS + SM::RS_FLOATS + 48 + team) * 4u;
   int team_epoch = 0;
+  const unsigned other_ctr_lds = hdr_lds + (unsigned)(SM::HDR_FLOATS + SM::RS_FLOATS + 48 + (1 - team)) * 4u;
+  int tile_it = 0;  // tiles this workgroup has finished (both teams count alike): the other team's arrival count is a function of it
+  auto wait_other_team = [&](int arrivals) {  // until the other team's waves have ALL made `arrivals` team syncs (wave_group_sync)
+    const int want = 4 * arrivals;
+    for (;;) {
+      unsigned v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(other_ctr_lds) : "memory");
+      if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - (unsigned)want) >= 0) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
   {
     const unsigned voff = (unsigned)lane0 * 16u;
     for (int p = wave; p < pp_stream_pieces(19); p += 8)
@@ -2224,8 +2353,8 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     const unsigned voff = (unsigned)lane * 16u;
     // ------------------------------------------------------------ per-lane sample identity
     const int s_local = tw * 32 + n;                  // sample within the team
-    const int ray_t = s_local / Sp;                   // ray within the team
-    const int jp = s_local - ray_t * Sp;
+    const int ray_t = WIDE ? 0 : s_local / Sp;        // ray within the team
+    const int jp = WIDE ? team * TEAM + s_local : s_local - ray_t * Sp;
     const int ray_raw = tile * rays_per_tile + team * rays_per_team + ray_t;
     const bool ray_ok = ray_raw < R.n_rays;
     const int ray = ray_ok ? ray_raw : (R.n_rays - 1);
@@ -2561,9 +2690,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     bool next_rows = false;
     if (FS == 2 && S == Sp && has_next) {
       const int first_ray = (tile + tile_step) * rays_per_tile + team * rays_per_team;
-      next_rows = first_ray + rays_per_team <= R.n_rays;
+      next_rows = WIDE ? first_ray < R.n_rays : first_ray + rays_per_team <= R.n_rays;
       if (next_rows) {
-        const float* src = cond + (size_t)first_ray * S * CS;
+        const float* src = cond + ((size_t)first_ray * S + (WIDE ? team * TEAM : 0)) * CS;
         const int pieces = (TEAM * CS) >> 8;  // CS is a multiple of 8: 128 rows = CS / 2 KiB
         for (int p = tw; p < pieces; p += 4) glds16_s_stream(src + p * 256, voff, __builtin_amdgcn_readfirstlane(rows_lds_addr + (unsigned)p * 1024u));
       }
@@ -2577,13 +2706,16 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int head = hl + 2 * hh;
-      *reinterpret_cast<float4*>(k_lds + ((ray_t * 4 + head) * Sp + jp) * 4) =
+      // (WIDE: a team's scratch holds ITS 128 samples in the 128-sample layout)
+      constexpr int SPT = WIDE ? TEAM : SP;
+      const int jt = WIDE ? s_local : jp;
+      *reinterpret_cast<float4*>(k_lds + ((ray_t * 4 + head) * SPT + jt) * 4) =
           make_float4(qkv[0][8 + 4 * hh], qkv[0][9 + 4 * hh], qkv[0][10 + 4 * hh], qkv[0][11 + 4 * hh]);
-      float* vcol = vt_lds + (ray_t * 4 + head) * 4 * Sp + jp;
+      float* vcol = vt_lds + (ray_t * 4 + head) * 4 * SPT + jt;
       vcol[0] = qkv[1][4 * hh];
-      vcol[Sp] = qkv[1][4 * hh + 1];
-      vcol[2 * Sp] = qkv[1][4 * hh + 2];
-      vcol[3 * Sp] = qkv[1][4 * hh + 3];
+      vcol[SPT] = qkv[1][4 * hh + 1];
+      vcol[2 * SPT] = qkv[1][4 * hh + 2];
+      vcol[3 * SPT] = qkv[1][4 * hh + 3];
       *reinterpret_cast<float4*>(q_lds + s_local * 16 + head * 4) =
           make_float4(qkv[0][4 * hh] * qs, qkv[0][4 * hh + 1] * qs, qkv[0][4 * hh + 2] * qs, qkv[0][4 * hh + 3] * qs);
     }
@@ -2592,7 +2724,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     {
       int a_ray, a_hp, a_jq;
       if constexpr (SP >= 64) {
-        constexpr int CH = SP / 64;
+        constexpr int CH = (WIDE ? TEAM : SP) / 64;  // WIDE: the team's 128 queries, as at SP = 128
         int idx = tw;
         const int chunk = idx % CH;
         idx /= CH;
@@ -2604,10 +2736,26 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         a_hp = lane >> 5;
         a_jq = lane & 31;
       }
-      if (S == Sp)
-        ray_attention_pp<SP, false>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
-      else
-        ray_attention_pp<SP, true>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
+      if constexpr (WIDE) {
+        // half 0 = team A's keys, half 1 = team B's.  A team reads its OWN half at once (its q|k|v phase ended at the team sync
+        // above) and the other half when the other team's waves have all arrived at the sync behind THEIR q|k|v phase: per tile
+        // team A makes 3 team syncs (behind T1, T2, T3), team B 4 (one more in front of T1).
+        const float* k0 = team == 0 ? k_lds : k_other;
+        const float* vt0 = team == 0 ? vt_lds : vt_other;
+        const float* k1 = team == 0 ? k_other : k_lds;
+        const float* vt1 = team == 0 ? vt_other : vt_lds;
+        const int other_t1 = team == 0 ? 4 * tile_it + 2 : 3 * tile_it + 1;
+        auto wait = [&]() { wait_other_team(other_t1); };
+        if (S == Sp)
+          ray_attention_pp256<false>(q_lds, k0, vt0, k1, vt1, o_lds, a_hp, a_jq, lane, S, team, wait);
+        else
+          ray_attention_pp256<true>(q_lds, k0, vt0, k1, vt1, o_lds, a_hp, a_jq, lane, S, team, wait);
+      } else {
+        if (S == Sp)
+          ray_attention_pp<SP, false>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
+        else
+          ray_attention_pp<SP, true>(q_lds, k_lds, vt_lds, o_lds, a_ray, a_hp, a_ray * Sp + a_jq, lane, S);
+      }
     }
     segment_wait();  // the team's rows of the next tile
     PP_TSYNC();
@@ -2674,7 +2822,12 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_TSYNC();
     // ============================================================ phase 27 = T4: compositing (one wavefront per ray)
     PP_TILE_RAYS(Rt);
-    for (int rt = tw; rt < rays_per_team; rt += 4) {
+    // WIDE: the tile's one ray is composited by team B's first wave, from both teams' halves of rs_all (contiguous: sample jp
+    // of the ray is entry jp), once team A's waves have arrived at the sync behind their T3 (their densities are written).
+    const int t4_rays = WIDE ? ((team == 1 && tw == 0) ? 1 : 0) : rays_per_team;
+    const float* rs_ray = WIDE ? rs_all : rs_lds;
+    if (WIDE && t4_rays) wait_other_team(3 * tile_it + 3);
+    for (int rt = WIDE ? 0 : tw; rt < t4_rays; rt += 4) {
       const int rr = tile * rays_per_tile + team * rays_per_team + rt;
       if (rr >= R.n_rays || !out_rgb) continue;
       float rlen = 1.0f;
@@ -2689,7 +2842,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
         float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
         float dd = 0.f;
         if (ok) {
-          c = reinterpret_cast<const float4*>(rs_lds)[rt * Sp + jj];
+          c = reinterpret_cast<const float4*>(rs_ray)[rt * Sp + jj];
           dd = sample_depth(Rt, rr, jj);
           if (!D.wo_render_interval) {
             const float intv = (jj + 1 < S) ? (sample_depth(Rt, rr, jj + 1) - dd) : 1e10f;
@@ -2746,6 +2899,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       }
     }
     rows_in_lds = next_rows;
+    ++tile_it;
     // Team A goes straight on to V_0 of its next tile (inputs from its own rows in LDS, no weights) and meets team B at the
     // end of that phase; team B's T4 ends at that same workgroup barrier, behind its wait for stage 0 of the next tile.
     if (team == 1) {
@@ -2907,8 +3061,9 @@ extern "C" int64_t mnerf_decoder_wstream_floats(int32_t cond_dim, int32_t cond_s
 #if MNERF_DECODER_PART == 0
 // Does the ping-pong form (decoder_pp_kernel) take this decoder at Sp padded samples?  -> its FiLM K16-step count (2 .. 4), or 0.
 static int pp_film_steps(const mnerf_decoder* dec, const DecSched& sch, int Sp) {
-  const int pp_max_s = mnerf_tune().decoder_pp_max_s < 128 ? mnerf_tune().decoder_pp_max_s : 128;
-  // FiLM stages of 2 K16-steps (<= 5 views) at every S; of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
+  const int pp_max_s = mnerf_tune().decoder_pp_max_s < 256 ? mnerf_tune().decoder_pp_max_s : 256;
+  // FiLM stages of 2 K16-steps (<= 5 views) at every S <= 256 (round 5: the 256-sample instance, one ray per tile across both teams);
+  // of 3 / 4 steps (6 .. 11 views) for S <= 64 (the instances that exist)
   const int fs = sch.film_steps;
   const bool f16 = dec->wstream_format == MNERF_WSTREAM_F16X2 || dec->wstream_format == MNERF_WSTREAM_F16X1;
   const bool ok = f16 && Sp > 0 && Sp <= pp_max_s && dec->L_3D == 10 &&
@@ -2999,8 +3154,8 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
                        ext_dir, *scn);                                                               \
   } while (0)
 #if MNERF_DECODER_PART == 0
-  // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream, S <= 128 (round 3: 82.3 vs
-  // 88.7 ms per 800x800 frame at 128 samples per ray; the knob can only LOWER the limit: there is no 256-sample instance)
+  // ---- ping-pong form (decoder_pp_kernel): the shipped decoder shape on the split-fp16 stream, S <= 256 (round 3: 82.3 vs
+  // 88.7 ms per 800x800 frame at 128 samples per ray; round 5: the 256-sample instance; the knob can only LOWER the limit)
   const int fs = fused_scene ? 0 : pp_film_steps(dec, sch, Sp);
   if (fs) {
     PPSched pps;
@@ -3036,8 +3191,9 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   } while (0)
 #define MNERF_LAUNCH_PP(SP_, FS_) MNERF_LAUNCH_PP_(SP_, FS_, false)
     if (dec->wstream_format == MNERF_WSTREAM_F16X1) {  // reduced-precision fast mode: the shipped shape only
-      MNERF_REQUIRE(fs == 2 && !poses, MNERF_E_UNSUPPORTED,
-                    "%s: the one-product fp16 mode (MNERF_WSTREAM_F16X1) is built for <= 5 source views without a pose table", who);
+      MNERF_REQUIRE(fs == 2 && !poses && Sp <= 128, MNERF_E_UNSUPPORTED,
+                    "%s: the one-product fp16 mode (MNERF_WSTREAM_F16X1) is built for <= 5 source views, sample_intvs <= 128, without a "
+                    "pose table", who);
 #define MNERF_LAUNCH_PP1(SP_)                                                                                          \
   do {                                                                                                                \
     const size_t lds = SmemPP<SP_>::TOTAL_FLOATS * sizeof(float);                                                     \
@@ -3071,8 +3227,10 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
       MNERF_LAUNCH_PP(32, 2);
     else if (Sp == 64)
       MNERF_LAUNCH_PP(64, 2);
-    else
+    else if (Sp == 128)
       MNERF_LAUNCH_PP(128, 2);
+    else  // 128 < S <= 256 (configs/test_video_own.yaml: sample_intvs 256)
+      MNERF_LAUNCH_PP(256, 2);
 #undef MNERF_LAUNCH_PP
 #undef MNERF_LAUNCH_PP_
     return mnerf_check_launch(who);
@@ -3102,7 +3260,8 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
     case 32: MNERF_LAUNCH_DECODER_FMT(4, 32); break;
     case 64: MNERF_LAUNCH_DECODER_FMT(4, 64); break;
     case 128: MNERF_LAUNCH_DECODER_FMT(4, 128); break;
-    default:  // 128 < S <= 256: one 8-wave workgroup per CU, VALU ray attention
+    default:  // 128 < S <= 256 when the ping-pong form does not apply (other stream formats, 6+ views, MNERF_DECODER_PP_MAX_S < 256):
+              // one 8-wave workgroup per CU, VALU ray attention
 #if MNERF_DECODER_PART == 1
       MNERF_REQUIRE(false, MNERF_E_UNSUPPORTED, "%s: the one-launch form needs sample_intvs <= 128", who);
 #else

@@ -7,6 +7,7 @@
 #   frames=C1,C2,..     tools/exp/frame_time.py per configuration (c2 c3 c5 s<N> demo); MNERF_LIB_VARIANTS="a b" runs every
 #                       configuration with libmnerf_hip.so and libmnerf_hip_<a>.so ... in turn (same-box A/B)  -> frames.log
 #   profile             tools/profile_round.sh TAG (kernel stats, bench trace, PMC passes, counter json files)
+#   config=CFG          tools/profile_config.sh TAG_CFG CFG (kernel stats + PMC of one secondary configuration: c3 c5 s256 ...)
 #   trace=SCRIPT[,ARG..] rocprofv3 --kernel-trace --stats over python tools/exp/SCRIPT ARGS -> SCRIPT_kernel_stats.md
 #                       (TRACE_PERIODS=K: only the last K periods between decoder launches, e.g. training iterations)
 #   py=SCRIPT[,ARG..]   python tools/exp/SCRIPT ARGS                           -> SCRIPT.log
@@ -39,6 +40,8 @@ PY
       done; done; done;;
     profile)
       bash tools/profile_round.sh $TAG; ls $O;;
+    config)
+      bash tools/profile_config.sh ${TAG}_$arg $arg | cut -c1-170;;
     trace)
       IFS=, read -r script rest <<< "$arg"
       R=$PWD; rm -rf /tmp/trace_$TAG; ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/trace_$TAG -o t -- python $R/tools/exp/$script ${rest//,/ } > $R/$O/${script%.py}_trace.log 2>&1 )

@@ -1,7 +1,8 @@
 """Small driver for rocprofv3 passes: `frames` full-frame renders (encoder + ray chunks) of one BASELINE configuration,
-no CPU baseline, no warm-up loop.   prof_render.py [frames] [c2 | c3 | c5]
+no CPU baseline, no warm-up loop.   prof_render.py [frames] [c2 | c3 | c5 | s<N>]
   c2 (default) BASELINE config[1]: 512x640, 3 views, 64 samples;  c3 config[2]: Blender-like 800x800, 128 samples, white
-  background;  c5 config[4]: 10 source views at 512x640."""
+  background;  c5 config[4]: 10 source views at 512x640;  s<N>: config[1]'s frame at N samples per ray (s256: the sample count
+  of configs/test_video_own.yaml, decoder_pp_kernel<256>)."""
 import os
 import sys
 
@@ -20,6 +21,9 @@ if cfg == "c3":
 elif cfg == "c5":
     opt, model, _ = bench.build_model(dev, 10, 64)
     _, batch = bench.make_batch(dev, 0, 512, 640, 10, seed=32)
+elif cfg.startswith("s"):
+    opt, model, _ = bench.build_model(dev, 3, int(cfg[1:]))
+    _, batch = bench.make_batch(dev, 0)
 else:
     opt, model, _ = bench.build_model(dev)
     _, batch = bench.make_batch(dev, 0)
