@@ -154,6 +154,14 @@ def test_long_rays_full_launch_is_reproducible_and_matches_oracle(hip, S):
         assert torch.equal(a, b)
     assert linf(old[0], first[0]) < 5e-5 and linf(old[2], first[2]) < 5e-5 and linf(old[1], first[1]) < 3e-4
     assert linf(old[0][1024:1280], ref[0]) < 1e-4
+    # per-sample colours / densities of the two kernels (the outputs CondNeRF.forward hands back), a ragged launch of 1 001 rays
+    rays_s = make_rays_struct(cfg, batch, 1001, ray_begin=333)
+    cond_s = hip.cost_volume(sc, rays_s, dec.cond_stride)
+    new_s = hip.decoder_chunk(dec, sc.views[0], rays_s, cond_s, want_samples=True)
+    with hip.knob("decoder_pp_max_s", 128):
+        old_s = hip.decoder_chunk(dec, sc.views[0], rays_s, cond_s, want_samples=True)
+    assert linf(new_s[3], old_s[3]) < 5e-5 and linf(new_s[4], old_s[4]) < 5e-5 * max(1.0, float(old_s[4].abs().max()))
+    assert linf(new_s[0], old_s[0]) < 5e-5
 
 
 def test_other_kernels_next_to_the_f16_decoder_on_a_second_stream():
