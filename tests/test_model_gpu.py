@@ -291,6 +291,25 @@ def test_demo_own_yaml_renders_the_reference_scene_from_disk(tmp_path, monkeypat
     assert np.abs(frames[int(g["video_frames"][0])].astype(int) - want.astype(int)).max() <= 1
 
 
+def test_video_own_yaml_at_256_samples_runs_the_wide_ping_pong_decoder(tmp_path, monkeypatch):
+    """configs/test_video_own.yaml (sample_intvs 256, attn_splits 4, IBRNet switches, the reference's scene at 960 x 640) through
+    test.py with three poses: decoder_pp_kernel<256> (round 5) against the round-2 kernel it replaces (behind the knob) on real
+    data with density_maskfill / raytrans_posenc / ELU on: the same frames within the parity gate."""
+    import os
+    import test as entry
+    from conftest import GOLDEN
+    from matchnerf_amd import hip
+    monkeypatch.chdir(tmp_path)
+    argv = ["--yaml=test_video_own", f"--data_test.colmap.root_dir={os.path.join(GOLDEN, 'demo_data')}", "--data_test.colmap.num_workers=0",
+            "--data_test.tnt=", f"--output_root={tmp_path}", "--load=", "--nerf.video_n_frames=3"]
+    new = entry.run(argv)["colmap"]
+    assert new.shape == (3, 640, 960, 3) and new.dtype == np.uint8
+    with hip.knob("decoder_pp_max_s", 128):
+        old = entry.run(argv)["colmap"]
+    assert np.abs(new.astype(int) - old.astype(int)).max() <= 1
+    assert len({int(f.astype(np.int64).sum()) for f in new}) == 3
+
+
 def test_two_same_shaped_batches_do_not_share_launch_context():
     """the per-source-set launch context (host cameras + RGBA source images) must never survive from
     one batch to the next.  Batch A is rendered and FREED, batch B of the same shape is then allocated (the caching
