@@ -37,7 +37,9 @@ Also in the JSON line (N = 1):
                 roofline.frame: the step as a whole and its render kernels in rays/s against the matrix-path bound and
                 the vector-L1 tap bound (measured tap bytes per ray); every fraction in the line is <= 1.
   config        secondary workloads timed outside the timed region: BASELINE config[2] (Blender-like
-                800x800, 128 samples/ray) and config[4] (10 source views, 512x640).
+                800x800, 128 samples/ray), config[4] (10 source views, 512x640), config[1]'s frame at 256 samples per ray
+                (decoder_pp_kernel<256>) and a full Coach.train_iteration (forward, backward, clipping, AdamW step) at 64
+                and at the reference's training 128 samples per ray.
   cpu_baseline  the CPU oracle (a port of the reference path, pinned to it by goldens) timed on this
                 host's cores: one encoder pass + one full 4096-ray chunk, best of 3.
 """
