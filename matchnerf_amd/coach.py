@@ -133,15 +133,46 @@ class Coach:
 
     @torch.no_grad()
     def test_model_video(self, **kwargs):
-        """coach.py:455-529 without the encoders: returns {dataset: frames [F,H,W,3] uint8}."""
+        """coach.py:455-529: every batch of every test set rendered along its video path (dtu / blender / colmap-by-config:
+        interpolate, llff: spiral; white background for blender), written under <output_path>/test_videos/<set>/ as the reference
+        names them: `<scene>_view<tgt>_src<ids>.gif` at 12 fps when nerf.save_gif, `..._f<i>.jpg` frames when nerf.save_frames, and
+        the strip of source views `<name>.jpg` (PIL instead of imageio; the reference's .mp4 needs scikit-video / ffmpeg, neither in
+        this image, and is skipped).  Returns {set: frames [F,H,W,3] uint8 of its FIRST batch element}."""
+        from PIL import Image
         self.model.eval()
+        out_root = os.path.join(self.opts.output_path, "test_videos")
         videos = {}
         for loader in self.test_loaders:
-            mode = getattr(getattr(self.opts.data_test, loader.get_name(), {}), "render_path_mode", "interpolate")
+            name = loader.get_name()
+            out_dir = os.path.join(out_root, name)
+            os.makedirs(out_dir, exist_ok=True)
+            if name == "llff":
+                mode = "spiral"
+            elif name == "colmap":
+                mode = getattr(getattr(self.opts.data_test, "colmap", {}), "render_path_mode", "interpolate")
+            else:  # dtu, blender (and the other sets the reference has no video rule for)
+                mode = "interpolate"
+            self.model.nerf_setbg_opaque = (name == "blender")
+            n_frames = int(self.opts.nerf.video_n_frames)
             for batch in loader:
                 var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
                 var = self.model(var, mode="test", render_video=True, render_path_mode=mode)
-                _, _, _, h, w = var.images.shape
-                videos[loader.get_name()] = (var.rgb.reshape(-1, h, w, 3).clamp(0, 1) * 255).to(torch.uint8).numpy()
-                break
+                b, _, _, h, w = var.images.shape
+                # forward returns the reference's frame-major layout [n_frames * B, HW, 3]
+                frames = (var.rgb.reshape(n_frames, b, h, w, 3).clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()
+                for bi in range(b):
+                    clip = frames[:, bi]
+                    videos.setdefault(name, clip)
+                    ids = [int(x) for x in batch["view_ids"][bi]] if "view_ids" in batch else list(range(self.n_src_views + 1))
+                    scene = batch["scene"][bi] if "scene" in batch else f"scene{bi}"
+                    stem = f"{scene}_view{ids[-1]:02d}_src" + "_".join(f"{x:02d}" for x in ids[:self.n_src_views])
+                    if getattr(self.opts.nerf, "save_frames", False):
+                        for fi, fr in enumerate(clip):
+                            Image.fromarray(fr).save(os.path.join(out_dir, f"{stem}_f{fi}.jpg"))
+                    if getattr(self.opts.nerf, "save_gif", False):
+                        imgs = [Image.fromarray(fr) for fr in clip]
+                        imgs[0].save(os.path.join(out_dir, f"{stem}.gif"), save_all=True, append_images=imgs[1:], duration=1000 // 12, loop=0)
+                    src = (var.images[bi, :self.n_src_views].permute(0, 2, 3, 1).cpu().numpy() * 255).astype("uint8")
+                    Image.fromarray(np.concatenate(list(src), axis=1)).save(os.path.join(out_dir, f"{stem}.jpg"))
+            self.model.nerf_setbg_opaque = False
         return videos

@@ -289,6 +289,15 @@ def test_demo_own_yaml_renders_the_reference_scene_from_disk(tmp_path, monkeypat
     assert frames.shape == (24, 160, 256, 3) and frames.dtype == np.uint8
     want = (torch.from_numpy(g["video_rgb"][0]).reshape(160, 256, 3).clamp(0, 1) * 255).to(torch.uint8).numpy()
     assert np.abs(frames[int(g["video_frames"][0])].astype(int) - want.astype(int)).max() <= 1
+    # what the reference's test_model_video leaves on disk (coach.py:507-527), under its names: the GIF (nerf.save_gif) and
+    # the strip of source views; no per-frame files (nerf.save_frames is off in this yaml)
+    from PIL import Image
+    out_dir = tmp_path / "test_video" / "demo" / "test_videos" / "colmap"
+    with Image.open(out_dir / "printer_view00_src02_01_00.gif") as im:
+        assert im.n_frames == 24 and im.size == (256, 160)
+    with Image.open(out_dir / "printer_view00_src02_01_00.jpg") as im:
+        assert im.size == (3 * 256, 160)
+    assert not list(out_dir.glob("*_f0.jpg"))
 
 
 def test_video_own_yaml_at_256_samples_runs_the_wide_ping_pong_decoder(tmp_path, monkeypatch):
