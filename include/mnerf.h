@@ -33,6 +33,9 @@
  *       mnerf_window_attention_backward_stats.
  *   v8  no layout change: mnerf_decoder.wstream_format accepts MNERF_WSTREAM_F16X1 (one-product fp16 fast mode); pose tables at
  *       sample_intvs <= 128 (was 64); mnerf_debug_set_knob serialised with the launches' reads.
+ *   v9  mnerf_scene gained feat_op (appended: the offsets of the older fields are unchanged, sizeof grows by 8): the split-fp16
+ *       OPERAND IMAGE of the feature maps that the matrix form of the cost volume reads (mnerf_cost_volume_operands,
+ *       mnerf_cost_volume_operand_bytes).  NULL keeps the segment walk.
  */
 #ifndef MNERF_H_
 #define MNERF_H_
@@ -43,7 +46,7 @@
 extern "C" {
 #endif
 
-#define MNERF_ABI_VERSION 8
+#define MNERF_ABI_VERSION 9
 #define MNERF_MAX_VIEWS 16
 #define MNERF_FEAT_CH 128 /* channels of one pair-specific GMFlow feature map */
 /* floats per sample of a `cond` buffer: sum(cos_n_group) + 4 n_views + 1, rounded up to a multiple of 8.
@@ -112,6 +115,12 @@ typedef struct mnerf_scene {
   const float* feat[2];
   const float* images;
   mnerf_view views[MNERF_MAX_VIEWS];
+  /* ABI v9: operand image of feat[] for the MATRIX FORM of the cost volume (mnerf_cost_volume_operands below), or NULL.
+   * With it, mnerf_cost_volume / mnerf_render_chunk interpolate the 128 channels of every (pair, scale) on the matrix pipe
+   * (v_mfma_f32_32x32x16_f16, split-fp16 operands) for launches over contiguous pixels of one pose (ray_idx == NULL, no pose
+   * table); every other launch, and a NULL pointer, takes the segment walk on feat[] - which must stay valid either way
+   * (the backward kernels and the walk read it). */
+  const void* feat_op;
 } mnerf_scene;
 
 /* Decoder parameters, pre-packed by the host (matchnerf_amd/cond_nerf.py):
@@ -183,6 +192,17 @@ int mnerf_composite(int32_t n_rays, int32_t n_samples, const float* rgb_s, const
  * bias column of the packed FiLM layer). */
 int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* rays, int32_t cond_stride,
                       float* cond, void* stream);
+
+/* ABI v9 — operand image for the matrix form of K1+K2: the feature maps of scene->feat[] re-laid for the matrix pipe, once per
+ * source set (two launches, ~0.1 ms at 3 views of 512x640; enqueue-only).  Every fp32 texel x becomes two fp16 terms of 2^e x
+ * (one power-of-two gain per map, taken from the map's largest magnitude, so that the cosine - which is scale-free per map -
+ * is unchanged); texels are stored in aligned 2-row x 4-column cells, channel-tile-major, so that the 16 texels of a 4 x 4
+ * chunk are the K dimension of one v_mfma_f32_32x32x16_f16 A operand per 32 channels, read with fully coalesced 16-byte loads
+ * (layout: matchnerf_amd/csrc/cost_volume_mm.hip).  `opnd`: caller-owned, 16-byte aligned, mnerf_cost_volume_operand_bytes(scene)
+ * bytes (about the size of the fp32 maps); scene->feat_op is ignored by both functions.  Replaces nothing in the reference: it
+ * is the layout change that lets sample_features_by_grid (models/gmflow/utils.py:131-134) run as a matrix product. */
+int64_t mnerf_cost_volume_operand_bytes(const mnerf_scene* scene);
+int mnerf_cost_volume_operands(const mnerf_scene* scene, void* opnd, void* stream);
 
 /* K3+K4+K5 — conditional radiance MLP, per-ray transformer and compositing for one chunk.
  * Replaces CondNeRF.forward (models/rfdecoder/cond_nerf.py:52-100), MultiHeadAttention

@@ -50,6 +50,8 @@ static mnerf_tuning read_tuning() {
   t.decoder_stagger = env_int("MNERF_DECODER_STAGGER", 16);     // ~130k cycles ~ half a tile
   t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 5 = texel tiles in LDS (slower, kept: cost_volume.hip); 0 = plain
+  t.cv_mm = env_int("MNERF_CV_MM", 1);            // matrix form of the cost volume where it applies (cost_volume_mm.hip)
+  t.cv_mm_spw = env_int("MNERF_CV_MM_SPW", 4);
   t.cv_uvpair = env_int("MNERF_CV_UVPAIR", -1);
   t.cv_pair_block = env_int("MNERF_CV_PAIR_BLOCK", 8);
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
@@ -79,7 +81,7 @@ extern "C" int mnerf_debug_set_knob(const char* name, int value, int* old_value)
   struct Knob { const char* name; int* slot; };
   const Knob knobs[] = {{"decoder_pp", &g_tuning.decoder_pp}, {"decoder_pp_grid", &g_tuning.decoder_pp_grid},
                         {"decoder_pp_max_s", &g_tuning.decoder_pp_max_s}, {"decoder_grid", &g_tuning.decoder_grid},
-                        {"cv_variant", &g_tuning.cv_variant}, {"cv_uvpair", &g_tuning.cv_uvpair}, {"cv_pair_block", &g_tuning.cv_pair_block}, {"cv_grid", &g_tuning.cv_grid},
+                        {"cv_variant", &g_tuning.cv_variant}, {"cv_mm", &g_tuning.cv_mm}, {"cv_mm_spw", &g_tuning.cv_mm_spw}, {"cv_uvpair", &g_tuning.cv_uvpair}, {"cv_pair_block", &g_tuning.cv_pair_block}, {"cv_grid", &g_tuning.cv_grid},
                         {"render_fused", &g_tuning.render_fused}};
   for (const Knob& k : knobs)
     if (name && strcmp(name, k.name) == 0) {

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "decoder.hip", "decoder_backward.hip", "decoder_fused", "encoder_backward.hip", "encoder_block.hip",
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "cost_volume_mm.hip", "decoder.hip", "decoder_backward.hip", "decoder_fused", "encoder_backward.hip", "encoder_block.hip",
            "geometry.hip", "instance_norm.hip", "qkv.hip", "render_chunk.hip", "window_attention.hip", "window_attention_backward.hip"]
 # objects that are a second compilation of another source: object name -> (source, extra flags).
 # decoder_fused: the one-launch ray chunk (decoder.hip, MNERF_DECODER_PART=1).  Its workgroups run the cost-volume walk on
@@ -24,7 +24,7 @@ DERIVED = {"decoder_fused": ("decoder.hip", ["-DMNERF_DECODER_PART=1"])}
 # decoder.hip (both parts): the same flag — the two forms of the ray chunk are bit-identical only if their trunks are
 # compiled alike, and the trunk's own packed multiplies sat next to the partner workgroup's matrix instructions too;
 # measured neutral (19.60 vs 19.75 ms per frame).
-EXTRA_FLAGS = {"cost_volume.hip": ["-fno-slp-vectorize"], "decoder.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"cost_volume.hip": ["-fno-slp-vectorize"], "cost_volume_mm.hip": ["-fno-slp-vectorize"], "decoder.hip": ["-fno-slp-vectorize"]}
 DECODER_SOURCES = ["decoder.hip", "split_f16.hpp", "cv_walk.hpp", "common.hpp"]  # what decoder_kernel is compiled from
 # -amdgpu-use-amdgpu-trackers: the AMDGPU register-pressure trackers in the scheduler; the fused decoder spills 57 instead
 # of 108 vector registers with them (decoder 20.8 -> 20.15 ms per frame on MI355X), everything else is unchanged
@@ -59,7 +59,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-COST_VOLUME_SOURCES = ["cost_volume.hip", "cv_walk.hpp", "common.hpp"]  # what cost_volume_lean_kernel is compiled from
+COST_VOLUME_SOURCES = ["cost_volume.hip", "cost_volume_mm.hip", "cv_walk.hpp", "common.hpp"]  # what cost_volume_lean_kernel is compiled from
 
 
 def cost_volume_source_hash():

@@ -37,13 +37,15 @@ struct mnerf_tuning {
   int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
   int cv_pair_block;  // MNERF_CV_PAIR_BLOCK (default 8): view pairs per launch of the many-view cost volume (0: all in one)
+  int cv_mm;      // MNERF_CV_MM (default 1): the matrix form of the cost volume (cost_volume_mm.hip) where it applies (scene->feat_op given, contiguous pixels)
+  int cv_mm_spw;  // MNERF_CV_MM_SPW (default 4): samples per wave and work item of the matrix form (an item = one 8x4-pixel tile x 4 x spw samples)
   int cv_uvpair;  // MNERF_CV_UVPAIR (default -1 = by LDS footprint): 1 / 0 force the per-pair projection scratch of the walk on / off
   int wa_min4;
   int wa_xcd;  // pre-split window attention: all query blocks of a window on one XCD (1) or launch order (0)
   int render_fused;  // MNERF_RENDER_FUSED (default 0): 1 = mnerf_render_chunk uses the one-launch form where it applies
   int decoder_pp;       // MNERF_DECODER_PP (default 1): the ping-pong form of the split-fp16 decoder where it applies
   int decoder_pp_grid;  // MNERF_DECODER_PP_GRID (default 256): its persistent grid, one 8-wave workgroup per CU
-  int decoder_pp_max_s; // MNERF_DECODER_PP_MAX_S (default 128, values above 128 are clamped): largest padded sample count per ray that takes the ping-pong form
+  int decoder_pp_max_s; // MNERF_DECODER_PP_MAX_S (default 256, values above 256 are clamped): largest padded sample count per ray that takes the ping-pong form
 };
 mnerf_tuning mnerf_tune();  // a snapshot (api.cpp: copied under the table lock)
 // true exactly once per (mask, current HIP device): guards hipFuncSetAttribute, which is per device
@@ -53,6 +55,8 @@ int mnerf_scene_check(const mnerf_scene* sc, const mnerf_rays* rays, const char*
 // fused ray-chunk form (decoder.hip), used by mnerf_render_chunk (render_chunk.hip)
 bool mnerf_fused_render_applies(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays);
 bool mnerf_cost_volume_takes_pose_table(const mnerf_scene* sc);                 // cost_volume.hip
+bool mnerf_cost_volume_mm_applies(const mnerf_scene* sc, const mnerf_rays* rays);  // cost_volume_mm.hip
+int mnerf_cost_volume_mm_launch(const mnerf_scene* sc, const mnerf_rays* rays, int cond_stride, float* cond, void* stream);
 bool mnerf_decoder_takes_pose_table(const mnerf_decoder* dec, int n_samples);   // decoder.hip
 int mnerf_fused_render_launch(const mnerf_scene* sc, const mnerf_decoder* dec, const mnerf_rays* rays, float* rgb,
                               float* depth, float* opacity, void* stream);

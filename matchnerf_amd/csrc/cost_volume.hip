@@ -559,6 +559,8 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
                 "mnerf_cost_volume: cond_stride=%d < cond_dim+1=%d", cond_stride,
                 sumG + 4 * scene->n_views + 1);
   if (rays->n_rays == 0) return MNERF_OK;
+  if (mnerf_tune().cv_mm && mnerf_cost_volume_mm_applies(scene, rays))  // matrix form (cost_volume_mm.hip)
+    return mnerf_cost_volume_mm_launch(scene, rays, cond_stride, cond, stream);
   const bool poses = rays->pose_table != nullptr;
   if (poses) {
     MNERF_REQUIRE(rays->rays_per_pose > 0 && rays->rays_per_pose % 64 == 0, MNERF_E_RANGE,

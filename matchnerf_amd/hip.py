@@ -14,7 +14,7 @@ import os
 
 import numpy as np
 
-MNERF_ABI_VERSION = 8
+MNERF_ABI_VERSION = 9
 MNERF_POSE_FLOATS = 24  # floats of one row of mnerf_rays.pose_table
 MNERF_OK, MNERF_E_NULL, MNERF_E_RANGE, MNERF_E_UNSUPPORTED, MNERF_E_ALIGN = 0, -1, -2, -3, -4  # include/mnerf.h
 MNERF_MAX_VIEWS = 16
@@ -25,6 +25,7 @@ _LIB = None
 _LIB_PATH = os.environ.get("MNERF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmnerf_hip.so")
 
 EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_ray_samples", "mnerf_composite", "mnerf_cost_volume",
+           "mnerf_cost_volume_operand_bytes", "mnerf_cost_volume_operands",
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
@@ -52,7 +53,7 @@ class Rays(C.Structure):
 class Scene(C.Structure):
     _fields_ = [("n_views", C.c_int32), ("n_scales", C.c_int32), ("fh", C.c_int32 * 2), ("fw", C.c_int32 * 2),
                 ("n_group", C.c_int32 * 2), ("feat", C.c_void_p * 2), ("images", C.c_void_p),
-                ("views", View * MNERF_MAX_VIEWS)]
+                ("views", View * MNERF_MAX_VIEWS), ("feat_op", C.c_void_p)]
 
 
 class Decoder(C.Structure):
@@ -143,6 +144,10 @@ def load():
     lib.mnerf_cost_volume_backward.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, fp, fp, vp]
     lib.mnerf_cost_volume.restype = C.c_int
     lib.mnerf_cost_volume.argtypes = [C.POINTER(Scene), C.POINTER(Rays), i32, fp, vp]
+    lib.mnerf_cost_volume_operand_bytes.restype = i64
+    lib.mnerf_cost_volume_operand_bytes.argtypes = [C.POINTER(Scene)]
+    lib.mnerf_cost_volume_operands.restype = C.c_int
+    lib.mnerf_cost_volume_operands.argtypes = [C.POINTER(Scene), vp, vp]
     lib.mnerf_debug_set_knob.restype = C.c_int
     lib.mnerf_debug_set_knob.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     lib.mnerf_decoder_backward_workspace_bytes.restype = i64
@@ -478,6 +483,28 @@ def cost_volume(scene, rays, cond_stride, out=None, device=None, stream=None):
     with _on(out.device, stream) as st:
         check(lib.mnerf_cost_volume(C.byref(scene), C.byref(rays), int(cond_stride), _ptr(out), st),
               "mnerf_cost_volume")
+    return out
+
+
+def cost_volume_operand_bytes(scene):
+    """Bytes of the operand image of a scene's feature maps (mnerf_cost_volume_operands)."""
+    n = int(load().mnerf_cost_volume_operand_bytes(C.byref(scene)))
+    if n < 0:
+        raise MnerfError("mnerf_cost_volume_operand_bytes: unsupported scene")
+    return n
+
+
+def cost_volume_operands(scene, out=None, device=None, stream=None):
+    """The split-fp16 operand image of ``scene.feat`` for the matrix form of the cost volume (ABI v9): returns the uint8
+    tensor that holds it and points ``scene.feat_op`` at it.  The caller keeps the tensor alive as long as the scene is used."""
+    import torch
+    lib = load()
+    n = cost_volume_operand_bytes(scene)
+    if out is None or out.numel() < n:
+        out = torch.empty(n, dtype=torch.uint8, device=torch.device(device) if device is not None else _current_device())
+    with _on(out.device, stream) as st:
+        check(lib.mnerf_cost_volume_operands(C.byref(scene), out.data_ptr(), st), "mnerf_cost_volume_operands")
+    scene.feat_op = out.data_ptr()
     return out
 
 

@@ -62,6 +62,8 @@ class MatchNeRF(torch.nn.Module):
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
         self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
         self.pose_batching = os.environ.get("MNERF_POSE_BATCHING", "1") != "0"  # video of small frames: several poses per launch
+        self.cv_matrix_form = os.environ.get("MNERF_CV_MM", "1") != "0"  # full-frame renders: the cost volume on the matrix pipe
+        self._cv_ops = None
 
     def _dec(self):
         """the CondNeRF module, also when the reference's coach wrapped it in nn.DataParallel (coach.py:83-85)"""
@@ -70,6 +72,7 @@ class MatchNeRF(torch.nn.Module):
     # ------------------------------------------------------------------ forward (matchnerf.py:32-73)
     def forward(self, batch, mode=None, render_video=False, render_path_mode="interpolate"):
         self._frame = None  # the launch context below never outlives one forward (see _frame_ctx)
+        self._cv_ops = None
         ref_images = batch.images[:, :self.n_src_views]
         ref_feats_list = self.get_img_feat(ref_images, attn_splits_list=self.opts.encoder.attn_splits_list,
                                            cur_n_src_views=self.n_src_views)
@@ -218,6 +221,24 @@ class MatchNeRF(torch.nn.Module):
             sc.views[v] = hip.make_view(ex[b, v], it[b, v], nf[b, v, 0], nf[b, v, 1])
         return sc
 
+    def _scene_mm(self, b, ref_poses_host, ref_feats_list, images_cl):
+        """``_scene`` + the split-fp16 operand image of the feature maps (``hip.cost_volume_operands``, ABI v9) that the matrix
+        form of the cost volume reads: built once per source set and batch element (two short launches, ~the bytes of the maps),
+        shared by every pose and ray chunk rendered from it.  Keyed on the identity and version of the maps; the entry holds the
+        maps themselves (see ``_frame_ctx`` for why) and ``forward`` drops it at its top.  MNERF_CV_MM=0 keeps the walk."""
+        sc = self._scene(b, ref_poses_host, ref_feats_list, images_cl)
+        if not self.cv_matrix_form:
+            return sc
+        key = tuple((f.data_ptr(), f._version, tuple(f.shape)) for f in ref_feats_list)
+        if self._cv_ops is None or self._cv_ops[0] != key:
+            self._cv_ops = (key, {}, list(ref_feats_list))
+        ops = self._cv_ops[1]
+        if b not in ops:
+            ops[b] = hip.cost_volume_operands(sc, device=ref_feats_list[0].device)
+        else:
+            sc.feat_op = ops[b].data_ptr()
+        return sc
+
     def _decoder(self, n_samples, device):
         return self._dec().decoder_struct(n_samples, device, self.nerf_setbg_opaque)
 
@@ -288,7 +309,8 @@ class MatchNeRF(torch.nn.Module):
         depth = torch.empty(batch_size, n_rays, 1, device=device)
         opacity = torch.empty(batch_size, n_rays, 1, device=device)
         for b in range(batch_size):
-            sc = self._scene(b, ref_host, ref_feats_list, images_cl)
+            sc = self._scene(b, ref_host, ref_feats_list, images_cl) if idx32 is not None else \
+                self._scene_mm(b, ref_host, ref_feats_list, images_cl)
             kinv, c2w = camera.target_ray_consts(tgt_ex[b], tgt_in[b], legacy)
             strat = torch.rand(n_rays, n_samples, device=device) if stratified else None
             for c in range(0, n_rays, chunk):
