@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256, CV_WAVES_PER_SIMD) void cost_volume_kernel(mne
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
       if (live) {
-        out[sumG + 3 * v + 0] = t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11;
-        out[sumG + 3 * v + 1] = t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11;
-        out[sumG + 3 * v + 2] = t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11;
+        out[sumG + 3 * v + 0] = bilin4(t00.x, t01.x, t10.x, t11.x, b);
+        out[sumG + 3 * v + 1] = bilin4(t00.y, t01.y, t10.y, t11.y, b);
+        out[sumG + 3 * v + 2] = bilin4(t00.z, t01.z, t10.z, t11.z, b);
         out[sumG + 3 * V + v] = m;
       }
     }

@@ -137,24 +137,6 @@ __global__ __launch_bounds__(256) void cvm_split_kernel(mnerf_scene sc, char* __
 }
 
 // ============================================================================ the kernel
-// wave-uniform minimum / maximum of a per-lane int: row all-reduce with DPP, the four rows through scalar registers
-template <bool MAX>
-__device__ __forceinline__ int cvm_wave_minmax(int v) {
-#define CVM_MM_STEP(CTRL)                                                        \
-  {                                                                              \
-    const int t = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);      \
-    v = MAX ? max(v, t) : min(v, t);                                             \
-  }
-  CVM_MM_STEP(0xB1)   // quad_perm [1,0,3,2]
-  CVM_MM_STEP(0x4E)   // quad_perm [2,3,0,1]
-  CVM_MM_STEP(0x141)  // row_half_mirror
-  CVM_MM_STEP(0x140)  // row_mirror
-#undef CVM_MM_STEP
-  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
-            d = __builtin_amdgcn_readlane(v, 48);
-  return MAX ? max(max(a, b), max(c, d)) : min(min(a, b), min(c, d));
-}
-
 // v_permlane32_swap: upper half of a <-> lower half of b
 __device__ __forceinline__ void cvm_swap32(float& a, float& b) {
   asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));
@@ -166,10 +148,10 @@ __device__ __forceinline__ float cvm_fold_pair(float x, float y) {
   return x + y;
 }
 
-// bilinear footprint of one ray in one map: top-left texel and the four weights as two packed fp16 pairs (row y0 / row y0 + 1:
-// (weight of x0, weight of x0 + 1)), hi and lo terms.  bilin_setup()'s arithmetic (cv_walk.hpp).
+// bilinear footprint of one ray in one map: top-left texel (xy = y0 << 16 | x0) and the four weights as two packed fp16 pairs
+// (row y0 / row y0 + 1: (weight of x0, weight of x0 + 1)), hi and lo terms.  bilin_setup()'s arithmetic (cv_walk.hpp).
 struct CvmTap {
-  int x0, y0;
+  unsigned xy;
   unsigned top_hi, bot_hi, top_lo, bot_lo;
 };
 
@@ -177,10 +159,19 @@ __device__ __forceinline__ unsigned cvm_pack_h2(float a, float b) {
   const cvm_f2 ab = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(ab, cvm_h2));  // v_cvt_pk_f16_f32 (RNE)
 }
-__device__ __forceinline__ float cvm_h_lo(unsigned p) { return (float)__builtin_bit_cast(cvm_h2, p).x; }
-__device__ __forceinline__ float cvm_h_hi(unsigned p) { return (float)__builtin_bit_cast(cvm_h2, p).y; }
+// w - half(hpk.lo16 / hi16) in one v_fma_mix_f32 (split_f16.hpp: resid_lo / resid_hi)
+__device__ __forceinline__ float cvm_resid_lo(float v, unsigned hpk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpk));
+  return r;
+}
+__device__ __forceinline__ float cvm_resid_hi(float v, unsigned hpk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(v), "v"(hpk));
+  return r;
+}
 
-__device__ __forceinline__ CvmTap cvm_tap(float u, float v, int h, int w) {
+__device__ __forceinline__ CvmTap cvm_tap(float u, float v, int h, int w, int& x0, int& y0) {
   const float gx = u * 2.0f - 1.0f, gy = v * 2.0f - 1.0f;
   float x = ((gx + 1.0f) * 0.5f) * (float)(w - 1);
   float y = ((gy + 1.0f) * 0.5f) * (float)(h - 1);
@@ -190,112 +181,211 @@ __device__ __forceinline__ CvmTap cvm_tap(float u, float v, int h, int w) {
   const float fx = x - x0f, fy = y - y0f;
   const float w00 = (1.0f - fx) * (1.0f - fy), w01 = fx * (1.0f - fy), w10 = (1.0f - fx) * fy, w11 = fx * fy;
   CvmTap t;
-  t.x0 = (int)x0f;
-  t.y0 = (int)y0f;
+  x0 = (int)x0f;
+  y0 = (int)y0f;
+  t.xy = ((unsigned)y0 << 16) | (unsigned)x0;
   t.top_hi = cvm_pack_h2(w00, w01);
   t.bot_hi = cvm_pack_h2(w10, w11);
-  t.top_lo = cvm_pack_h2(w00 - cvm_h_lo(t.top_hi), w01 - cvm_h_hi(t.top_hi));
-  t.bot_lo = cvm_pack_h2(w10 - cvm_h_lo(t.bot_hi), w11 - cvm_h_hi(t.bot_hi));
+  t.top_lo = cvm_pack_h2(cvm_resid_lo(w00, t.top_hi), cvm_resid_hi(w01, t.top_hi));
+  t.bot_lo = cvm_pack_h2(cvm_resid_lo(w10, t.bot_hi), cvm_resid_hi(w11, t.bot_hi));
   return t;
 }
 
-// wave-uniform chunk range of one map: row pairs [p_lo, p_hi], x blocks [xb_lo, xb_hi]
+// Wave-uniform chunk range of one map.  Chunks are addressed on a grid anchored at the rays' smallest row pair / x block:
+// chunk (cr, cx) = row pairs p_lo + 2 cr, + 1 and x block xb_lo + cx.  `mask` holds one bit per chunk of the first 8 x 8 window
+// of that grid (bit 8 cr + cx) that some ray's footprint touches: the chunk loop walks its set bits with scalar instructions.
+// A footprint wider than the window (`big`: magnifying or degenerate projections) takes the general loop over [p_lo, p_hi] x
+// [xb_lo, xb_hi].  (A footprint's second row / column beyond the map's last one carries weight exactly 0 - the coordinate was
+// clamped onto the last texel - and is left out, as bilin_setup()'s min(x0 + 1, w - 1) does: chunks never start past the map.)
 struct CvmBox {
   int p_lo, p_hi, xb_lo, xb_hi;
+  unsigned long long mask;
+  int big;
 };
-// (a footprint's second row / column beyond the map's last one carries weight exactly 0 - the coordinate was clamped onto the
-// last texel - and is left out, as bilin_setup()'s min(x0 + 1, w - 1) does: chunks never start past the map)
-__device__ __forceinline__ CvmBox cvm_box(const CvmTap& t, int h, int w) {
-  CvmBox b;
-  b.p_lo = cvm_wave_minmax<false>(t.y0) >> 1;
-  b.p_hi = min(cvm_wave_minmax<true>(t.y0) + 1, h - 1) >> 1;
-  b.xb_lo = cvm_wave_minmax<false>(t.x0) >> 2;
-  b.xb_hi = min(cvm_wave_minmax<true>(t.x0) + 1, w - 1) >> 2;
-  return b;
+
+// One SIDE of a unit = one map of a (pair, scale): what the chunk loop needs, all wave-uniform (scalar registers); the rays'
+// footprints (CvmTap, per lane) are read from the wave's LDS scratch when the side becomes the current one.
+struct CvmSide {
+  const char* map;  // the map's operand image
+  int nxb;          // x blocks per row pair
+  int item;         // view * n_scales + scale: index of the footprints / chunk range in the scratch
+  CvmBox box;
+  int p, xb;        // the side's first chunk
+};
+
+// a ray touches chunk (row pairs p, p + 1; x block xb) iff its 2 x 2 footprint intersects rows [2 p, 2 p + 4) x columns
+// [4 xb, 4 xb + 4)   (general loop only)
+__device__ __forceinline__ bool cvm_occupied(const CvmTap& t, int p, int xb) {
+  const int y0 = (int)(t.xy >> 16), x0 = (int)(t.xy & 0xffffu);
+  const bool mine = (unsigned)(y0 - 2 * p + 1) <= 4u && (unsigned)(x0 - 4 * xb + 1) <= 4u;
+  return __builtin_amdgcn_ballot_w64(mine) != 0;
 }
 
-// one row of a chunk for this lane: the packed weight pair E = (w(x0), w(x0 + 1)) of that row placed at columns dx, dx + 1 of
-// the chunk's four: two dwords (columns 0,1 | columns 2,3).  dx in [-1, 3] (checked by the caller: E = 0 otherwise).
-__device__ __forceinline__ void cvm_strip(unsigned E, int dx, unsigned& d0, unsigned& d1) {
-  const unsigned e = dx < 0 ? (E >> 16) : E;
-  const unsigned long long s = (unsigned long long)e << ((dx < 0 ? 0 : 16 * dx) & 63);
-  d0 = (unsigned)s;
-  d1 = (unsigned)(s >> 32);
+// lowest set bit of a non-zero mask -> chunk position; the bit is cleared
+__device__ __forceinline__ void cvm_pop(unsigned long long& m, const CvmBox& box, int& p, int& xb) {
+  const int bit = __builtin_ctzll(m);
+  m &= m - 1;
+  p = box.p_lo + 2 * (bit >> 3);
+  xb = box.xb_lo + (bit & 7);
 }
 
-// B operand (hi and lo) of one chunk for this lane: rows r0 + 2 half, r0 + 2 half + 1; columns c0 .. c0 + 3
-__device__ __forceinline__ void cvm_weights(const CvmTap& t, int r0, int c0, int half, cvm_h8& bh, cvm_h8& bl) {
-  const int dy = t.y0 - (r0 + 2 * half);  // 0: (top, bottom); -1: (bottom, -); 1: (-, top)
-  const int dx = t.x0 - c0;
-  const bool xok = (unsigned)(dx + 1) <= 4u;
-  const bool s0_top = xok && dy == 0, s0_bot = xok && dy == -1, s1_bot = s0_top, s1_top = xok && dy == 1;
-  const unsigned e0h = s0_top ? t.top_hi : (s0_bot ? t.bot_hi : 0u), e1h = s1_bot ? t.bot_hi : (s1_top ? t.top_hi : 0u);
-  const unsigned e0l = s0_top ? t.top_lo : (s0_bot ? t.bot_lo : 0u), e1l = s1_bot ? t.bot_lo : (s1_top ? t.top_lo : 0u);
+// B operand (hi and lo) of one chunk for this lane: rows 2 (p + half), 2 (p + half) + 1; columns 4 xb .. 4 xb + 3.
+// A row's packed pair E = (w(x0), w(x0 + 1)) lands at columns dx, dx + 1 of the four, the footprint's top row in row dy of the
+// lane's two: every output dword is ONE v_perm_b32 of (top, bottom) with a byte selector that depends on (dy, dx) only
+// (0x0c = constant zero, so a footprint that misses the chunk gives zeros by itself).  The four selectors of a (dy, dx) come
+// from a 35-entry table in LDS with one ds_read_b128.
+#define CVM_LUT_ROWS 5  // dy clamped to [-2, 2]
+#define CVM_LUT_COLS 7  // k = dx + 1 clamped to [-1, 5]
+#define CVM_LUT_BYTES 576
+__device__ inline unsigned cvm_lut_word(int dyv, int kv, int slot, int d) {
+  // slot 0 (row 2 (p + half)): top if dy == 0, bottom if dy == -1; slot 1 (the row below): bottom if dy == 0, top if dy == 1
+  const int rowsrc = slot == 0 ? (dyv == 0 ? 1 : (dyv == -1 ? 0 : -1)) : (dyv == 0 ? 0 : (dyv == 1 ? 1 : -1));
+  if (rowsrc < 0) return 0x0c0c0c0cu;
+  const int kk = kv - 2 * d;  // columns 2, 3 see the pair two columns further left
+  const unsigned col = kk == 0 ? 0x0c0c0302u : (kk == 1 ? 0x03020100u : (kk == 2 ? 0x01000c0cu : 0x0c0c0c0cu));
+  unsigned out = 0;
+  for (int b = 0; b < 4; ++b) {
+    unsigned byte = (col >> (8 * b)) & 0xffu;
+    if (byte != 0x0cu && rowsrc == 1) byte += 4;  // v_perm_b32: bytes 4-7 = first source (top), 0-3 = second (bottom)
+    out |= byte << (8 * b);
+  }
+  return out;
+}
+__device__ __forceinline__ void cvm_lut_init(unsigned* lut) {  // whole workgroup; the caller synchronises
+  for (int t = threadIdx.x; t < CVM_LUT_ROWS * CVM_LUT_COLS * 4; t += blockDim.x) {
+    const int e = t >> 2, which = t & 3;
+    lut[t] = cvm_lut_word(e / CVM_LUT_COLS - 2, e % CVM_LUT_COLS - 1, which >> 1, which & 1);
+  }
+}
+
+__device__ __forceinline__ int cvm_med3(int a, int lo, int hi) { return max(lo, min(a, hi)); }
+
+__device__ __forceinline__ void cvm_weights(const CvmTap& t, int p, int xb, int half, const cvm_u4* __restrict__ lut, cvm_h8& bh,
+                                            cvm_h8& bl) {
+  const int y0 = (int)(t.xy >> 16), x0 = (int)(t.xy & 0xffffu);
+  const int dy = y0 - 2 * (p + half);
+  const int k = x0 - 4 * xb + 1;
+  const cvm_u4 sel = lut[(cvm_med3(dy, -2, 2) + 2) * CVM_LUT_COLS + cvm_med3(k, -1, 5) + 1];
   cvm_u4 H, Lo;
-  unsigned a, b;
-  cvm_strip(e0h, dx, a, b), H.x = a, H.y = b;
-  cvm_strip(e1h, dx, a, b), H.z = a, H.w = b;
-  cvm_strip(e0l, dx, a, b), Lo.x = a, Lo.y = b;
-  cvm_strip(e1l, dx, a, b), Lo.z = a, Lo.w = b;
+  H.x = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.x), H.y = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.y);
+  H.z = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.z), H.w = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.w);
+  Lo.x = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.x), Lo.y = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.y);
+  Lo.z = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.z), Lo.w = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.w);
   bh = __builtin_bit_cast(cvm_h8, H);
   bl = __builtin_bit_cast(cvm_h8, Lo);
 }
 
 __device__ __forceinline__ cvm_f16 cvm_mfma(cvm_h8 a, cvm_h8 b, cvm_f16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// F^T (all 128 channels x the wave's 32 rays) of one map: every occupied chunk of the rays' footprints.
-// `map` = the map's operand image, wave-uniform; acc[ct] = channels 32 ct .. 32 ct + 31.
-__device__ __forceinline__ void cvm_interp(cvm_f16 (&acc)[4], const char* __restrict__ map, int nxb, const CvmTap& t, const CvmBox& box,
-                                           int n, int half) {
-  bool first = true;
-  for (int p = box.p_lo; p <= box.p_hi; p += 2) {
-    for (int xb = box.xb_lo; xb <= box.xb_hi; ++xb) {
-      const int r0 = 2 * p, c0 = 4 * xb;
-      // a ray touches the chunk iff its 2 x 2 footprint intersects rows [r0, r0 + 4) x columns [c0, c0 + 4)
-      const bool mine = (unsigned)(t.y0 - r0 + 1) <= 4u && (unsigned)(t.x0 - c0 + 1) <= 4u;
-      if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
-      const unsigned voff = (unsigned)((p + half) * nxb + xb) * (unsigned)CVM_CELL_BYTES + (unsigned)n * 16u;
-      const char* src = map + voff;
-      cvm_u4 ah[4], al[4];
+// A operands of a chunk for this lane (lanes 0-31: row pair p, lanes 32-63: row pair p + 1): + 1024 ct + 512 (hi | lo).
+// Wave-uniform part (scalar registers) + the lane's offset inside the chunk (one register per side: cvm_lane_off)
+__device__ __forceinline__ const char* cvm_chunk_base(const CvmSide& s, int p, int xb) {
+  return s.map + (size_t)((unsigned)(p * s.nxb + xb) * (unsigned)CVM_CELL_BYTES);
+}
+__device__ __forceinline__ unsigned cvm_lane_off(int nxb, int n, int half) {
+  return (unsigned)(half * nxb) * (unsigned)CVM_CELL_BYTES + (unsigned)n * 16u;
+}
+
+// channel tiles per side run: all four (128 channels): the rays' weights of a chunk are built once.  (Two passes over 64
+// channels each - 64 accumulator registers per side - were measured: the compiler still needs ~190 registers, two waves per
+// SIMD either way, and every per-chunk cost is paid twice: 8.3-8.5 against 7.9 ms per frame.)
+#define CVM_NCT 4
+
+// F^T (128 channels x the wave's 32 rays) of one side: every occupied chunk of the rays' footprints, in raster order.
+// On entry (ah, al) hold the A operands of the side's first chunk; the operands of the chunk after the current one - the side's
+// next chunk, else the first chunk of the side that follows in the kernel's sequence (`next_first`, a complete per-lane address)
+// - are requested as soon as the matrix instructions that read the registers have been issued: their latency is covered by
+// this chunk's matrix work and, at the end of a unit, by the dot products.
+__device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&ah)[CVM_NCT], cvm_u4 (&al)[CVM_NCT], const CvmSide& s,
+                                             const CvmTap& tap, const char* next_first, const cvm_u4* __restrict__ lut, int n, int half) {
+  cvm_h8 bh, bl;
+  const unsigned loff = cvm_lane_off(s.nxb, n, half);
+  if (!s.box.big) {
+    unsigned long long m = s.box.mask;
+    int p, xb;
+    cvm_pop(m, s.box, p, xb);  // = (s.p, s.xb), whose operands are in (ah, al)
+    int pn = p, xn = xb;
+    bool more = m != 0;
+    const char* nsrc = next_first;
+    if (more) {
+      cvm_pop(m, s.box, pn, xn);
+      nsrc = cvm_chunk_base(s, pn, xn) + loff;
+    }
+    cvm_weights(tap, p, xb, half, lut, bh, bl);
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        ah[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024);
-        al[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512);
+    for (int ct = 0; ct < CVM_NCT; ++ct) {
+      cvm_f16 z;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+      const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
+      z = cvm_mfma(l, bh, z);
+      z = cvm_mfma(h, bl, z);
+      acc[ct] = cvm_mfma(h, bh, z);
+      ah[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024);
+      al[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024 + 512);
+    }
+    while (more) {
+      p = pn, xb = xn;
+      more = m != 0;
+      nsrc = next_first;
+      if (more) {
+        cvm_pop(m, s.box, pn, xn);
+        nsrc = cvm_chunk_base(s, pn, xn) + loff;
       }
-      cvm_h8 bh, bl;
-      cvm_weights(t, r0, c0, half, bh, bl);
-      if (first) {
+      cvm_weights(tap, p, xb, half, lut, bh, bl);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          cvm_f16 z;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-          const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
-          z = cvm_mfma(l, bh, z);
-          z = cvm_mfma(h, bl, z);
-          acc[ct] = cvm_mfma(h, bh, z);
-        }
-        first = false;
-      } else {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
-          acc[ct] = cvm_mfma(l, bh, acc[ct]);
-          acc[ct] = cvm_mfma(h, bl, acc[ct]);
-          acc[ct] = cvm_mfma(h, bh, acc[ct]);
-        }
+      for (int ct = 0; ct < CVM_NCT; ++ct) {
+        const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
+        acc[ct] = cvm_mfma(l, bh, acc[ct]);
+        acc[ct] = cvm_mfma(h, bl, acc[ct]);
+        acc[ct] = cvm_mfma(h, bh, acc[ct]);
+        ah[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024);
+        al[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024 + 512);
       }
     }
+    return;
+  }
+  // general loop (a footprint wider than the 8 x 8 chunk window): every chunk of the range, operands loaded on demand
+#pragma unroll
+  for (int ct = 0; ct < CVM_NCT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+  for (int p = s.box.p_lo; p <= s.box.p_hi; p += 2)
+    for (int xb = s.box.xb_lo; xb <= s.box.xb_hi; ++xb) {
+      if (!cvm_occupied(tap, p, xb)) continue;
+      const char* src = cvm_chunk_base(s, p, xb) + loff;
+      cvm_weights(tap, p, xb, half, lut, bh, bl);
+#pragma unroll
+      for (int ct = 0; ct < CVM_NCT; ++ct) {
+        const cvm_h8 h = __builtin_bit_cast(cvm_h8, *reinterpret_cast<const cvm_u4*>(src + ct * 1024));
+        const cvm_h8 l = __builtin_bit_cast(cvm_h8, *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512));
+        acc[ct] = cvm_mfma(l, bh, acc[ct]);
+        acc[ct] = cvm_mfma(h, bl, acc[ct]);
+        acc[ct] = cvm_mfma(h, bh, acc[ct]);
+      }
+    }
+#pragma unroll
+  for (int ct = 0; ct < CVM_NCT; ++ct) {
+    ah[ct] = *reinterpret_cast<const cvm_u4*>(next_first + ct * 1024);
+    al[ct] = *reinterpret_cast<const cvm_u4*>(next_first + ct * 1024 + 512);
   }
 }
 
-// one (pair, scale) for the wave's 32 rays at one depth index: adds the cosines of this lane's groups (group 2 i + half in
-// slot i) to cacc.  G = channel groups of the scale (1, 2, 4, 8).
-__device__ __forceinline__ void cvm_unit(float (&cacc)[4], const char* __restrict__ map_a, const char* __restrict__ map_b, int fh, int fw,
-                                         int nxb, const CvmTap& ta, const CvmTap& tb, float inv_ga, float inv_gb, int G, int n, int half) {
-  cvm_f16 fa[4], fb[4];
-  cvm_interp(fa, map_a, nxb, ta, cvm_box(ta, fh, fw), n, half);
-  cvm_interp(fb, map_b, nxb, tb, cvm_box(tb, fh, fw), n, half);
+// One cosine from the two half-wave partial sums of (dot, |a|^2, |b|^2) of TWO groups x / y: lower half-wave <- group x,
+// upper half-wave <- group y.  CosineSimilarity: x1 / max(|x1|, eps) . x2 / max(|x2|, eps), eps = 1e-8, on the UN-scaled maps:
+// with the maps' gains ga, gb in the sums, dot / (ga gb) / (max(|a| / ga, eps) max(|b| / gb, eps))
+// = dot rsqrt(max(|a|^2, (eps ga)^2)) rsqrt(max(|b|^2, (eps gb)^2)): the gains only move the clamps (ea2, eb2, wave-uniform).
+__device__ __forceinline__ float cvm_cos_pair(float dx, float dy, float ax, float ay, float bx, float by, float ea2, float eb2) {
+  const float d = cvm_fold_pair(dx, dy);
+  const float a = cvm_fold_pair(ax, ay);
+  const float b = cvm_fold_pair(bx, by);
+  return d * (__builtin_amdgcn_rsqf(fmaxf(a, ea2)) * __builtin_amdgcn_rsqf(fmaxf(b, eb2)));
+}
+
+// cosines of one unit from the two maps' interpolated features: slot i of a lane = group 2 i + half.
+// G = channel groups of the scale (1, 2, 4, 8).
+__device__ __forceinline__ void cvm_cosines(float (&cacc)[4], const cvm_f16 (&fa)[CVM_NCT], const cvm_f16 (&fb)[CVM_NCT], float ea2,
+                                            float eb2, int G) {
   // three dot products per 16-channel granule (this lane's 8 channels of it: registers 8 (q & 1) .. + 7 of tile q >> 1)
   float dot[8], na[8], nb[8];
 #pragma unroll
@@ -310,44 +400,90 @@ __device__ __forceinline__ void cvm_unit(float (&cacc)[4], const char* __restric
     }
     dot[q] = d, na[q] = a, nb[q] = b;
   }
-  // granules -> groups (wave-uniform): 8 / G granules each
-  if (G <= 4) {
+  if (G == 8) {  // granule = group
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dot[q] = dot[2 * q] + dot[2 * q + 1], na[q] = na[2 * q] + na[2 * q + 1], nb[q] = nb[2 * q] + nb[2 * q + 1];
+    for (int i = 0; i < 4; ++i) cacc[i] += cvm_cos_pair(dot[2 * i], dot[2 * i + 1], na[2 * i], na[2 * i + 1], nb[2 * i], nb[2 * i + 1], ea2, eb2);
+    return;
   }
-  if (G <= 2) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) dot[q] = dot[2 * q] + dot[2 * q + 1], na[q] = na[2 * q] + na[2 * q + 1], nb[q] = nb[2 * q] + nb[2 * q + 1];
-  }
-  if (G <= 1) dot[0] = dot[0] + dot[1], na[0] = na[0] + na[1], nb[0] = nb[0] + nb[1], dot[1] = na[1] = nb[1] = 0.0f;
-  const float sdot = inv_ga * inv_gb, sa = inv_ga * inv_ga, sb = inv_gb * inv_gb;
+  for (int q = 0; q < 4; ++q) dot[q] = dot[2 * q] + dot[2 * q + 1], na[q] = na[2 * q] + na[2 * q + 1], nb[q] = nb[2 * q] + nb[2 * q + 1];
+  if (G == 4) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (2 * i < G) {  // wave-uniform
-      const float d = cvm_fold_pair(dot[2 * i], dot[2 * i + 1]) * sdot;
-      const float a = cvm_fold_pair(na[2 * i], na[2 * i + 1]) * sa;
-      const float b = cvm_fold_pair(nb[2 * i], nb[2 * i + 1]) * sb;
-      // CosineSimilarity: x1 / max(|x1|, eps) . x2 / max(|x2|, eps), eps = 1e-8  (max(sqrt(a), eps) = sqrt(max(a, eps^2)))
-      const float c = d * (__builtin_amdgcn_rsqf(fmaxf(a, 1e-16f)) * __builtin_amdgcn_rsqf(fmaxf(b, 1e-16f)));
-      cacc[i] += c;
-    }
+    for (int i = 0; i < 2; ++i) cacc[i] += cvm_cos_pair(dot[2 * i], dot[2 * i + 1], na[2 * i], na[2 * i + 1], nb[2 * i], nb[2 * i + 1], ea2, eb2);
+    return;
   }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) dot[q] = dot[2 * q] + dot[2 * q + 1], na[q] = na[2 * q] + na[2 * q + 1], nb[q] = nb[2 * q] + nb[2 * q + 1];
+  if (G == 2) {
+    cacc[0] += cvm_cos_pair(dot[0], dot[1], na[0], na[1], nb[0], nb[1], ea2, eb2);
+    return;
+  }
+  cacc[0] += cvm_cos_pair(dot[0] + dot[1], 0.0f, na[0] + na[1], 0.0f, nb[0] + nb[1], 0.0f, ea2, eb2);  // (upper half-wave: 0)
 }
 
 struct CvmGrid {
   int tile_y0, ntx, n_tiles, nsg, spw;  // first tile row, tiles per row, tiles, sample groups per tile, samples per wave and item
 };
 
-__global__ __launch_bounds__(256, 2) void cost_volume_mm_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride, float* __restrict__ cond,
-                                                                const char* __restrict__ opnd, CvmGrid grid) {
-  __shared__ float uv_lds[4][CVM_UV_MAX_VIEWS][32][2];
+// per-wave LDS scratch of one depth index: projections (u, v) [V][32] | footprints [V * n_scales][32] x (uint4 weights, xy) |
+// chunk ranges [V * n_scales]
+// | the 32 rays' conditioning rows of the depth index [32][cond_stride] (assembled here, stored with 16-byte stores)
+__host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, int cond_stride) {
+  const size_t items = (size_t)n_views * n_scales;
+  return (size_t)n_views * 32 * 8 + items * (32 * 16 + 32 * 4 + 32) + (size_t)32 * cond_stride * 4;
+}
+
+#ifndef CVM_WAVES_PER_SIMD
+#define CVM_WAVES_PER_SIMD 2
+#endif
+#ifndef CVM_WG_WAVES
+#define CVM_WG_WAVES 4  // waves per workgroup: wave w runs on SIMD w % 4, so waves w and w + 4 share a SIMD
+#endif
+#ifndef CVM_PRIO
+#define CVM_PRIO 0
+#endif
+// -DCVM_STATS (tools/exp/cvmm_stats.py): per-phase s_memtime sums of every wave, added into the buffer MNERF_CVDBG_PTR names
+#ifdef CVM_STATS
+#define CVM_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define CVM_T(i)                                                  \
+  {                                                               \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+    st[i] += t_ - t_last;                                         \
+    t_last = t_;                                                  \
+  }
+#else
+#define CVM_DBG_PARAM
+#define CVM_T(i)
+#endif
+__global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_volume_mm_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
+                                                                                 float* __restrict__ cond, const char* __restrict__ opnd,
+                                                                                 CvmGrid grid CVM_DBG_PARAM) {
+#ifdef CVM_STATS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) char cvm_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 31, half = lane >> 5;
-  const int S = R.n_samples, V = sc.n_views;
+  const int S = R.n_samples, V = sc.n_views, NS = sc.n_scales;
   const int W = R.width, H = R.height;
-  const int maps = V * (V - 1);
+  const int items = V * NS;
   const CvmLayout L = cvm_layout(sc);
   const float* inv_gain = reinterpret_cast<const float*>(opnd) + 2 * CVM_MAX_MAPS;
+  const cvm_u4* lut = reinterpret_cast<const cvm_u4*>(cvm_smem);
+  cvm_lut_init(reinterpret_cast<unsigned*>(cvm_smem));
+  __syncthreads();
+#if CVM_PRIO
+  // The two waves of a SIMD run the same program and start together; with equal priority the arbiter alternates between them
+  // and they stay in phase - both in their matrix runs, then both in their dot products - so neither pipe overlaps the other.
+  // A fixed priority for the second team lets it run as if alone and the first team fill whichever pipe it leaves free.
+  if (wave >= CVM_WG_WAVES / 2) __builtin_amdgcn_s_setprio(3);
+#endif
+  char* wl = cvm_smem + CVM_LUT_BYTES + (size_t)wave * cvm_wave_lds_bytes(V, NS, cond_stride);
+  float2* uv = reinterpret_cast<float2*>(wl);                                     // [V][32]
+  cvm_u4* tapw = reinterpret_cast<cvm_u4*>(wl + (size_t)V * 256);                 // [items][32]
+  unsigned* tapxy = reinterpret_cast<unsigned*>(wl + (size_t)V * 256 + (size_t)items * 512);  // [items][32]
+  int4* boxes = reinterpret_cast<int4*>(wl + (size_t)V * 256 + (size_t)items * 640);          // [items][2]: range | mask, big
+  float* rows = reinterpret_cast<float*>(wl + (size_t)V * 256 + (size_t)items * 672);        // [32][cond_stride]
 
   // XCD-major contiguous runs of items (see cost_volume_kernel): item = (tile, sample group), sample groups of a tile adjacent
   const int nwg = gridDim.x;
@@ -357,83 +493,218 @@ __global__ __launch_bounds__(256, 2) void cost_volume_mm_kernel(mnerf_scene sc, 
   const int tile = item / grid.nsg, sg = item - tile * grid.nsg;
   const int tyi = tile / grid.ntx, txi = tile - tyi * grid.ntx;
 
-  // this lane's ray: pixel (8 txi + n % 8, 4 (tile_y0 + tyi) + n / 8); lanes outside the image or the launch's pixel range work
-  // on the nearest pixel inside and store nothing
+  // this lane's ray: pixel (8 txi + n % 8, 4 (tile_y0 + tyi) + n / 8).  A pixel of the image that lies outside the launch's
+  // range is still evaluated (and not stored): a tile's chunk ranges, and with them the order of its sums, then do not depend on
+  // how a frame is cut into launches.  Lanes outside the image work on the nearest pixel inside.
   const int px = txi * 8 + (n & 7), py = (grid.tile_y0 + tyi) * 4 + (n >> 3);
-  int pix = min(py, H - 1) * W + min(px, W - 1);
-  const bool ray_live = px < W && py < H && pix >= R.ray_begin && pix < R.ray_begin + R.n_rays;
-  pix = max(R.ray_begin, min(pix, R.ray_begin + R.n_rays - 1));
-  const int ray = pix - R.ray_begin;
-  const RayGeom g = make_ray(R, ray);
+  const int pix = min(py, H - 1) * W + min(px, W - 1);
+  const int ray_geo = pix - R.ray_begin;                                           // make_ray: pixel = ray_begin + ray
+  const int ray = max(0, min(ray_geo, R.n_rays - 1));                              // rows / stratified offsets: a ray of the launch
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-  const int G0 = sc.n_group[0], G1 = sc.n_scales > 1 ? sc.n_group[1] : 0;
+  const int G0 = sc.n_group[0], G1 = NS > 1 ? sc.n_group[1] : 0;
   const int sumG = G0 + G1;
-  const float inv_pairs = 1.0f / (float)(V * (V - 1) / 2);
-  float (*uv)[32][2] = uv_lds[wave];
+  const int n_pairs = V * (V - 1) / 2;
+  const float inv_pairs = 1.0f / (float)n_pairs;
 
   for (int k = 0; k < grid.spw; ++k) {
-    const int j = (sg * grid.spw + k) * 4 + wave;
+    const int j = (sg * grid.spw + k) * CVM_WG_WAVES + wave;
     if (j >= S) break;  // wave-uniform
-    const float d = sample_depth(R, ray, j);
+    float* out = rows + n * cond_stride;  // this ray's row of the depth index, assembled in LDS
     float wx, wy, wz;
-    ray_point(g, d, wx, wy, wz);
-    float* out = cond + ((size_t)ray * S + j) * cond_stride;
+    {
+      int rg = ray_geo;
+      asm volatile("" : "+v"(rg));  // the ray is rebuilt per depth index (15 instructions) instead of living in six registers
+      ray_point(make_ray(R, rg), sample_depth(R, ray, j), wx, wy, wz);
+    }
 
+    CVM_T(7)
     // ---- pass 1 (cv_pass1's arithmetic): projections, colours, masks; half-wave `half` takes views half, half + 2, ..
-    cvw_handoff();  // the previous sample's reads of uv are done
+    cvw_handoff();  // the previous depth index's reads of the scratch are done
     for (int v = half; v < V; v += 2) {
       float u, w_, z;
       project(sc.views[v], wx, wy, wz, wm1, hm1, u, w_, z);
-      uv[v][n][0] = u;
-      uv[v][n][1] = w_;
+      uv[v * 32 + n] = make_float2(u, w_);
       const Bilin b = bilin_setup(u, w_, H, W);
       const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * H * W;
       const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
-      if (ray_live) {
-        out[sumG + 3 * v + 0] = t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11;
-        out[sumG + 3 * v + 1] = t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11;
-        out[sumG + 3 * v + 2] = t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11;
-        out[sumG + 3 * V + v] = m;
-      }
+      out[sumG + 3 * v + 0] = bilin4(t00.x, t01.x, t10.x, t11.x, b);
+      out[sumG + 3 * v + 1] = bilin4(t00.y, t01.y, t10.y, t11.y, b);
+      out[sumG + 3 * v + 2] = bilin4(t00.z, t01.z, t10.z, t11.z, b);
+      out[sumG + 3 * V + v] = m;
     }
-    if (ray_live && half == 0) {
+    if (half == 0) {
       const int dc = sumG + 4 * V;
       out[dc] = 1.0f;  // constant input of the packed FiLM bias column
       for (int c = dc + 1; c < cond_stride; ++c) out[c] = 0.0f;
     }
     cvw_handoff();
+    CVM_T(0)
 
-    // ---- pass 2: one unit per (pair, scale); slot i of a lane = group 2 i + half
-    float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
-    int p = 0;
-    for (int a = 0; a < V - 1; ++a) {
-      const float ua = uv[a][n][0], va = uv[a][n][1];
-      for (int b = a + 1; b < V; ++b, ++p) {
-        const float ub = uv[b][n][0], vb = uv[b][n][1];
-        {
-          const char* ma = opnd + L.off[0] + (size_t)(2 * p) * L.map_bytes[0];
-          cvm_unit(c0, ma, ma + L.map_bytes[0], sc.fh[0], sc.fw[0], L.nxb[0], cvm_tap(ua, va, sc.fh[0], sc.fw[0]), cvm_tap(ub, vb, sc.fh[0], sc.fw[0]),
-                   inv_gain[2 * p], inv_gain[2 * p + 1], G0, n, half);
-        }
-        if (sc.n_scales > 1) {
-          const char* ma = opnd + L.off[1] + (size_t)(2 * p) * L.map_bytes[1];
-          cvm_unit(c1, ma, ma + L.map_bytes[1], sc.fh[1], sc.fw[1], L.nxb[1], cvm_tap(ua, va, sc.fh[1], sc.fw[1]), cvm_tap(ub, vb, sc.fh[1], sc.fw[1]),
-                   inv_gain[CVM_MAX_MAPS + 2 * p], inv_gain[CVM_MAX_MAPS + 2 * p + 1], G1, n, half);
-        }
-      }
-    }
-    if (ray_live) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gi = 2 * i + half;
-        if (gi < G0) out[gi] = c0[i] * inv_pairs;
-        if (gi < G1) out[G0 + gi] = c1[i] * inv_pairs;
-      }
-    }
+    // ---- pass 1b: footprint and chunk range of every (view, scale) = item; half-wave `half` takes items half, half + 2, ..
+    // (the range is a minimum / maximum over the 32 rays = the two DPP rows of the half-wave)
+    for (int it = 0; 2 * it < items; ++it) {
+      const int i = min(2 * it + half, items - 1);  // (an odd item count: the upper half-wave repeats the last item)
+      const int v = i / NS, s = i - v * NS;
+      const float2 p2 = uv[v * 32 + n];
+      int x0, y0;
+      const CvmTap t = cvm_tap(p2.x, p2.y, sc.fh[s], sc.fw[s], x0, y0);
+      cvm_u4 wv;
+      wv.x = t.top_hi, wv.y = t.bot_hi, wv.z = t.top_lo, wv.w = t.bot_lo;
+      tapw[i * 32 + n] = wv;
+      tapxy[i * 32 + n] = t.xy;
+      // chunk range and occupancy: minimum / maximum / OR over the 32 rays = the two DPP rows of the half-wave
+      const int y1 = min(y0 + 1, sc.fh[s] - 1), x1 = min(x0 + 1, sc.fw[s] - 1);
+      int xmin = x0, xmax = x1, ymin = y0, ymax = y1;
+#define CVM_MM_STEP(CTRL)                                                                                                    \
+  {                                                                                                                          \
+    xmin = min(xmin, __builtin_amdgcn_update_dpp(xmin, xmin, CTRL, 0xF, 0xF, false));                                         \
+    xmax = max(xmax, __builtin_amdgcn_update_dpp(xmax, xmax, CTRL, 0xF, 0xF, false));                                         \
+    ymin = min(ymin, __builtin_amdgcn_update_dpp(ymin, ymin, CTRL, 0xF, 0xF, false));                                         \
+    ymax = max(ymax, __builtin_amdgcn_update_dpp(ymax, ymax, CTRL, 0xF, 0xF, false));                                         \
   }
-  (void)maps;
+      CVM_MM_STEP(0xB1)   // quad_perm [1,0,3,2]
+      CVM_MM_STEP(0x4E)   // quad_perm [2,3,0,1]
+      CVM_MM_STEP(0x141)  // row_half_mirror
+      CVM_MM_STEP(0x140)  // row_mirror
+#undef CVM_MM_STEP
+      // the other row of this half-wave: lanes 16 apart (ds_swizzle BitMode: and 0x1f, or 0, xor 0x10)
+      xmin = min(xmin, __builtin_amdgcn_ds_swizzle(xmin, 0x401F));
+      xmax = max(xmax, __builtin_amdgcn_ds_swizzle(xmax, 0x401F));
+      ymin = min(ymin, __builtin_amdgcn_ds_swizzle(ymin, 0x401F));
+      ymax = max(ymax, __builtin_amdgcn_ds_swizzle(ymax, 0x401F));
+      const int p_lo = ymin >> 1, xb_lo = xmin >> 2, p_hi = ymax >> 1, xb_hi = xmax >> 2;
+      const int big = (((p_hi - p_lo) >> 1) > 7 || xb_hi - xb_lo > 7) ? 1 : 0;  // uniform over the half-wave
+      // this ray's chunks on the grid anchored at (p_lo, xb_lo): rows cra, crb x columns cxa, cxb (bit 8 cr + cx; window 8 x 8)
+      const int cra = min(((y0 >> 1) - p_lo) >> 1, 7), crb = min(((y1 >> 1) - p_lo) >> 1, 7);
+      const int cxa = min((x0 >> 2) - xb_lo, 7), cxb = min((x1 >> 2) - xb_lo, 7);
+      unsigned long long mk = (1ull << (8 * cra + cxa)) | (1ull << (8 * cra + cxb)) | (1ull << (8 * crb + cxa)) | (1ull << (8 * crb + cxb));
+      unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+#define CVM_OR_STEP(CTRL)                                                                             \
+  {                                                                                                   \
+    mlo |= (unsigned)__builtin_amdgcn_update_dpp((int)mlo, (int)mlo, CTRL, 0xF, 0xF, false);          \
+    mhi |= (unsigned)__builtin_amdgcn_update_dpp((int)mhi, (int)mhi, CTRL, 0xF, 0xF, false);          \
+  }
+      CVM_OR_STEP(0xB1)
+      CVM_OR_STEP(0x4E)
+      CVM_OR_STEP(0x141)
+      CVM_OR_STEP(0x140)
+#undef CVM_OR_STEP
+      mlo |= (unsigned)__builtin_amdgcn_ds_swizzle((int)mlo, 0x401F);
+      mhi |= (unsigned)__builtin_amdgcn_ds_swizzle((int)mhi, 0x401F);
+      if (n == 0 && 2 * it + half < items) {
+        boxes[2 * i] = make_int4(p_lo, p_hi, xb_lo, xb_hi);
+        boxes[2 * i + 1] = make_int4(big ? 0 : (int)mlo, big ? 0 : (int)mhi, big, 0);
+      }
+    }
+    cvw_handoff();
+
+    CVM_T(1)
+    // ---- pass 2: the sides of all units in one sequence - per unit (pair, scale): side a, side b - each side's first chunk
+    // requested while the side before it is still being worked on
+    float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+    auto tap_of = [&](int i) {
+      CvmTap t;
+      const cvm_u4 wv = tapw[i * 32 + n];
+      t.xy = tapxy[i * 32 + n];
+      t.top_hi = wv.x, t.bot_hi = wv.y, t.top_lo = wv.z, t.bot_lo = wv.w;
+      return t;
+    };
+    auto side_of = [&](const char* map, int view, int s) {
+      CvmSide o;
+      o.map = map;
+      o.nxb = L.nxb[s];
+      o.item = view * NS + s;
+      const int4 bx = boxes[2 * o.item], mk = boxes[2 * o.item + 1];
+      o.box.p_lo = __builtin_amdgcn_readfirstlane(bx.x), o.box.p_hi = __builtin_amdgcn_readfirstlane(bx.y);
+      o.box.xb_lo = __builtin_amdgcn_readfirstlane(bx.z), o.box.xb_hi = __builtin_amdgcn_readfirstlane(bx.w);
+      o.box.mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mk.x) |
+                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mk.y) << 32);
+      o.box.big = o.box.mask == 0;  // (pass 1b stores no mask for a footprint wider than the window)
+      o.p = o.box.p_lo, o.xb = o.box.xb_lo;  // general loop: the range's first chunk (occupied or not)
+      if (!o.box.big) {
+        unsigned long long m = o.box.mask;
+        cvm_pop(m, o.box, o.p, o.xb);
+      }
+      return o;
+    };
+    cvm_u4 ah[CVM_NCT], al[CVM_NCT];
+    // running map pointers per scale: side a of the current pair (side b follows it in memory, the next pair's sides after that)
+    const char* mp0 = opnd + L.off[0];
+    const char* mp1 = opnd + L.off[1];
+    int pr = 0, a = 0, b = 1, s = 0;
+    CvmSide sa = side_of(mp0, 0, 0);
+    {
+      const char* src = cvm_chunk_base(sa, sa.p, sa.xb) + cvm_lane_off(sa.nxb, n, half);
+#pragma unroll
+      for (int ct = 0; ct < CVM_NCT; ++ct) {
+        ah[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024);
+        al[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512);
+      }
+    }
+    const int n_units = n_pairs * NS;
+    for (int u = 0; u < n_units; ++u) {
+      const char* map_a = s == 0 ? mp0 : mp1;
+      const CvmSide sb = side_of(map_a + L.map_bytes[s], b, s);
+      const char* first_b = cvm_chunk_base(sb, sb.p, sb.xb) + cvm_lane_off(sb.nxb, n, half);
+      cvm_f16 fa[CVM_NCT], fb[CVM_NCT];
+      CVM_T(2)
+      cvm_side_run(fa, ah, al, sa, tap_of(sa.item), first_b, lut, n, half);
+      CVM_T(3)
+      // the unit after this one: next scale of the pair, else the next pair.  The last unit of the depth index re-requests its
+      // own first chunk (one wasted request per depth index keeps the chunk loop free of conditional loads).
+      const float ga = inv_gain[s * CVM_MAX_MAPS + 2 * pr], gb = inv_gain[s * CVM_MAX_MAPS + 2 * pr + 1];  // 1 / gain
+      const int G = s == 0 ? G0 : G1;
+      const int s_cur = s;
+      if (++s == NS) {
+        s = 0, ++pr;
+        mp0 += 2 * L.map_bytes[0], mp1 += 2 * L.map_bytes[1];
+        if (++b == V) ++a, b = a + 1;
+      }
+      const bool last = u == n_units - 1;
+      const CvmSide sn = last ? sb : side_of(s == 0 ? mp0 : mp1, a, s);
+      const char* first_n = cvm_chunk_base(sn, sn.p, sn.xb) + cvm_lane_off(sn.nxb, n, half);
+      CVM_T(2)
+      cvm_side_run(fb, ah, al, sb, tap_of(sb.item), first_n, lut, n, half);
+      CVM_T(4)
+      // clamps of the two norms in the scaled sums: (eps gain)^2
+      const float ea = 1e-8f / ga, eb = 1e-8f / gb;
+      if (s_cur == 0)
+        cvm_cosines(c0, fa, fb, ea * ea, eb * eb, G);
+      else
+        cvm_cosines(c1, fa, fb, ea * ea, eb * eb, G);
+      sa = sn;
+      CVM_T(5)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gi = 2 * i + half;
+      if (gi < G0) out[gi] = c0[i] * inv_pairs;
+      if (gi < G1) out[G0 + gi] = c1[i] * inv_pairs;
+    }
+    // the 32 rows leave as 16-byte pieces, consecutive lanes on consecutive pieces of a row (a row is cond_stride / 4 pieces:
+    // the scattered 4-byte stores of one value per lane cost the memory pipeline ~20 instructions of 32 partial lines each)
+    cvw_handoff();
+    {
+      const int ppr = cond_stride >> 2;  // pieces per row (cond_stride is a multiple of 8)
+      for (int c = lane; c < 32 * ppr; c += 64) {
+        const int r = c / ppr, part = c - r * ppr;
+        const int rpx = txi * 8 + (r & 7), rpy = (grid.tile_y0 + tyi) * 4 + (r >> 3);
+        const int rpix = rpy * W + rpx;
+        if (rpx < W && rpy < H && rpix >= R.ray_begin && rpix < R.ray_begin + R.n_rays)
+          *reinterpret_cast<v4f*>(cond + ((size_t)(rpix - R.ray_begin) * S + j) * cond_stride + 4 * part) =
+              *reinterpret_cast<const v4f*>(rows + r * cond_stride + 4 * part);
+      }
+    }
+    CVM_T(6)
+  }
+#ifdef CVM_STATS
+  if (dbg && lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(dbg + i, st[i]);
+    atomicAdd(dbg + 8, 1ull);
+  }
+#endif
 }
 
 // ============================================================================ host
@@ -485,12 +756,29 @@ int mnerf_cost_volume_mm_launch(const mnerf_scene* scene, const mnerf_rays* rays
   g.ntx = (W + 7) / 8;
   g.n_tiles = g.ntx * (row_last / 4 - g.tile_y0 + 1);
   int spw = mnerf_tune().cv_mm_spw;
-  if (spw <= 0) spw = 4;
+  if (spw <= 0) spw = 2;
   g.spw = spw;
-  g.nsg = (rays->n_samples + 4 * spw - 1) / (4 * spw);
+  g.nsg = (rays->n_samples + CVM_WG_WAVES * spw - 1) / (CVM_WG_WAVES * spw);
   const long long items = (long long)g.n_tiles * g.nsg;
   MNERF_REQUIRE(items < (1ll << 31), MNERF_E_RANGE, "mnerf_cost_volume: %lld work items", items);
-  hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(256), 0, (hipStream_t)stream, *scene, *rays, cond_stride,
+  const size_t lds = CVM_LUT_BYTES + CVM_WG_WAVES * cvm_wave_lds_bytes(scene->n_views, scene->n_scales, cond_stride);
+  MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
+  static std::atomic<int> lds_set[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& seen = lds_set[dev & 63];
+  if ((int)lds > seen.load(std::memory_order_relaxed)) {
+    (void)hipFuncSetAttribute((const void*)cost_volume_mm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    seen.store((int)lds, std::memory_order_relaxed);
+  }
+#ifdef CVM_STATS
+  unsigned long long* dbg = nullptr;
+  if (const char* e = getenv("MNERF_CVDBG_PTR")) dbg = (unsigned long long*)strtoull(e, nullptr, 0);
+  hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays, cond_stride,
+                     cond, reinterpret_cast<const char*>(scene->feat_op), g, dbg);
+#else
+  hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays, cond_stride,
                      cond, reinterpret_cast<const char*>(scene->feat_op), g);
+#endif
   return mnerf_check_launch("mnerf_cost_volume");
 }

@@ -36,6 +36,13 @@ __device__ __forceinline__ Bilin bilin_setup(float u, float v, int h, int w) {
 }
 
 
+// one bilinear value: the products summed in tap order, as an explicit multiply + FMA chain (what the compiler made of
+// a w00 + b w01 + c w10 + d w11 in the walk kernels; spelled out so that every cost-volume kernel gives the same bits whatever
+// the surrounding code looks like)
+__device__ __forceinline__ float bilin4(float a, float b, float c, float d, const Bilin& w) {
+  return __builtin_fmaf(d, w.w11, __builtin_fmaf(c, w.w10, __builtin_fmaf(b, w.w01, a * w.w00)));
+}
+
 // ============================================================================ segment walk
 // Same arithmetic as cost_volume_kernel, different traversal.  PMC showed that kernel bound by
 // the bytes the texture path delivers to registers (~18 TB/s of taps, 53 % of L1 peak), not by
@@ -495,9 +502,9 @@ __device__ __forceinline__ void cv_pass1(const mnerf_scene& sc, const mnerf_rays
       const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
       const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
       if (live) {
-        cv_store<NT>(out + sumG + 3 * v + 0, t00.x * b.w00 + t01.x * b.w01 + t10.x * b.w10 + t11.x * b.w11);
-        cv_store<NT>(out + sumG + 3 * v + 1, t00.y * b.w00 + t01.y * b.w01 + t10.y * b.w10 + t11.y * b.w11);
-        cv_store<NT>(out + sumG + 3 * v + 2, t00.z * b.w00 + t01.z * b.w01 + t10.z * b.w10 + t11.z * b.w11);
+        cv_store<NT>(out + sumG + 3 * v + 0, bilin4(t00.x, t01.x, t10.x, t11.x, b));
+        cv_store<NT>(out + sumG + 3 * v + 1, bilin4(t00.y, t01.y, t10.y, t11.y, b));
+        cv_store<NT>(out + sumG + 3 * v + 2, bilin4(t00.z, t01.z, t10.z, t11.z, b));
         cv_store<NT>(out + sumG + 3 * V + v, m);
       }
     }
