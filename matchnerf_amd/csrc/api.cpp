@@ -51,7 +51,7 @@ static mnerf_tuning read_tuning() {
   t.decoder_stagger_mode = env_int("MNERF_DECODER_STAGGER_MODE", 0);
   t.cv_variant = env_int("MNERF_CV_VARIANT", 3);  // 3 / 4 = segment walk with 16 / 8 lanes per sample; 5 = texel tiles in LDS (slower, kept: cost_volume.hip); 0 = plain
   t.cv_mm = env_int("MNERF_CV_MM", 1);            // matrix form of the cost volume where it applies (cost_volume_mm.hip)
-  t.cv_mm_spw = env_int("MNERF_CV_MM_SPW", 2);
+  t.cv_mm_spw = env_int("MNERF_CV_MM_SPW", 4);
   t.cv_uvpair = env_int("MNERF_CV_UVPAIR", -1);
   t.cv_pair_block = env_int("MNERF_CV_PAIR_BLOCK", 8);
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap

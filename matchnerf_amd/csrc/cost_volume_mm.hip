@@ -198,7 +198,7 @@ __device__ __forceinline__ CvmTap cvm_tap(float u, float v, int h, int w, int& x
 // [xb_lo, xb_hi].  (A footprint's second row / column beyond the map's last one carries weight exactly 0 - the coordinate was
 // clamped onto the last texel - and is left out, as bilin_setup()'s min(x0 + 1, w - 1) does: chunks never start past the map.)
 struct CvmBox {
-  int p_lo, p_hi, xb_lo, xb_hi;
+  int p_lo, xb_lo;
   unsigned long long mask;
   int big;
 };
@@ -297,7 +297,8 @@ __device__ __forceinline__ unsigned cvm_lane_off(int nxb, int n, int half) {
 // - are requested as soon as the matrix instructions that read the registers have been issued: their latency is covered by
 // this chunk's matrix work and, at the end of a unit, by the dot products.
 __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&ah)[CVM_NCT], cvm_u4 (&al)[CVM_NCT], const CvmSide& s,
-                                             const CvmTap& tap, const char* next_first, const cvm_u4* __restrict__ lut, int n, int half) {
+                                             const CvmTap& tap, const char* next_first, const cvm_u4* __restrict__ lut, int n, int half,
+                                             int fh, int fw) {
   cvm_h8 bh, bl;
   const unsigned loff = cvm_lane_off(s.nxb, n, half);
   if (!s.box.big) {
@@ -345,13 +346,20 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
     }
     return;
   }
-  // general loop (a footprint wider than the 8 x 8 chunk window): every chunk of the range, operands loaded on demand
+  // general loop (a footprint wider than the 8 x 8 chunk window): every chunk of the rays' range, operands loaded on demand
+  int p_hi, xb_hi;
+  {
+    int ymax = (int)(tap.xy >> 16), xmax = (int)(tap.xy & 0xffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ymax = max(ymax, __shfl_xor(ymax, off, 64)), xmax = max(xmax, __shfl_xor(xmax, off, 64));
+    p_hi = __builtin_amdgcn_readfirstlane(min(ymax + 1, fh - 1) >> 1), xb_hi = __builtin_amdgcn_readfirstlane(min(xmax + 1, fw - 1) >> 2);
+  }
 #pragma unroll
   for (int ct = 0; ct < CVM_NCT; ++ct)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
-  for (int p = s.box.p_lo; p <= s.box.p_hi; p += 2)
-    for (int xb = s.box.xb_lo; xb <= s.box.xb_hi; ++xb) {
+  for (int p = s.box.p_lo; p <= p_hi; p += 2)
+    for (int xb = s.box.xb_lo; xb <= xb_hi; ++xb) {
       if (!cvm_occupied(tap, p, xb)) continue;
       const char* src = cvm_chunk_base(s, p, xb) + loff;
       cvm_weights(tap, p, xb, half, lut, bh, bl);
@@ -405,6 +413,7 @@ __device__ __forceinline__ void cvm_cosines(float (&cacc)[4], const cvm_f16 (&fa
     for (int i = 0; i < 4; ++i) cacc[i] += cvm_cos_pair(dot[2 * i], dot[2 * i + 1], na[2 * i], na[2 * i + 1], nb[2 * i], nb[2 * i + 1], ea2, eb2);
     return;
   }
+  asm volatile("" : "+v"(dot[0]), "+v"(na[0]), "+v"(nb[0]));  // (keeps the sums below out of the G = 8 path)
 #pragma unroll
   for (int q = 0; q < 4; ++q) dot[q] = dot[2 * q] + dot[2 * q + 1], na[q] = na[2 * q] + na[2 * q + 1], nb[q] = nb[2 * q] + nb[2 * q + 1];
   if (G == 4) {
@@ -430,7 +439,7 @@ struct CvmGrid {
 // | the 32 rays' conditioning rows of the depth index [32][cond_stride] (assembled here, stored with 16-byte stores)
 __host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, int cond_stride) {
   const size_t items = (size_t)n_views * n_scales;
-  return (size_t)n_views * 32 * 8 + items * (32 * 16 + 32 * 4 + 32) + (size_t)32 * cond_stride * 4;
+  return (size_t)n_views * 32 * 8 + items * (32 * 16 + 32 * 4 + 16) + (size_t)32 * cond_stride * 4;
 }
 
 #ifndef CVM_WAVES_PER_SIMD
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   const int W = R.width, H = R.height;
   const int items = V * NS;
   const CvmLayout L = cvm_layout(sc);
-  const float* inv_gain = reinterpret_cast<const float*>(opnd) + 2 * CVM_MAX_MAPS;
+  const float* gain = reinterpret_cast<const float*>(opnd);
   const cvm_u4* lut = reinterpret_cast<const cvm_u4*>(cvm_smem);
   cvm_lut_init(reinterpret_cast<unsigned*>(cvm_smem));
   __syncthreads();
@@ -482,8 +491,8 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   float2* uv = reinterpret_cast<float2*>(wl);                                     // [V][32]
   cvm_u4* tapw = reinterpret_cast<cvm_u4*>(wl + (size_t)V * 256);                 // [items][32]
   unsigned* tapxy = reinterpret_cast<unsigned*>(wl + (size_t)V * 256 + (size_t)items * 512);  // [items][32]
-  int4* boxes = reinterpret_cast<int4*>(wl + (size_t)V * 256 + (size_t)items * 640);          // [items][2]: range | mask, big
-  float* rows = reinterpret_cast<float*>(wl + (size_t)V * 256 + (size_t)items * 672);        // [32][cond_stride]
+  int4* boxes = reinterpret_cast<int4*>(wl + (size_t)V * 256 + (size_t)items * 640);          // [items]: p_lo, xb_lo, mask (0: big)
+  float* rows = reinterpret_cast<float*>(wl + (size_t)V * 256 + (size_t)items * 656);        // [32][cond_stride]
 
   // XCD-major contiguous runs of items (see cost_volume_kernel): item = (tile, sample group), sample groups of a tile adjacent
   const int nwg = gridDim.x;
@@ -554,15 +563,13 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       wv.x = t.top_hi, wv.y = t.bot_hi, wv.z = t.top_lo, wv.w = t.bot_lo;
       tapw[i * 32 + n] = wv;
       tapxy[i * 32 + n] = t.xy;
-      // chunk range and occupancy: minimum / maximum / OR over the 32 rays = the two DPP rows of the half-wave
+      // chunk grid anchor and occupancy: minimum / OR over the 32 rays = the two DPP rows of the half-wave
       const int y1 = min(y0 + 1, sc.fh[s] - 1), x1 = min(x0 + 1, sc.fw[s] - 1);
-      int xmin = x0, xmax = x1, ymin = y0, ymax = y1;
+      int xmin = x0, ymin = y0;
 #define CVM_MM_STEP(CTRL)                                                                                                    \
   {                                                                                                                          \
     xmin = min(xmin, __builtin_amdgcn_update_dpp(xmin, xmin, CTRL, 0xF, 0xF, false));                                         \
-    xmax = max(xmax, __builtin_amdgcn_update_dpp(xmax, xmax, CTRL, 0xF, 0xF, false));                                         \
     ymin = min(ymin, __builtin_amdgcn_update_dpp(ymin, ymin, CTRL, 0xF, 0xF, false));                                         \
-    ymax = max(ymax, __builtin_amdgcn_update_dpp(ymax, ymax, CTRL, 0xF, 0xF, false));                                         \
   }
       CVM_MM_STEP(0xB1)   // quad_perm [1,0,3,2]
       CVM_MM_STEP(0x4E)   // quad_perm [2,3,0,1]
@@ -571,15 +578,15 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
 #undef CVM_MM_STEP
       // the other row of this half-wave: lanes 16 apart (ds_swizzle BitMode: and 0x1f, or 0, xor 0x10)
       xmin = min(xmin, __builtin_amdgcn_ds_swizzle(xmin, 0x401F));
-      xmax = max(xmax, __builtin_amdgcn_ds_swizzle(xmax, 0x401F));
       ymin = min(ymin, __builtin_amdgcn_ds_swizzle(ymin, 0x401F));
-      ymax = max(ymax, __builtin_amdgcn_ds_swizzle(ymax, 0x401F));
-      const int p_lo = ymin >> 1, xb_lo = xmin >> 2, p_hi = ymax >> 1, xb_hi = xmax >> 2;
-      const int big = (((p_hi - p_lo) >> 1) > 7 || xb_hi - xb_lo > 7) ? 1 : 0;  // uniform over the half-wave
+      const int p_lo = ymin >> 1, xb_lo = xmin >> 2;
       // this ray's chunks on the grid anchored at (p_lo, xb_lo): rows cra, crb x columns cxa, cxb (bit 8 cr + cx; window 8 x 8)
-      const int cra = min(((y0 >> 1) - p_lo) >> 1, 7), crb = min(((y1 >> 1) - p_lo) >> 1, 7);
-      const int cxa = min((x0 >> 2) - xb_lo, 7), cxb = min((x1 >> 2) - xb_lo, 7);
-      unsigned long long mk = (1ull << (8 * cra + cxa)) | (1ull << (8 * cra + cxb)) | (1ull << (8 * crb + cxa)) | (1ull << (8 * crb + cxb));
+      const int cra = ((y0 >> 1) - p_lo) >> 1, crb = ((y1 >> 1) - p_lo) >> 1;
+      const int cxa = (x0 >> 2) - xb_lo, cxb = (x1 >> 2) - xb_lo;
+      const unsigned long long ob = __builtin_amdgcn_ballot_w64(crb > 7 || cxb > 7);
+      const bool big = (half ? (unsigned)(ob >> 32) : (unsigned)ob) != 0u;  // uniform over the half-wave
+      unsigned long long mk = (1ull << ((8 * cra + cxa) & 63)) | (1ull << ((8 * cra + cxb) & 63)) | (1ull << ((8 * crb + cxa) & 63)) |
+                              (1ull << ((8 * crb + cxb) & 63));
       unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
 #define CVM_OR_STEP(CTRL)                                                                             \
   {                                                                                                   \
@@ -593,10 +600,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
 #undef CVM_OR_STEP
       mlo |= (unsigned)__builtin_amdgcn_ds_swizzle((int)mlo, 0x401F);
       mhi |= (unsigned)__builtin_amdgcn_ds_swizzle((int)mhi, 0x401F);
-      if (n == 0 && 2 * it + half < items) {
-        boxes[2 * i] = make_int4(p_lo, p_hi, xb_lo, xb_hi);
-        boxes[2 * i + 1] = make_int4(big ? 0 : (int)mlo, big ? 0 : (int)mhi, big, 0);
-      }
+      if (n == 0 && 2 * it + half < items) boxes[i] = make_int4(p_lo, xb_lo, big ? 0 : (int)mlo, big ? 0 : (int)mhi);
     }
     cvw_handoff();
 
@@ -616,11 +620,10 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       o.map = map;
       o.nxb = L.nxb[s];
       o.item = view * NS + s;
-      const int4 bx = boxes[2 * o.item], mk = boxes[2 * o.item + 1];
-      o.box.p_lo = __builtin_amdgcn_readfirstlane(bx.x), o.box.p_hi = __builtin_amdgcn_readfirstlane(bx.y);
-      o.box.xb_lo = __builtin_amdgcn_readfirstlane(bx.z), o.box.xb_hi = __builtin_amdgcn_readfirstlane(bx.w);
-      o.box.mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mk.x) |
-                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(mk.y) << 32);
+      const int4 bx = boxes[o.item];
+      o.box.p_lo = __builtin_amdgcn_readfirstlane(bx.x), o.box.xb_lo = __builtin_amdgcn_readfirstlane(bx.y);
+      o.box.mask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(bx.z) |
+                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(bx.w) << 32);
       o.box.big = o.box.mask == 0;  // (pass 1b stores no mask for a footprint wider than the window)
       o.p = o.box.p_lo, o.xb = o.box.xb_lo;  // general loop: the range's first chunk (occupied or not)
       if (!o.box.big) {
@@ -650,11 +653,11 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       const char* first_b = cvm_chunk_base(sb, sb.p, sb.xb) + cvm_lane_off(sb.nxb, n, half);
       cvm_f16 fa[CVM_NCT], fb[CVM_NCT];
       CVM_T(2)
-      cvm_side_run(fa, ah, al, sa, tap_of(sa.item), first_b, lut, n, half);
+      cvm_side_run(fa, ah, al, sa, tap_of(sa.item), first_b, lut, n, half, sc.fh[s], sc.fw[s]);
       CVM_T(3)
       // the unit after this one: next scale of the pair, else the next pair.  The last unit of the depth index re-requests its
       // own first chunk (one wasted request per depth index keeps the chunk loop free of conditional loads).
-      const float ga = inv_gain[s * CVM_MAX_MAPS + 2 * pr], gb = inv_gain[s * CVM_MAX_MAPS + 2 * pr + 1];  // 1 / gain
+      const float ga = gain[s * CVM_MAX_MAPS + 2 * pr], gb = gain[s * CVM_MAX_MAPS + 2 * pr + 1];
       const int G = s == 0 ? G0 : G1;
       const int s_cur = s;
       if (++s == NS) {
@@ -666,10 +669,10 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       const CvmSide sn = last ? sb : side_of(s == 0 ? mp0 : mp1, a, s);
       const char* first_n = cvm_chunk_base(sn, sn.p, sn.xb) + cvm_lane_off(sn.nxb, n, half);
       CVM_T(2)
-      cvm_side_run(fb, ah, al, sb, tap_of(sb.item), first_n, lut, n, half);
+      cvm_side_run(fb, ah, al, sb, tap_of(sb.item), first_n, lut, n, half, sc.fh[s_cur], sc.fw[s_cur]);
       CVM_T(4)
       // clamps of the two norms in the scaled sums: (eps gain)^2
-      const float ea = 1e-8f / ga, eb = 1e-8f / gb;
+      const float ea = 1e-8f * ga, eb = 1e-8f * gb;
       if (s_cur == 0)
         cvm_cosines(c0, fa, fb, ea * ea, eb * eb, G);
       else
@@ -756,7 +759,7 @@ int mnerf_cost_volume_mm_launch(const mnerf_scene* scene, const mnerf_rays* rays
   g.ntx = (W + 7) / 8;
   g.n_tiles = g.ntx * (row_last / 4 - g.tile_y0 + 1);
   int spw = mnerf_tune().cv_mm_spw;
-  if (spw <= 0) spw = 2;
+  if (spw <= 0) spw = 4;
   g.spw = spw;
   g.nsg = (rays->n_samples + CVM_WG_WAVES * spw - 1) / (CVM_WG_WAVES * spw);
   const long long items = (long long)g.n_tiles * g.nsg;

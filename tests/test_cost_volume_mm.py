@@ -29,7 +29,7 @@ def hip():
 
 def _rows(hip, sc, cfg, batch, n, begin, cs, mm):
     rays = make_rays_struct(cfg, batch, n, ray_begin=begin)
-    with hip.knob("cv_mm", 1 if mm else 0):
+    with hip.knob("cv_mm", int(mm)):
         out = hip.cost_volume(sc, rays, cs)
     return out.reshape(n, cfg.sample_intvs, cs)
 
@@ -42,10 +42,10 @@ def test_matrix_form_matches_reference_and_walk(hip, name):
     n = h * w
     dc = g["cond"].shape[-1]
     cs = ((dc + 1 + 7) // 8) * 8
-    walk = _rows(hip, sc, cfg, batch, n, 0, cs, mm=False)
+    walk = _rows(hip, sc, cfg, batch, n, 0, cs, mm=0)
     keep = hip.cost_volume_operands(sc)  # noqa: F841  (sets sc.feat_op; the tensor must outlive the launches)
     assert sc.feat_op
-    mm = _rows(hip, sc, cfg, batch, n, 0, cs, mm=True)
+    mm = _rows(hip, sc, cfg, batch, n, 0, cs, mm=1)
     torch.cuda.synchronize()
     sum_g = sum(cfg.cos_n_group)
     idx = torch.from_numpy(g["stage_rays"]).long().cuda()
@@ -67,13 +67,36 @@ def test_matrix_form_is_chunk_invariant_and_reproducible(hip, name):
     h, w = batch["images"].shape[-2:]
     n = h * w
     cs = ((g["cond"].shape[-1] + 1 + 7) // 8) * 8
-    whole = _rows(hip, sc, cfg, batch, n, 0, cs, mm=True)
+    whole = _rows(hip, sc, cfg, batch, n, 0, cs, mm=1)
     for _ in range(3):
-        assert torch.equal(_rows(hip, sc, cfg, batch, n, 0, cs, mm=True), whole)
+        assert torch.equal(_rows(hip, sc, cfg, batch, n, 0, cs, mm=1), whole)
     cuts = [0, 1, w - 3, 5 * w + 7, n // 2 + 11, n - 1, n]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
-        part = _rows(hip, sc, cfg, batch, hi - lo, lo, cs, mm=True)
+        part = _rows(hip, sc, cfg, batch, hi - lo, lo, cs, mm=1)
         assert torch.equal(part, whole[lo:hi]), (lo, hi)
+
+
+@pytest.mark.parametrize("focal", [6.0, 40.0])
+def test_wide_footprints_take_the_general_loop(hip, focal):
+    """A target camera with a very short focal length: neighbouring target pixels land many texels apart in the source maps, so
+    a tile's footprints exceed the 8 x 8 chunk window (`big`) and the kernel walks the rays' whole chunk range with operands
+    loaded on demand.  The segment walk (pinned to the reference by the goldens) is the yardstick; samples behind or beside the
+    source cameras exercise the border clamp on the way."""
+    g, cfg, sd, batch, feats_gpu, img_gpu = _case_on_gpu("c1_default")
+    batch = {k: v.clone() for k, v in batch.items()}
+    h, w = batch["images"].shape[-2:]
+    batch["intrinsics"][0, -1] = torch.tensor([[focal, 0.0, w / 2.0], [0.0, focal, h / 2.0], [0.0, 0.0, 1.0]])
+    sc = make_scene_struct(cfg, batch, feats_gpu, img_gpu)
+    n = h * w
+    dc = g["cond"].shape[-1]
+    cs = ((dc + 1 + 7) // 8) * 8
+    walk = _rows(hip, sc, cfg, batch, n, 0, cs, mm=0)
+    keep = hip.cost_volume_operands(sc)  # noqa: F841
+    mm = _rows(hip, sc, cfg, batch, n, 0, cs, mm=1)
+    sum_g = sum(cfg.cos_n_group)
+    assert float((mm[..., :sum_g] - walk[..., :sum_g]).abs().max()) < 5e-6
+    assert torch.equal(mm[..., sum_g:], walk[..., sum_g:])
+    assert not torch.equal(mm[..., :sum_g], torch.zeros_like(mm[..., :sum_g]))
 
 
 def test_operand_image_round_trips_the_maps(hip):
