@@ -45,6 +45,7 @@ Also in the JSON line (N = 1):
 """
 import argparse
 import json
+from math import log10 as math_log10
 import os
 import socket
 import subprocess
@@ -369,6 +370,10 @@ def main():
     other_math = {}
     if world == 1:
         rgb_default = full[:, :3].clone()
+        # PSNR against the target image (the synthetic scene's pseudo ground truth; metrics.py:19-41 on the whole frame)
+        gt = batch.images[0, -1].permute(1, 2, 0).reshape(-1, 3)
+        psnr_of = lambda rgb: float(-10.0 * torch.log10(((rgb - gt) ** 2).mean()))
+        psnr_default = psnr_of(rgb_default)
         keep = os.environ.get("MNERF_DECODER_MATH")
         try:
             for m in ("f16x3", "bf16x6", "f32", "f16"):  # "f16": the reduced-precision fast mode (outside the parity gate)
@@ -386,7 +391,17 @@ def main():
                 other_math[m] = {"rays_per_s": round(n_rays / (msm * 1e-3), 1), "ms_per_step": round(msm, 3),
                                  "decoder_ms_per_frame": _per_frame(tm.summary(), "decoder", 2),
                                  "fused_ray_chunk_ms_per_frame": _per_frame(tm.summary(), "render_fused", 2),
-                                 "rgb_linf_vs_default_math": float((fullm[:, :3] - rgb_default).abs().max())}
+                                 "rgb_linf_vs_default_math": float((fullm[:, :3] - rgb_default).abs().max()),
+                                 # north_star's "PSNR delta < 0.01 dB": against the target image, and - where a deviation
+                                 # weighs most - the worst case for a render 30 dB from its ground truth (mse 1e-3)
+                                 "psnr_delta_db": round(psnr_of(fullm[:, :3]) - psnr_default, 5),
+                                 "psnr_delta_db_at_30dB": {
+                                     "what": "for a render 30 dB from its ground truth (mse 1e-3): deviation uncorrelated with the "
+                                             "residual | perfectly aligned with it (upper bound)",
+                                     "uncorrelated": round(10.0 * math_log10(
+                                         1.0 + float(((fullm[:, :3] - rgb_default) ** 2).mean()) / 1e-3), 5),
+                                     "aligned_bound": round(10.0 * math_log10(
+                                         (1e-3 ** 0.5 + float(((fullm[:, :3] - rgb_default) ** 2).mean().sqrt())) ** 2 / 1e-3), 5)}}
         except Exception as e:  # noqa: BLE001  (a side measurement must not cost the headline line)
             other_math["error"] = f"{type(e).__name__}: {e}"[:300]
         finally:

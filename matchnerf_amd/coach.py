@@ -150,12 +150,25 @@ class Coach:
                 mode = "spiral"
             elif name == "colmap":
                 mode = getattr(getattr(self.opts.data_test, "colmap", {}), "render_path_mode", "interpolate")
-            else:  # dtu, blender (and the other sets the reference has no video rule for)
+            elif name in ("dtu", "blender"):
                 mode = "interpolate"
+            else:  # coach.py:480-481: the reference has no video rule for the other sets (ibrnet, tnt, ...)
+                raise Exception(f"Unknown dataset for rendering video {name}")
             self.model.nerf_setbg_opaque = (name == "blender")
             n_frames = int(self.opts.nerf.video_n_frames)
             for batch in loader:
                 var = edict({k: (v.to(self.opts.device) if torch.is_tensor(v) else v) for k, v in batch.items()})
+                # (coach.py:487-488 passes opts.nerf.render_video; this method IS the video test, so a config that leaves the
+                # switch off still gets the frames - and is told so once)
+                if not getattr(self.opts.nerf, "render_video", True) and not getattr(self, "_warned_render_video", False):
+                    import warnings
+                    warnings.warn("test_model_video: nerf.render_video is off in the options; rendering the video path anyway")
+                    self._warned_render_video = True
+                if getattr(self.opts, "vis_depth", False) and not getattr(self, "_warned_vis_depth", False):
+                    import warnings
+                    warnings.warn("test_model_video: vis_depth (depth maps next to the frames, coach.py:497-505) and the .mp4 "
+                                  "container (skvideo, coach.py:511-525) are not written: frames / GIF / source strip only")
+                    self._warned_vis_depth = True
                 var = self.model(var, mode="test", render_video=True, render_path_mode=mode)
                 b, _, _, h, w = var.images.shape
                 # forward returns the reference's frame-major layout [n_frames * B, HW, 3]

@@ -609,18 +609,33 @@ class CondNeRF(nn.Module):
         ver = tuple(int(p._version) for p in self.parameters())
         ptr = tuple(int(p.data_ptr()) for p in self.parameters())
         return (ver, ptr, n_samples, bool(self.opt.decoder.raytrans_posenc), bool(self.opt.nerf.legacy_coord),
-                decoder_math())
+                self.math_for(n_samples, self._training_now()))
 
-    def math_for(self, n_samples):
-        """the matrix path the kernel runs for S samples per ray (MNERF_DECODER_MATH; every S <= 256 has all three)"""
-        return decoder_math()
+    def _training_now(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def math_for(self, n_samples, training=False):
+        """the matrix path the kernel runs for S samples per ray (MNERF_DECODER_MATH).  f16x3 / bf16x6 / f32 exist for every
+        S <= 256.  The one-product fast mode "f16" exists in the ping-pong decoder at S <= 128 only and has no backward of its
+        own (mnerf_decoder_backward re-evaluates the forward in fp32: gradients of another function), so a request for it falls
+        back to the parity path f16x3 - with one warning - for longer rays and under autograd, instead of failing with
+        MNERF_E_UNSUPPORTED deep inside a launch."""
+        math = decoder_math()
+        if math == "f16" and (n_samples > 128 or training):
+            if not getattr(self, "_warned_f16", False):
+                import warnings
+                warnings.warn(f"MNERF_DECODER_MATH=f16 (one-product fast mode) does not exist for "
+                              f"{'training' if training else f'sample_intvs={n_samples} > 128'}: using f16x3")
+                self._warned_f16 = True
+            return "f16x3"
+        return math
 
     def packed(self, n_samples, device):
         """(wstream, small, cond_stride, wstream_format) for the HIP kernel; re-packed when any
         parameter changed (load_state_dict / optimizer step), S or MNERF_DECODER_MATH changed."""
         key = self._pack_key(n_samples)
         if self._packed is None or self._packed[0] != key or self._packed[1].device != torch.device(device):
-            math = self.math_for(n_samples)
+            math = self.math_for(n_samples, self._training_now())
             if math in ("f16x3", "f16") and self.pts_bias.weight.is_cuda and self.pts_bias.weight.device == torch.device(device):
                 # parameters on the GPU (every training iteration re-packs after the optimizer step): the stream is assembled
                 # THERE, without a device->host copy (packing.DecoderPacker, bit-identical to pack_wstream_h)

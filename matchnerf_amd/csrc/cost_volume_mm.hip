@@ -432,14 +432,16 @@ __device__ __forceinline__ void cvm_cosines(float (&cacc)[4], const cvm_f16 (&fa
 
 struct CvmGrid {
   int tile_y0, ntx, n_tiles, nsg, spw;  // first tile row, tiles per row, tiles, sample groups per tile, samples per wave and item
+  int stage_rows;                       // rows assembled in LDS (0: many views - the scratch would cost the second workgroup of a CU)
+  int pair_begin, pair_end, a0, b0;     // PAIR BLOCK of this launch (cv_walk.hpp "PAIR BLOCKS"): pairs [pair_begin, pair_end), the first one = views (a0, b0)
 };
 
 // per-wave LDS scratch of one depth index: projections (u, v) [V][32] | footprints [V * n_scales][32] x (uint4 weights, xy) |
 // chunk ranges [V * n_scales]
 // | the 32 rays' conditioning rows of the depth index [32][cond_stride] (assembled here, stored with 16-byte stores)
-__host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, int cond_stride) {
+__host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, int cond_stride, int stage_rows) {
   const size_t items = (size_t)n_views * n_scales;
-  return (size_t)n_views * 32 * 8 + items * (32 * 16 + 32 * 4 + 16) + (size_t)32 * cond_stride * 4;
+  return (size_t)n_views * 32 * 8 + items * (32 * 16 + 32 * 4 + 16) + (stage_rows ? (size_t)32 * cond_stride * 4 : 0);
 }
 
 #ifndef CVM_WAVES_PER_SIMD
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   // A fixed priority for the second team lets it run as if alone and the first team fill whichever pipe it leaves free.
   if (wave >= CVM_WG_WAVES / 2) __builtin_amdgcn_s_setprio(3);
 #endif
-  char* wl = cvm_smem + CVM_LUT_BYTES + (size_t)wave * cvm_wave_lds_bytes(V, NS, cond_stride);
+  char* wl = cvm_smem + CVM_LUT_BYTES + (size_t)wave * cvm_wave_lds_bytes(V, NS, cond_stride, grid.stage_rows);
   float2* uv = reinterpret_cast<float2*>(wl);                                     // [V][32]
   cvm_u4* tapw = reinterpret_cast<cvm_u4*>(wl + (size_t)V * 256);                 // [items][32]
   unsigned* tapxy = reinterpret_cast<unsigned*>(wl + (size_t)V * 256 + (size_t)items * 512);  // [items][32]
@@ -509,16 +511,19 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   const int pix = min(py, H - 1) * W + min(px, W - 1);
   const int ray_geo = pix - R.ray_begin;                                           // make_ray: pixel = ray_begin + ray
   const int ray = max(0, min(ray_geo, R.n_rays - 1));                              // rows / stratified offsets: a ray of the launch
+  const bool row_wr = grid.stage_rows || (px < W && py < H && ray_geo >= 0 && ray_geo < R.n_rays);  // direct rows: live rays only
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   const int G0 = sc.n_group[0], G1 = NS > 1 ? sc.n_group[1] : 0;
   const int sumG = G0 + G1;
   const int n_pairs = V * (V - 1) / 2;
   const float inv_pairs = 1.0f / (float)n_pairs;
+  const bool first_block = grid.pair_begin == 0, last_block = grid.pair_end == n_pairs;
 
   for (int k = 0; k < grid.spw; ++k) {
     const int j = (sg * grid.spw + k) * CVM_WG_WAVES + wave;
     if (j >= S) break;  // wave-uniform
-    float* out = rows + n * cond_stride;  // this ray's row of the depth index, assembled in LDS
+    // this ray's row of the depth index: assembled in LDS, or (many views) written to memory value by value
+    float* out = grid.stage_rows ? rows + n * cond_stride : cond + ((size_t)ray * S + j) * cond_stride;
     float wx, wy, wz;
     {
       int rg = ray_geo;
@@ -533,17 +538,19 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       float u, w_, z;
       project(sc.views[v], wx, wy, wz, wm1, hm1, u, w_, z);
       uv[v * 32 + n] = make_float2(u, w_);
-      const Bilin b = bilin_setup(u, w_, H, W);
-      const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * H * W;
-      const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
-      const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
-      const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
-      out[sumG + 3 * v + 0] = bilin4(t00.x, t01.x, t10.x, t11.x, b);
-      out[sumG + 3 * v + 1] = bilin4(t00.y, t01.y, t10.y, t11.y, b);
-      out[sumG + 3 * v + 2] = bilin4(t00.z, t01.z, t10.z, t11.z, b);
-      out[sumG + 3 * V + v] = m;
+      if (row_wr && first_block) {  // (a later pair block only needs the projections)
+        const Bilin b = bilin_setup(u, w_, H, W);
+        const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * H * W;
+        const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+        const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
+        const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
+        out[sumG + 3 * v + 0] = bilin4(t00.x, t01.x, t10.x, t11.x, b);
+        out[sumG + 3 * v + 1] = bilin4(t00.y, t01.y, t10.y, t11.y, b);
+        out[sumG + 3 * v + 2] = bilin4(t00.z, t01.z, t10.z, t11.z, b);
+        out[sumG + 3 * V + v] = m;
+      }
     }
-    if (half == 0) {
+    if (half == 0 && row_wr && first_block) {
       const int dc = sumG + 4 * V;
       out[dc] = 1.0f;  // constant input of the packed FiLM bias column
       for (int c = dc + 1; c < cond_stride; ++c) out[c] = 0.0f;
@@ -608,6 +615,14 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     // ---- pass 2: the sides of all units in one sequence - per unit (pair, scale): side a, side b - each side's first chunk
     // requested while the side before it is still being worked on
     float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!first_block && row_wr) {  // a later pair block continues the raw sums the blocks before it left in the rows
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gi = 2 * i + half;
+        if (gi < G0) c0[i] = out[gi];
+        if (gi < G1) c1[i] = out[G0 + gi];
+      }
+    }
     auto tap_of = [&](int i) {
       CvmTap t;
       const cvm_u4 wv = tapw[i * 32 + n];
@@ -634,10 +649,10 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     };
     cvm_u4 ah[CVM_NCT], al[CVM_NCT];
     // running map pointers per scale: side a of the current pair (side b follows it in memory, the next pair's sides after that)
-    const char* mp0 = opnd + L.off[0];
-    const char* mp1 = opnd + L.off[1];
-    int pr = 0, a = 0, b = 1, s = 0;
-    CvmSide sa = side_of(mp0, 0, 0);
+    const char* mp0 = opnd + L.off[0] + (size_t)(2 * grid.pair_begin) * L.map_bytes[0];
+    const char* mp1 = opnd + L.off[1] + (size_t)(2 * grid.pair_begin) * L.map_bytes[1];
+    int pr = grid.pair_begin, a = grid.a0, b = grid.b0, s = 0;
+    CvmSide sa = side_of(mp0, a, 0);
     {
       const char* src = cvm_chunk_base(sa, sa.p, sa.xb) + cvm_lane_off(sa.nxb, n, half);
 #pragma unroll
@@ -646,7 +661,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
         al[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512);
       }
     }
-    const int n_units = n_pairs * NS;
+    const int n_units = (grid.pair_end - grid.pair_begin) * NS;
     for (int u = 0; u < n_units; ++u) {
       const char* map_a = s == 0 ? mp0 : mp1;
       const CvmSide sb = side_of(map_a + L.map_bytes[s], b, s);
@@ -680,16 +695,18 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       sa = sn;
       CVM_T(5)
     }
+    if (row_wr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gi = 2 * i + half;
-      if (gi < G0) out[gi] = c0[i] * inv_pairs;
-      if (gi < G1) out[G0 + gi] = c1[i] * inv_pairs;
+      for (int i = 0; i < 4; ++i) {
+        const int gi = 2 * i + half;
+        if (gi < G0) out[gi] = last_block ? c0[i] * inv_pairs : c0[i];
+        if (gi < G1) out[G0 + gi] = last_block ? c1[i] * inv_pairs : c1[i];
+      }
     }
     // the 32 rows leave as 16-byte pieces, consecutive lanes on consecutive pieces of a row (a row is cond_stride / 4 pieces:
     // the scattered 4-byte stores of one value per lane cost the memory pipeline ~20 instructions of 32 partial lines each)
     cvw_handoff();
-    {
+    if (grid.stage_rows) {
       const int ppr = cond_stride >> 2;  // pieces per row (cond_stride is a multiple of 8)
       for (int c = lane; c < 32 * ppr; c += 64) {
         const int r = c / ppr, part = c - r * ppr;
@@ -764,7 +781,17 @@ int mnerf_cost_volume_mm_launch(const mnerf_scene* scene, const mnerf_rays* rays
   g.nsg = (rays->n_samples + CVM_WG_WAVES * spw - 1) / (CVM_WG_WAVES * spw);
   const long long items = (long long)g.n_tiles * g.nsg;
   MNERF_REQUIRE(items < (1ll << 31), MNERF_E_RANGE, "mnerf_cost_volume: %lld work items", items);
-  const size_t lds = CVM_LUT_BYTES + CVM_WG_WAVES * cvm_wave_lds_bytes(scene->n_views, scene->n_scales, cond_stride);
+  // Many views: one launch per BLOCK of view pairs over all rays (cv_walk.hpp "PAIR BLOCKS": the maps a launch gathers from
+  // then fit the Infinity Cache and, per XCD band, come close to its L2); the raw cosine sums travel through the rows.
+  const int n_pairs = scene->n_views * (scene->n_views - 1) / 2;
+  int blk = mnerf_tune().cv_pair_block > 0 ? mnerf_tune().cv_pair_block : n_pairs;
+  if (scene->n_views <= 5) blk = n_pairs;  // (what the walk does: up to 10 pairs x 2 sides x 13.1 MB at 512x640 = 262 MB)
+  // rows are assembled in LDS unless that scratch is what keeps a second workgroup off the CU (160 KiB of LDS; from 7 views on)
+  // - or the launch is one of several pair blocks (only the first writes colours and masks)
+  g.stage_rows = blk >= n_pairs &&
+                 (2 * (CVM_LUT_BYTES + CVM_WG_WAVES * cvm_wave_lds_bytes(scene->n_views, scene->n_scales, cond_stride, 1)) <= 160 * 1024 ||
+                  2 * (CVM_LUT_BYTES + CVM_WG_WAVES * cvm_wave_lds_bytes(scene->n_views, scene->n_scales, cond_stride, 0)) > 160 * 1024);
+  const size_t lds = CVM_LUT_BYTES + CVM_WG_WAVES * cvm_wave_lds_bytes(scene->n_views, scene->n_scales, cond_stride, g.stage_rows);
   MNERF_REQUIRE(lds <= 160 * 1024, MNERF_E_UNSUPPORTED, "mnerf_cost_volume: %d views need %zu B of LDS", scene->n_views, lds);
   static std::atomic<int> lds_set[64];
   int dev = 0;
@@ -777,11 +804,19 @@ int mnerf_cost_volume_mm_launch(const mnerf_scene* scene, const mnerf_rays* rays
 #ifdef CVM_STATS
   unsigned long long* dbg = nullptr;
   if (const char* e = getenv("MNERF_CVDBG_PTR")) dbg = (unsigned long long*)strtoull(e, nullptr, 0);
-  hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays, cond_stride,
-                     cond, reinterpret_cast<const char*>(scene->feat_op), g, dbg);
-#else
-  hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays, cond_stride,
-                     cond, reinterpret_cast<const char*>(scene->feat_op), g);
 #endif
+  int a = 0, b = 1;
+  for (int p0 = 0; p0 < n_pairs; p0 += blk) {
+    g.pair_begin = p0, g.pair_end = p0 + blk < n_pairs ? p0 + blk : n_pairs, g.a0 = a, g.b0 = b;
+#ifdef CVM_STATS
+    hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays,
+                       cond_stride, cond, reinterpret_cast<const char*>(scene->feat_op), g, dbg);
+#else
+    hipLaunchKernelGGL(cost_volume_mm_kernel, dim3((unsigned)items), dim3(64 * CVM_WG_WAVES), lds, (hipStream_t)stream, *scene, *rays,
+                       cond_stride, cond, reinterpret_cast<const char*>(scene->feat_op), g);
+#endif
+    for (int i = 0; i < blk; ++i)  // the pair after the block's last one
+      if (++b == scene->n_views) ++a, b = a + 1;
+  }
   return mnerf_check_launch("mnerf_cost_volume");
 }

@@ -103,8 +103,7 @@ def render_frame_sharded(model, batch, mode="test"):
     tgt_pose, ref_poses = model.extract_poses(batch)
     b, _, _, h, w = ref_images.shape
     first, n = shard_rows(h, w, rank, world)
-    idx = torch.arange(first, first + n, device=ref_images.device)
-    out = model.render(model.opts, tgt_pose, ray_idx=idx, mode=mode, ref_poses=ref_poses, ref_images=ref_images,
+    out = model.render(model.opts, tgt_pose, ray_range=(first, n), mode=mode, ref_poses=ref_poses, ref_images=ref_images,
                        ref_feats_list=feats)
     tile = torch.cat([out.rgb, out.depth, out.opacity], -1).permute(1, 0, 2).reshape(n, b * 5)   # rows = rays
     full = gather_tiles(tile, [shard_rows(h, w, r, world)[1] for r in range(world)])

@@ -61,7 +61,11 @@ class MatchNeRF(torch.nn.Module):
         self._frame = None        # per-source-set launch context (host camera copies, RGBA images): see _frame_ctx
         self.kernel_timer = None  # hip.KernelTimer: per-kernel event timing (bench.py)
         self.fused_render = False  # True: ray chunks take the one-launch form where it exists (slower on MI355X: DESIGN.md)
-        self.pose_batching = os.environ.get("MNERF_POSE_BATCHING", "1") != "0"  # video of small frames: several poses per launch
+        # video of small frames: several poses per launch through a pose table (mnerf_rays.pose_table).  OFF by default since
+        # round 6: the table never paid (157.4 against 158.6 ms for demo_own.yaml's 24 frames, profiles/history/r5_video_demo_own.log)
+        # and it keeps the cost volume on the segment walk, which the matrix form of the pose-by-pose launches now beats
+        # (DESIGN.md section 4).  MNERF_POSE_BATCHING=1 brings it back; tests/test_pose_table_gpu.py keeps it bit-identical.
+        self.pose_batching = os.environ.get("MNERF_POSE_BATCHING", "0") == "1"
         self.cv_matrix_form = os.environ.get("MNERF_CV_MM", "1") != "0"  # full-frame renders: the cost volume on the matrix pipe
         self._cv_ops = None
 
@@ -279,9 +283,10 @@ class MatchNeRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ render (matchnerf.py:88-143)
     def render(self, opt, tgt_pose=None, ray_idx=None, mode=None, ref_poses=None, ref_images=None,
-               ref_feats_list=None):
+               ref_feats_list=None, ray_range=None):
         """Rays of one target pose -> edict(rgb [B,N,3], depth [B,N,1], opacity [B,N,1]).
-        ``ray_idx`` (LongTensor [N], shared by the batch) selects pixels; None = full image."""
+        ``ray_idx`` (LongTensor [N], shared by the batch) selects pixels; ``ray_range`` = (first pixel, count) a contiguous run of
+        pixels (a band of rows: dist.render_frame_sharded) that keeps the kernels of the full-frame path; neither = full image."""
         if tgt_pose is None:
             raise Exception("Must provide tgt_pose.")
         if not ref_images.is_cuda:
@@ -290,7 +295,10 @@ class MatchNeRF(torch.nn.Module):
         device = ref_images.device
         n_samples = int(opt.nerf.sample_intvs)
         legacy = bool(opt.nerf.legacy_coord)
-        n_rays = img_h * img_w if ray_idx is None else int(ray_idx.numel())
+        assert ray_idx is None or ray_range is None
+        pix0, n_rays = (0, img_h * img_w) if ray_range is None else (int(ray_range[0]), int(ray_range[1]))
+        if ray_idx is not None:
+            n_rays = int(ray_idx.numel())
         idx32 = None if ray_idx is None else ray_idx.to(device=device, dtype=torch.int32).contiguous()
         stratified = mode == "train" and bool(opt.nerf.sample_stratified)
 
@@ -300,6 +308,8 @@ class MatchNeRF(torch.nn.Module):
         ref_host, images_cl = self._frame_ctx(ref_poses, ref_images)
         tgt_ex, tgt_in, tgt_nf = self._tgt_host(tgt_pose)
         if needs_grad:
+            if ray_range is not None:
+                ray_idx = torch.arange(pix0, pix0 + n_rays, device=device)
             return self._render_with_grad(opt, ref_host, (tgt_ex, tgt_in, tgt_nf), ray_idx, stratified, ref_images,
                                           ref_feats_list, images_cl, n_rays, n_samples, img_h, img_w)
         dec = self._decoder(n_samples, device)
@@ -316,7 +326,7 @@ class MatchNeRF(torch.nn.Module):
             for c in range(0, n_rays, chunk):
                 m = min(chunk, n_rays - c)
                 rays = hip.make_rays(
-                    m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1], ray_begin=c, legacy=legacy,
+                    m, n_samples, img_h, img_w, kinv, c2w, tgt_nf[b, 0], tgt_nf[b, 1], ray_begin=pix0 + c, legacy=legacy,
                     depth_inverse=(opt.nerf.depth.param == "inverse"),
                     ray_idx_ptr=None if idx32 is None else idx32[c:].data_ptr(),
                     strat_u_ptr=None if strat is None else strat[c:].data_ptr())
@@ -343,6 +353,14 @@ class MatchNeRF(torch.nn.Module):
         if per_launch < 2 or len(poses) < 2 or not ref_images.is_cuda or self.fused_render:
             return None
         n_samples = int(opt.nerf.sample_intvs)
+        # the hand-off rows of a launch are rays x S x cond_stride floats (3.2 GB for 262 144 rays at S = 128): never more than
+        # a quarter of what the device has free, so that a smaller card renders with fewer poses per launch instead of failing
+        if ref_images.is_cuda:
+            free, _ = torch.cuda.mem_get_info(device)
+            row_bytes = n_pix * n_samples * 4 * hip.MNERF_COND_STRIDE_MAX
+            per_launch = max(1, min(per_launch, int(free // 4 // max(row_bytes, 1))))
+            if per_launch < 2:
+                return None
         legacy = bool(opt.nerf.legacy_coord)
         ref_host, images_cl = self._frame_ctx(ref_poses, ref_images)
         dec = self._decoder(n_samples, device)

@@ -174,6 +174,9 @@ class TransformerPacker:
     def pack(self):
         """-> per layer ((qkv stream, (ew_q, ew_k, ew_v)), (block stream, (ew_merge, ew_w1, ew_w2))); streams are float32-word
         views of one fresh buffer.  One device->host copy (the exponents)."""
+        # the parameter OBJECTS are collected again on every pack: a layer whose Parameter was replaced since construction
+        # (layer.q_proj.weight = nn.Parameter(...), parametrize, weight tying) must not be packed from the old tensor
+        self.tensors = [t for layer in self.layers for t in layer._qkv_params() + layer._block_weights()]
         ts = [t.detach() for t in self.tensors]
         ews = [exponent_of_absmax(float(m)) for m in torch.stack(torch._foreach_norm(ts, float("inf"))).tolist()]
         scaled = torch._foreach_mul(ts, [float(2.0 ** e) for e in ews])
@@ -205,6 +208,7 @@ class DecoderPacker:
         self.device = torch.device(device)
         sd = {prefix + k: v for k, v in dec.state_dict().items()}
         self.names = [k for k in sd if not k.endswith("num_batches_tracked")]
+        self._dec_ref, self._prefix = dec, prefix
         self.params = [dict(dec.named_parameters())[k[len(prefix):]] for k in self.names]
         # the plan depends on the decoder's shape only: shared by every decoder of that shape on the device (DataParallel replicas)
         key = (int(n_views), tuple(int(g) for g in cos_n_group), int(L_3D), bool(legacy), str(self.device),
@@ -298,6 +302,9 @@ class DecoderPacker:
 
     def pack(self):
         """-> wstream (float32 words [total]) on the parameters' device; same bits as cond_nerf.pack_wstream_h."""
+        # (the Parameter objects are looked up again on every pack: see TransformerPacker.pack)
+        named = dict(self._dec_ref.named_parameters())
+        self.params = [named[k[len(self._prefix):]] for k in self.names]
         ts = [p.detach().to(torch.float32) for p in self.params]
         amax = torch.stack(torch._foreach_norm(ts, float("inf")))
         _, e = torch.frexp(amax)

@@ -55,7 +55,8 @@ def test_ten_source_views_match_oracle():
 
 
 @pytest.mark.parametrize("n_views", [10, 7])
-def test_pair_blocked_cost_volume_is_bit_identical_to_one_launch(n_views):
+@pytest.mark.parametrize("mm", [1, 0])  # matrix form (cost_volume_mm.hip) / segment walk
+def test_pair_blocked_cost_volume_is_bit_identical_to_one_launch(n_views, mm):
     """From 6 views on the cost volume runs one launch per block of view pairs (cv_walk.hpp "PAIR BLOCKS"); the per-sample
     cosine sums travel through the rows between the blocks as raw sums and are accumulated pair by pair in the same order:
     the rendered frame and the conditioning rows are bit-identical for every block size, including ragged last blocks."""
@@ -66,7 +67,7 @@ def test_pair_blocked_cost_volume_is_bit_identical_to_one_launch(n_views):
     frames = {}
     with torch.no_grad():
         for blk in (0, 8, 4, 7, 1):  # 0: all pairs in one launch (the round-3 form)
-            with hip.knob("cv_pair_block", blk):
+            with hip.knob("cv_pair_block", blk), hip.knob("cv_mm", mm):
                 out = model(batch, mode="test")
                 frames[blk] = (out.rgb.clone(), out.depth.clone(), out.opacity.clone())
     for blk, fr in frames.items():
@@ -133,20 +134,38 @@ def test_fullsize_outputs_are_finite_and_bounded(full_frame):
     assert float((depth - opacity * near).min()) >= -1e-4                        # sum w d >= near * sum w
 
 
-def test_fullsize_ray_subset_is_bit_identical(full_frame):
-    """rays are independent: rendering any subset through ray_idx (different tiles, different
-    workgroup neighbours) must reproduce the full-frame values exactly."""
-    opt, model, batch, _, rgb, depth, opacity = full_frame
-    g = torch.Generator().manual_seed(5)
-    idx = torch.randperm(512 * 640, generator=g)[:5000].cuda()
+def _subset_checks(model, opt, batch, feats, n_views, h, w, rgb, depth, opacity, n_sub, seed):
+    """Rays are independent.  (i) A ragged CONTIGUOUS run of pixels (``ray_range``: the kernels of the full-frame path, i.e. the
+    matrix form of the cost volume, other tiles and workgroup neighbours) reproduces the frame's values exactly; (ii) a random
+    subset through ``ray_idx`` takes the segment walk for the cost volume (the matrix form needs contiguous pixels): the same
+    cosines to a few ulp, hence the frame's values to far inside the parity gate - and exactly with the frame's cost volume
+    switched to the walk as well."""
+    from matchnerf_amd import hip
     tgt, ref = model.extract_poses(batch)
+    first, cnt = 37 * w + 11, 9 * w + 5
+    idx = torch.randperm(h * w, generator=torch.Generator().manual_seed(seed))[:n_sub].cuda()
+    with torch.no_grad():
+        run = model.render(opt, tgt, ray_range=(first, cnt), mode="test", ref_poses=ref, ref_images=batch.images[:, :n_views],
+                           ref_feats_list=feats)
+        sub = model.render(opt, tgt, ray_idx=idx, mode="test", ref_poses=ref, ref_images=batch.images[:, :n_views],
+                           ref_feats_list=feats)
+        with hip.knob("cv_mm", 0):
+            walk = model.render(opt, tgt, ray_range=(first, cnt), mode="test", ref_poses=ref, ref_images=batch.images[:, :n_views],
+                                ref_feats_list=feats)
+            sub_w = model.render(opt, tgt, ray_idx=first + torch.arange(cnt, device="cuda"), mode="test", ref_poses=ref,
+                                 ref_images=batch.images[:, :n_views], ref_feats_list=feats)
+    assert torch.equal(run.rgb[0], rgb[0, first:first + cnt]) and torch.equal(run.depth[0], depth[0, first:first + cnt])
+    assert torch.equal(run.opacity[0], opacity[0, first:first + cnt])
+    assert linf(sub.rgb[0], rgb[0, idx]) < 2e-5 and linf(sub.opacity[0], opacity[0, idx]) < 2e-5 and linf(sub.depth[0], depth[0, idx]) < 1e-4
+    for k in ("rgb", "depth", "opacity"):
+        assert torch.equal(walk[k], sub_w[k])
+
+
+def test_fullsize_ray_subset_is_bit_identical(full_frame):
+    opt, model, batch, _, rgb, depth, opacity = full_frame
     with torch.no_grad():
         feats = model.get_img_feat(batch.images[:, :3], cur_n_src_views=3)
-        sub = model.render(opt, tgt, ray_idx=idx, mode="test", ref_poses=ref, ref_images=batch.images[:, :3],
-                           ref_feats_list=feats)
-    assert torch.equal(sub.rgb[0], rgb[0, idx])
-    assert torch.equal(sub.depth[0], depth[0, idx])
-    assert torch.equal(sub.opacity[0], opacity[0, idx])
+    _subset_checks(model, opt, batch, feats, 3, 512, 640, rgb, depth, opacity, 5000, 5)
 
 
 def test_fullsize_chunking_is_bit_identical(full_frame, monkeypatch):
@@ -170,7 +189,7 @@ def test_fullsize_opacity_closed_form_and_cost_volume_range(full_frame):
     host = lambda t: t.detach().float().cpu().numpy()
     images_cl = torch.zeros(1, 3, 512, 640, 4, device="cuda")
     images_cl[..., :3] = batch.images[:, :3].permute(0, 1, 3, 4, 2)
-    sc = model._scene(0, (host(ref["extrinsics"]), host(ref["intrinsics"]), host(ref["near_fars"])), feats, images_cl)
+    sc = model._scene_mm(0, (host(ref["extrinsics"]), host(ref["intrinsics"]), host(ref["near_fars"])), feats, images_cl)
     dec = model._decoder(64, torch.device("cuda"))
     kinv, c2w = camera.target_ray_consts(host(tgt["extrinsics"])[0], host(tgt["intrinsics"])[0], True)
     nf = host(tgt["near_fars"])[0]
@@ -253,13 +272,7 @@ def test_big_frame_outputs_are_finite_and_bounded(big_frame):
 def test_big_frame_ray_subset_is_bit_identical(big_frame):
     name, c, opt, model, _, batch, _, feats, rgb, depth, opacity = big_frame
     h, w = c["hw"]
-    idx = torch.randperm(h * w, generator=torch.Generator().manual_seed(9))[:3000].cuda()
-    tgt, ref = model.extract_poses(batch)
-    with torch.no_grad():
-        sub = model.render(opt, tgt, ray_idx=idx, mode="test", ref_poses=ref, ref_images=batch.images[:, :c["n_views"]],
-                           ref_feats_list=feats)
-    assert torch.equal(sub.rgb[0], rgb[0, idx]) and torch.equal(sub.opacity[0], opacity[0, idx])
-    assert torch.equal(sub.depth[0], depth[0, idx])
+    _subset_checks(model, opt, batch, feats, c["n_views"], h, w, rgb, depth, opacity, 3000, 9)
 
 
 def test_big_frame_slab_matches_oracle(big_frame):
@@ -291,7 +304,7 @@ def test_big_frame_opacity_closed_form(big_frame):
     n0, n = (h // 3) * w, 2048
     tgt, ref = model.extract_poses(batch)
     ref_host, images_cl = model._frame_ctx(ref, batch.images[:, :v])
-    sc = model._scene(0, ref_host, feats, images_cl)
+    sc = model._scene_mm(0, ref_host, feats, images_cl)
     dec = model._decoder(S, torch.device("cuda"))
     t_ex, t_in, t_nf = model._tgt_host(tgt)
     kinv, c2w = camera.target_ray_consts(t_ex[0], t_in[0], True)

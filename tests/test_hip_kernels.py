@@ -234,6 +234,18 @@ def test_fast_fp16_mode_is_reduced_precision_and_says_so(hip, name):
     assert linf(rgb_s.reshape(g["rgb_samples"].shape), g["rgb_samples"]) < 1e-2  # observed 1.1e-3 .. 1.9e-3 (profiles/r5_fast_mode_err.log)
     assert linf(rgb, g["rgb"][0, sel]) < 1e-2 and linf(opacity, g["opacity"][0, sel, 0]) < 1e-2  # observed <= 2.2e-3
     assert linf(rgb_s, out["f16x3"][3]) > 1e-5  # one product is not three
+    # north_star's second gate, "PSNR delta < 0.01 dB": PSNR against the scene's target image (the pseudo ground truth of the
+    # goldens; metrics.py:19-41 on these pixels) of the fast render vs the parity render - and the same delta for a render that
+    # were 30 dB from its ground truth (a trained model; README.md:136-141), where the fast mode's deviation weighs most
+    h, w = batch["images"].shape[-2:]
+    gt = batch["images"][0, -1].permute(1, 2, 0).reshape(h * w, 3)[torch.from_numpy(sel).long()]
+    psnr = {m: -10.0 * torch.log10(((out[m][0].cpu() - gt) ** 2).mean()) for m in out}
+    assert abs(float(psnr["f16"] - psnr["f16x3"])) < 0.01
+    rms = float(((out["f16"][0] - out["f16x3"][0]) ** 2).mean().sqrt())
+    mse30 = 1e-3  # 30 dB
+    assert 10.0 * np.log10(1.0 + rms ** 2 / mse30) < 0.01  # deviation uncorrelated with the residual: 0.0003 .. 0.0008 dB
+    # (were it perfectly aligned with the residual - it is not a systematic bias - the bound would be 0.07 .. 0.12 dB)
+    assert 10.0 * np.log10((np.sqrt(mse30) + rms) ** 2 / mse30) < 0.2
     if name == "c1_default":
         table = torch.zeros(2, hip.MNERF_POSE_FLOATS, device="cuda")
         n = idx.numel() - idx.numel() % 64

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 
 
 def video(model, batch, batching, n_frames):
+    """(cv_mm = 0: a pose table travels with the segment walk - the matrix form of the cost volume takes one pose per launch -
+    so the pose-by-pose side is pinned to the walk as well: the claim under test is about the table, not about the kernel)"""
     model.opts.nerf.video_n_frames = n_frames
     model.pose_batching = batching
-    with torch.no_grad():
+    with torch.no_grad(), hip.knob("cv_mm", 0):
         out = model(EasyDict(dict(batch)), mode="test", render_video=True, render_path_mode="interpolate")
     return {k: out[k].clone() for k in ("rgb", "depth", "opacity")}
 
