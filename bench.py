@@ -29,10 +29,10 @@ Also in the JSON line (N = 1):
                 stream inside the timed region, against the ceiling of the matrix path IN USE (dense 16-bit
                 MFMA peak / products per MAC: 833 TFLOP/s for f16x3, 417 for bf16x6; 157.3 for the exact-f32
                 MFMA); next to it the same rate against the 2.5 PFLOP/s dense 16-bit peak, the measured MFMA-busy
-                fraction and HBM-side bytes per launch from the committed PMC passes (profiles/decoder_counters.json,
+                fraction and HBM-side bytes per launch from the committed PMC passes (profiles/current/decoder_counters.json,
                 ignored when the kernel sources changed since).
-                roofline.cost_volume: the second kernel of the frame (32 %, no matrix instructions): busy fractions of
-                the units that bind it (texture-address unit / vector L1, vector ALU) from profiles/cost_volume_counters.json
+                roofline.cost_volume: the second kernel of the frame (26 %; round 6: on the matrix pipe): busy fractions of
+                the units that bind it (texture-address unit / vector L1, vector ALU) from profiles/current/cost_volume_counters.json
                 (hash-guarded like the decoder's) and the same per-launch counts over THIS run's launch time.
                 roofline.frame: the step as a whole and its render kernels in rays/s against the matrix-path bound and
                 the vector-L1 tap bound (measured tap bytes per ray); every fraction in the line is <= 1.
@@ -84,7 +84,7 @@ def measured_counters(kernel_prefix, filename="decoder_counters.json", hash_name
     from matchnerf_amd.csrc import build
     now = getattr(build, hash_name)()
     try:
-        with open(os.path.join(REPO, "profiles", filename)) as f:
+        with open(os.path.join(REPO, "profiles", "current", filename)) as f:
             c = json.load(f)
     except Exception:  # noqa: BLE001
         return None
@@ -309,10 +309,11 @@ def main():
     torch.backends.cudnn.benchmark = False
 
     opt, model, weights = build_model(device)
-    scene, batch = make_batch(device, target_shift=rank)
+    rows_mode = args.shard == "rows" and world > 1
+    # views: every rank renders its own target pose; rows: ALL ranks render bands of the same frame (rank 0's pose)
+    scene, batch = make_batch(device, target_shift=0 if rows_mode else rank)
     n_rays = H * W
 
-    rows_mode = args.shard == "rows" and world > 1
     spans = []  # per step: (start, after the render, after the gather) events of this rank
 
     def step(timer=None):
@@ -346,6 +347,7 @@ def main():
     mdist.barrier()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, device)
     assert full.shape == ((1 if rows_mode else world) * n_rays, 5) and bool(torch.isfinite(full).all())
+    frame_bits = "%012x" % (int(full.contiguous().view(torch.int32).to(torch.int64).sum()) & 0xffffffffffff)
     # per-rank milliseconds per step (frame incl. encoder | of it the gather), collected on every rank
     mine = torch.tensor([sum(a.elapsed_time(c) for a, _, c in spans) / max(len(spans), 1),
                          sum(b.elapsed_time(c) for _, b, c in spans) / max(len(spans), 1)], device=device)
@@ -484,13 +486,25 @@ def main():
         if not fused:
             cvk = ksum["cost_volume"]
             cv_secs = cvk["avg_ms"] * 1e-3
+            mm_form = bool(getattr(model, "cv_matrix_form", False)) and os.environ.get("MNERF_CV_MM", "1") != "0"
             cv_entry = {
-                "kernel": "cost_volume_lean_kernel<8,false,false> (epipolar register-quad walk, group cosines, colours, masks; 0 MFMA)",
-                "bound": "vector-memory pipeline (texture-address unit / vector L1 -> registers) and vector ALU, co-bound",
+                "kernel": ("cost_volume_mm_kernel (matrix form: per 8x4-pixel tile and depth index the 128-channel bilinear "
+                           "interpolation of every (pair, scale) as v_mfma_f32_32x32x16_f16 over 4x4-texel chunks of a split-fp16 "
+                           "operand image; dot products, cosines, colours, masks on the vector ALU)") if mm_form else
+                          "cost_volume_lean_kernel<8,false,false> (epipolar register-quad walk, group cosines, colours, masks; 0 MFMA)",
+                "bound": ("none of its three units saturated (vector memory path 0.6, vector ALU 0.5, matrix pipe 0.25 busy): "
+                          "latency-bound at two waves per SIMD (256 registers: 128 accumulators + operands); DESIGN.md section 4") if mm_form
+                         else "vector-memory pipeline (texture-address unit / vector L1 -> registers) and vector ALU, co-bound",
                 "avg_launch_ms": round(cvk["avg_ms"], 4), "launch_rays": int(cvk["rays"] / cvk["launches"]),
                 "counters_source": cvc.get("source") if cv_fresh else
-                "profiles/cost_volume_counters.json is stale or absent: re-run tools/profile_round.sh",
+                "profiles/current/cost_volume_counters.json is stale or absent: re-run tools/profile_round.sh",
             }
+            if cv_fresh and mm_form != str(cvc.get("kernel", "")).startswith("cost_volume_mm"):
+                cv_fresh = False  # the committed counters belong to the other kernel
+                cv_entry["counters_source"] = "profiles/current/cost_volume_counters.json was measured on the other cost-volume kernel"
+            if cv_fresh and cvc.get("mfma_insts_per_launch"):
+                cv_entry.update({"mfma_insts_per_launch": cvc.get("mfma_insts_per_launch"), "mfma_busy_frac_measured": cvc.get("mfma_busy_frac"),
+                                 "issued_matrix_tflops": round(cvc["mfma_insts_per_launch"] * 2 * 32 * 32 * 16 / cv_secs / 1e12, 1)})
             if cv_fresh:
                 valu, l1b = cvc.get("valu_insts_per_launch"), cvc.get("l1_bytes_per_launch")
                 cv_entry.update({
@@ -546,6 +560,9 @@ def main():
                                         "1e-4 parity gate (not the default; a headline measured in it is not the parity-mode figure)"}[math],
                 "other_decoder_math": other_math or None,
                 "rays_per_step_per_gpu": n_rays, "kernel_launch_rays": int(launch_rays),
+                # 48-bit sum over the bit patterns of the last step's gathered output [rays, rgb | depth | opacity]: equal sums
+                # <=> (almost surely) equal frames; rows mode at any rank count must give the 1-GPU frame's sum
+                "frame_bits": frame_bits,
                 "parallelism": (f"row bands of one frame x{world} (strong scaling)" if rows_mode else
                                 f"target views x{world}") if world > 1 else "single GPU",
                 "per_rank_ms_per_step": {"what": "[step incl. encoder and gather, of it the gather] per rank, device events",
@@ -583,7 +600,7 @@ def main():
                 "traffic_algorithmic_bytes": (int(launch_rays * 296) if fused else  # 8d: compulsory bytes per ray
                                               int(samples_launch * 96 + launch_rays * 20)),
                 "counters_source": (counters.get("source") if fresh else
-                                    ("profiles/decoder_counters.json is stale or absent: re-run tools/profile_round.sh" if
+                                    ("profiles/current/decoder_counters.json is stale or absent: re-run tools/profile_round.sh" if
                                      counters is None or counters.get("stale") else None)),
                 "avg_launch_ms": round(dec["avg_ms"], 4), "flops_per_launch": flops_launch,
                 "issued_flops_per_launch": issued_launch,

@@ -42,7 +42,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 def source_hash():
     """sha256 over everything the decoder kernel is compiled from (its sources, the argument structs it takes from the
-    ABI header, the compiler flags): identifies the build that profile-derived numbers (profiles/decoder_counters.json)
+    ABI header, the compiler flags): identifies the build that profile-derived numbers (profiles/current/decoder_counters.json)
     belong to, so that bench.py can tell when they have gone stale.  (Other kernels' sources and the rest of the header
     are left out: a change in the encoder does not change the decoder's counters.)"""
     import hashlib
@@ -63,7 +63,7 @@ COST_VOLUME_SOURCES = ["cost_volume.hip", "cost_volume_mm.hip", "cv_walk.hpp", "
 
 
 def cost_volume_source_hash():
-    """The same for the stand-alone cost-volume kernel (profiles/cost_volume_counters.json)."""
+    """The same for the stand-alone cost-volume kernel (profiles/current/cost_volume_counters.json)."""
     import hashlib
     import re
     h = hashlib.sha256(" ".join(FLAGS + EXTRA_FLAGS.get("cost_volume.hip", [])).encode())

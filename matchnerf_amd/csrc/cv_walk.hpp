@@ -448,18 +448,10 @@ __host__ __device__ inline int cv_slot_lds_floats(int seg, int n_views, int sum_
 // the stand-alone kernel, LDS in the fused ray-chunk kernel), rows are `cond_stride` floats apart; samples at or
 // beyond S are computed on the last real sample and not written.  uv / wrec / cs: this slot's LDS scratch.
 // Only wave-level synchronisation inside (the lanes of a slot belong to one wave).
-#ifndef MNERF_NT_COND
-#define MNERF_NT_COND 0  // see decoder.hip: non-temporal row traffic measured slower, kept as a build-time experiment
-#endif
-// row stores of the stand-alone form (NT only has an effect when MNERF_NT_COND is built in)
+// row stores of the stand-alone form (the NT flag marked the rows for non-temporal stores in a round-2 experiment: measured slower,
+// tools/exp/patches/decoder_experiments_until_r5.patch)
 template <bool NT>
 __device__ __forceinline__ void cv_store(float* p, float v) {
-#if MNERF_NT_COND
-  if constexpr (NT) {
-    __builtin_nontemporal_store(v, p);
-    return;
-  }
-#endif
   *p = v;
 }
 

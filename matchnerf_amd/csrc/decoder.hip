@@ -371,17 +371,7 @@ __device__ __forceinline__ void kblock(f32x16 (&acc)[NMB], unsigned base_lds, in
 // Measured on MI355X (profiles/r2_nt_*): HBM-side counters unchanged (the scratch lines it was meant to protect are
 // written back either way), cost volume 9.8 -> 11.2 ms, decoder unchanged.  The write-then-read pair of the staged
 // form is served best by the default cache policy.
-#ifndef MNERF_NT_COND
-#define MNERF_NT_COND 0
-#endif
 __device__ __forceinline__ float4 ld_stream4(const float* p, bool lds) {
-#if MNERF_NT_COND
-  if (!lds) {
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
-  }
-#endif
   return *reinterpret_cast<const float4*>(p);
 }
 
@@ -1655,16 +1645,9 @@ struct SmemPP {
 // spills.  Activation half first, the activations are consumed where they are produced and the encoding is evaluated in
 // the short phase V_7.  The layer's sum is then accumulated in the other order, so this kernel's results differ from
 // decoder_kernel's in the last bits (not from one launch to the next: tests/test_stress_gpu.py).
-#ifndef MNERF_PP_L5_H_FIRST
-#define MNERF_PP_L5_H_FIRST 1
-#endif
 __device__ __host__ constexpr int pp_p0(int s, int fs = 2) {
   if (s == 0) return 1 + 8 * fs;  // FiLM: header + fs K16-steps x 4 blocks x (hi | lo)
-#if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 32, 33, 17, 33, 17, 9};
-#else
-  constexpr int t[PP_STAGES] = {17, 33, 33, 33, 33, 33, 33, 32, 17, 33, 17, 9};
-#endif
   return t[s];
 }
 // The ping-pong kernel's schedule is ONE fixed schedule (the host refuses anything else), so the position of every segment in
@@ -1683,33 +1666,25 @@ __device__ __host__ constexpr int pp_stream_off_floats(int k, int fs = 2) {
   return o;
 }
 __device__ __host__ constexpr int pp_seg_first(int s) {
-#if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {0, 1, 2, 4, 6, 8, 11, 10, 13, 14, 16, 18};
-#else
-  constexpr int t[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
-#endif
   return t[s];
 }
 __device__ __host__ constexpr int pp_seg_off_floats(int s, int i, int fs = 2) { return pp_stream_off_floats(pp_seg_first(s) + i, fs); }
-#ifndef MNERF_PP_DMA_IN_M
-#define MNERF_PP_DMA_IN_M 0  // measured (r4l, same box, 3 runs each): 4 -> 16.45-16.53 ms per frame, 2 -> 16.54-16.76, 0 -> 16.35-16.43
-#endif
 // how many of a wave's requests for stage n are issued inside the matrix phase M_{n-1} (decoder_pp_kernel: pp_m_dma).  Stages
 // whose previous matrix phase is not a plain ksteps_presplit2 call (M_0: FiLM + geometry, M_1 / M_7: the encoding halves with
 // the operand split between them) or has the next tile's first stage in flight (M_11) keep every request in the vector phase.
+// PP_DMA_IN_M = 0: no request is issued inside a matrix phase (4 measured 16.45-16.53, 2: 16.54-16.6 against 16.35-16.43 ms per
+// frame with all of them in the vector phases: profiles/history/r4_variants.md); the mechanism stays for the next attempt
+constexpr int PP_DMA_IN_M = 0;
 __device__ __host__ constexpr int pp_km(int n) {
-  const int enc_stage = MNERF_PP_L5_H_FIRST ? 7 : 6;  // the stage AFTER the encoding half of layer 5 stays in the burst
+  const int enc_stage = 7;  // (layer 5 takes its activation half first) the stage AFTER the encoding half of layer 5 stays in the burst
   if (n < 3 || n > 11 || n == enc_stage + 1) return 0;
   // requests k = 0 .. km-1 of a wave are pieces 2 tw + half + 8 k of the stage's first segment: they must exist for tw = 3, half = 1
   const int fit = pp_p0(n) / 8;  // largest km with 7 + 8 (km - 1) < pp_p0
-  return fit < MNERF_PP_DMA_IN_M ? fit : MNERF_PP_DMA_IN_M;
+  return fit < PP_DMA_IN_M ? fit : PP_DMA_IN_M;
 }
 __device__ __host__ constexpr int pp_p1(int s) {
-#if MNERF_PP_L5_H_FIRST
   constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 32, 0, 0, 32, 20, 0};
-#else
-  constexpr int t[PP_STAGES] = {0, 0, 32, 32, 32, 32, 0, 32, 0, 32, 20, 0};
-#endif
   return t[s];
 }
 
@@ -2078,15 +2053,9 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   }
   segment_wait();
   __syncthreads();
-  // Static issue priority for team B (experiment, MNERF_PP_BPRIO=1; default off).  Waves 4-7 are dispatched second, and between
-  // two waves of a SIMD at equal priority the OLDER one wins the vector-issue arbitration: round 4's first timeline had team
-  // B's matrix phases at 4.6 k cycles against team A's 3.85 k, its T2 at 12.6 k against 9.9 k.  One s_setprio for the whole
-  // kernel, no per-phase flips (MI355X_MICROARCH.md "two waves per SIMD", item 4).  MEASURED: priority only moves the loss to the
-  // other team (B's matrix phases 3.75 k, A's T2 16.9 k against B's 8.5 k): 18.99 vs 18.82 ms per frame, no gain.
-#ifndef MNERF_PP_BPRIO
-#define MNERF_PP_BPRIO 0
-#endif
-  if (MNERF_PP_BPRIO && team == 1) __builtin_amdgcn_s_setprio(MNERF_PP_BPRIO);
+  // (A static issue priority for team B - waves 4-7 are dispatched second, and between two waves of a SIMD at equal priority
+  // the OLDER one wins the vector-issue arbitration - was measured in round 4: it only moves the loss to the other team, 18.99
+  // against 18.82 ms per frame; profiles/history/r4_variants.md.)
   if (team == 1) __syncthreads();  // team B runs one phase behind team A from here on
 
   int tile_begin = blockIdx.x, tile_end = n_tiles, tile_step = gridDim.x;
@@ -2134,34 +2103,19 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 // per-lane offset in the vector ALU (glds16_sv) instead of ~200 distinct loop-invariant `stream + constant` pointers, which the
 // compiler hoisted out of the tile loop and parked in VGPR lanes (two v_readlane per request).  Bit-identical; same-box A/B
 // (gpurun_out/r5_3): 17.11 -> 16.99 ms per frame at S = 64, 36.9 -> 36.5 at S = 128.
-#ifndef MNERF_PP_DMA_VOFF
-#define MNERF_PP_DMA_VOFF 1
-#endif
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
-#ifdef MNERF_EXP_NO_DMA  // timing experiment (wrong results): what do the weight requests cost in total?
-    return;
-#endif
     unsigned voff = (unsigned)lane0 * 16u;
     asm volatile("" : "+v"(voff));
-#if MNERF_PP_DMA_VOFF
     int twl = tw;  // opaque: the requests' offsets are computed where they are used (see stage_piece)
     asm volatile("" : "+s"(twl));
-#else
-    const int twl = tw;
-#endif
     for (int i = 0; i < 2; ++i) {
       const int pieces = i == 0 ? pp_p0(s, FS) : pp_p1(s);
       const unsigned base = PP_SLOT_LDS(s, i);
       const int first = half == 2 ? twl : 2 * twl + half, step = half == 2 ? 4 : 8;
-#if MNERF_PP_DMA_VOFF
       for (int p = first; p < pieces; p += step)
         glds16_sv(D.wstream, voff, (unsigned)pp_seg_off_floats(s, i, FS) * 4u + (unsigned)p * 1024u,
                   __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
-#else
-      const float* src = PP_SEG_SRC(s, i);
-      for (int p = first; p < pieces; p += step) glds16_s(src + p * 256, voff, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
-#endif
     }
   };
   // ---- weight requests of a vector phase.  MNERF_PP_DMA_SPREAD = 0 (round 3): team A asks for its half of stage s (the odd
@@ -2173,9 +2127,6 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   // MEASURED (gpurun_out r4b, profiles/r4_variants.md): slower. Every request still stalls its wave (the queue is full whenever
   // eight waves feed it), now ten times per phase behind a scheduling fence each: vector phases 3.9 k -> 4.7 k cycles, decoder
   // 18.2 -> 19.0 ms per frame.  The bursts stay.
-#ifndef MNERF_PP_DMA_SPREAD
-#define MNERF_PP_DMA_SPREAD 0  // measured (round 4, same box): spread 18.99 ms per frame, bursts 18.20 - see below
-#endif
   int dma_k = 0;  // requests of the current vector phase already made by this wave (compile-time after unrolling)
   auto stage_piece = [&](int s, int half, int k) {
     const int i = k / 5;
@@ -2206,29 +2157,12 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       ++dma_k;
     }
   };
-#if MNERF_PP_DMA_SPREAD
-#define PP_BEGIN_V(stage_) do { dma_k = 0; } while (0)
-#define PP_DMA(sa_, sb_, n_) dma_some(sa_, sb_, n_)
-#define PP_END_V(sa_, next_stage_)                                  \
-  do {                                                              \
-    dma_some(sa_, next_stage_, 10);                                 \
-    if (team == 0) segment_wait();                                  \
-    PP_SYNC();                                                      \
-  } while (0)
-#else
   // MNERF_PP_B_EARLY (round 4, after the issue microbenchmark tools/exp/ubench/mfma_issue.hip): team B asks for its half of
   // stage s+1 at the START of its V_s instead of at its end.  The ring slots of stage s+1 are free from that point (their last
   // reader was team B's own M_{s-1}); asked for at the end of the phase, B's burst met team A's burst at the start of A's
   // V_{s+1} right behind the barrier — 65 KiB requested at once, and both teams stalled longer per request than one team's burst
   // alone does (~95 cycles).  Measured: 16.43-16.50 against 16.51-16.68 ms per frame (same box, three runs each).  V_0 keeps the late request: its rows sit in that buffer.
-#ifndef MNERF_PP_B_EARLY
-#define MNERF_PP_B_EARLY 1
-#endif
-#ifdef MNERF_EXP_NO_WAIT  // timing experiment (racy): the trunk's waits for the weight requests removed
-#define PP_SEGMENT_WAIT() do {} while (0)
-#else
 #define PP_SEGMENT_WAIT() segment_wait()
-#endif
   // MNERF_PP_DMA_IN_M = KM (round 4 experiment, default 0): the first KM of a wave's (up to 10) requests for stage n go out INSIDE
   // the matrix phase M_{n-1}, behind its matrix instructions (pp_m_dma below), the rest in the burst of the vector phase.  A
   // request stalls the issuing wave ~95 cycles in a vector phase and ~50 among matrix instructions
@@ -2267,56 +2201,30 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 #define PP_BEGIN_V(stage_)                                                          \
   do {                                                                              \
     if (team == 0) burst_from(stage_, 1, pp_km(stage_));                            \
-    else if (MNERF_PP_B_EARLY && (stage_) + 1 < PP_STAGES) burst_from((stage_) + 1, 0, pp_km((stage_) + 1)); \
+    else if ((stage_) + 1 < PP_STAGES) burst_from((stage_) + 1, 0, pp_km((stage_) + 1)); \
   } while (0)
   (void)dma_some;
 #define PP_DMA(sa_, sb_, n_) do {} while (0)
 #define PP_END_V(sa_, next_stage_)                                  \
   do {                                                              \
-    if (team == 1) { if ((next_stage_) >= 0 && (!MNERF_PP_B_EARLY || (sa_) < 0)) stage_dma(next_stage_, 0); } \
+    if (team == 1) { if ((next_stage_) >= 0 && (sa_) < 0) stage_dma(next_stage_, 0); } \
     else PP_SEGMENT_WAIT();                                         \
     PP_SYNC();                                                      \
   } while (0)
-#endif
 #define PP_END_M()                   \
   do {                               \
     if (team == 1) PP_SEGMENT_WAIT();   \
     PP_SYNC();                       \
   } while (0)
   // M_s: stage s's matrix instructions (+ team A: the requests for stage NXT_)
-#ifndef MNERF_PP_T4_DPP
-#define MNERF_PP_T4_DPP 1  // compositing scan / sums through DPP row operations instead of ds_bpermute shuffles (wave_sum_dpp):
-#endif                     // measured 16.77 -> 16.42 ms per frame (same box, two runs each); 0 restores the shuffles
-#ifndef MNERF_PP_PAIRS
-#define MNERF_PP_PAIRS 0  // 1: the two blocks of a pair interleaved, no back-to-back dependent MFMAs (measured: no faster, more spills)
-#endif
 // MNERF_PP_MPRIO (experiment, default 0): issue priority of a wave while it is in a matrix phase — its MFMAs then win the
 // SIMD's arbitration against the other team's vector instructions.
-#ifndef MNERF_PP_MPRIO
-#define MNERF_PP_MPRIO 0
-#endif
-#if MNERF_PP_MPRIO
-#define PP_PRIO_UP() __builtin_amdgcn_s_setprio(MNERF_PP_MPRIO)
-#define PP_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
-#else
 #define PP_PRIO_UP() do {} while (0)
 #define PP_PRIO_DOWN() do {} while (0)
-#endif
-#ifdef MNERF_EXP_NO_MFMA  // timing experiment (wrong results): the trunk's matrix phases empty -> what the vector side alone takes
-#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) do {} while (0)
-#elif MNERF_PP_PAIRS
-#define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2p<NMB_, NS0_, NS1_>(acc_, base0_, base1_, lane, hs_)
-#else
 #define PP_MFMA_(NMB_, NS0_, NS1_, acc_, base0_, base1_, hs_) ksteps_presplit2<NMB_, NS0_, NS1_, NPK>(acc_, base0_, base1_, lane, hs_)
-#endif
-#if defined(MNERF_EXP_NO_MFMA) || MNERF_PP_PAIRS
-#define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_) \
-  PP_MFMA_(NMB_, NS0_, NS1_, acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), hs_)
-#else
 #define PP_MFMA_HOOKED(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                      \
   ksteps_presplit2<NMB_, NS0_, NS1_, NPK>(acc_, PP_SLOT_LDS(s_, 0) + (hdr_bytes_), PP_SLOT_LDS(s_, 1), lane, hs_,        \
                                      [&](int i_, unsigned la_, unsigned lb_) { pp_m_dma(s_, ((NS0_) + (NS1_)) * (NMB_), i_, la_, lb_); })
-#endif
 #define PP_MFMA(NMB_, NS0_, NS1_, acc_, s_, hdr_bytes_, hs_)                                                   \
   do {                                                                                                         \
     PP_PRIO_UP();                                                                                              \
@@ -2518,7 +2426,6 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_HIDDEN_LAYER(4);
     PP_HIDDEN_LAYER(5);
 #undef PP_HIDDEN_LAYER
-#if MNERF_PP_L5_H_FIRST
     // ============================================================ layer 5 = [enc, h] -> 128 (stage 6: activation half, 7: encoding half)
     // V_6: FiLM + ReLU of layer 4 in place, its operands with the gain BOTH halves share, the layer's biases (they sit in the
     // header of the encoding half's segment, resident as header 7)
@@ -2542,32 +2449,6 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     PP_END_V(7, 8);
     PP_ENC_MFMA(acc, 7, mult_l5);  // M_7: += W5[:, :enc] . enc
     PP_END_M();
-#else
-    // ============================================================ layer 5 = [enc, h] -> 128 (stages 6: enc part, 7: h part)
-    // V_6: FiLM + ReLU of layer 4 into h (its operands are split in V_7), encoding operands with the common gain
-    int eg;
-    f32x16 h5[4];  // layer 4's activations wait here while the accumulators take the encoding part of layer 5
-    PP_BEGIN_V(6);
-    {
-      hmax = film_relu(h5);
-      eg = gain_exp(fmaxf(enc_max, hmax * pow2i(ec)));
-      __builtin_amdgcn_sched_barrier(0);  // three separate steps: activations (64 registers), encoding operands, then the
-      split_enc_half(0, pow2i(eg));       // accumulators' biases — interleaved by the scheduler they do not fit 256 registers
-      split_enc_half(1, pow2i(eg));
-      __builtin_amdgcn_sched_barrier(0);
-      ew_cur = header_ew(PP_HDR_LDS(6));
-      bias_init_h<4>(acc, PP_HDR_LDS(6), hl, pow2i(ew_cur + eg));
-    }
-    PP_END_V(6, 7);
-    PP_MFMA(4, 4, 0, acc, 6, 1024u, hs);  // M_6
-    PP_END_M();
-    PP_BEGIN_V(7);
-    split_blocks(h5, pow2i(eg + ec), 7, 8);  // V_7
-    ec = -eg - ew_cur + ecf;
-    PP_END_V(7, 8);
-    PP_MFMA(4, 4, 4, acc, 7, 0u, hs);  // M_7
-    PP_END_M();
-#endif
     // ============================================================ alpha head (stage 8) and feature_linear (stage 9): same operands
     PP_BEGIN_V(8);
     hmax = film_relu(acc);  // V_8
@@ -2849,46 +2730,20 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
             c.w = c.w * (intv * rlen);
           }
         }
-#if MNERF_PP_T4_DPP
         const float excl = carry + wave_exclusive_sum_dpp(c.w, lane);
-#else
-        float incl = __shfl_up(c.w, 1, 64);
-        if (lane == 0) incl = 0.0f;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const float t = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += t;
-        }
-        const float excl = carry + incl;
-#endif
         const float w = ok ? expf(-excl) * (1.0f - expf(-c.w)) : 0.0f;
         ar += w * c.x;
         ag += w * c.y;
         ab += w * c.z;
         ad += w * dd;
         ao += w;
-#if MNERF_PP_T4_DPP
         carry = readlane_f(excl + c.w, 63);
-#else
-        carry = __shfl(excl + c.w, 63, 64);
-#endif
       }
-#if MNERF_PP_T4_DPP
       ar = wave_sum_dpp(ar);
       ag = wave_sum_dpp(ag);
       ab = wave_sum_dpp(ab);
       ad = wave_sum_dpp(ad);
       ao = wave_sum_dpp(ao);
-#else
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        ar += __shfl_xor(ar, off, 64);
-        ag += __shfl_xor(ag, off, 64);
-        ab += __shfl_xor(ab, off, 64);
-        ad += __shfl_xor(ad, off, 64);
-        ao += __shfl_xor(ao, off, 64);
-      }
-#endif
       if (lane == 0) {
         const float bg = D.setbg_opaque ? (1.0f - ao) : 0.0f;
         out_rgb[(size_t)rr * 3 + 0] = ar + bg;
@@ -3159,13 +3014,8 @@ static int launch_decoder(const char* who, const mnerf_decoder* dec, const mnerf
   const int fs = fused_scene ? 0 : pp_film_steps(dec, sch, Sp);
   if (fs) {
     PPSched pps;
-#if MNERF_PP_L5_H_FIRST
     const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 11, 10, 13, 14, 16, 18};  // layer 5: activation half, then encoding half
     const int nseg[PP_STAGES] = {1, 1, 2, 2, 2, 2, 2, 1, 1, 2, 2, 1};
-#else
-    const int first[PP_STAGES] = {0, 1, 2, 4, 6, 8, 10, 11, 13, 14, 16, 18};
-    const int nseg[PP_STAGES] = {1, 1, 2, 2, 2, 2, 1, 2, 1, 2, 2, 1};
-#endif
     for (int i = 0; i < PP_STAGES; ++i) {
       pps.seg_first[i] = first[i], pps.n_seg[i] = nseg[i];
       // the kernel's compile-time piece counts must be the schedule's

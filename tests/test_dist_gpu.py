@@ -100,6 +100,36 @@ def test_bench_self_spawns_two_ranks():
     assert j["config"]["rays_per_step_per_gpu"] == 512 * 640 and "roofline" in j
 
 
+def _bench(*flags, gpus):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MNERF_FORCE_DEVICE="0", MNERF_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-secondary", *flags], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """BASELINE config[3] as the driver will start it on an 8-GPU node - `bench.py --gpus 8`, both shard modes - with the eight
+    ranks sharing this box's one GPU (MNERF_FORCE_DEVICE=0) over gloo: the REAL model in eight processes, one JSON line with
+    n_gpus 8 and eight per-rank rows; the frame gathered from eight row bands has the bits of the frame one rank renders."""
+    one = _bench(gpus=1)
+    rows = _bench("--shard", "rows", gpus=8)
+    views = _bench("--shard", "views", gpus=8)
+    for j, scaling in ((rows, "strong"), (views, "weak")):
+        assert j["n_gpus"] == 8 and j["scaling"] == scaling and j["value"] > 0
+        assert len(j["config"]["per_rank_ms_per_step"]["ranks"]) == 8
+    assert rows["config"]["frame_bits"] == one["config"]["frame_bits"]
+    assert views["config"]["frame_bits"] != one["config"]["frame_bits"]  # eight different target poses
+
+
 def _nccl_one_rank_worker(port, q):
     try:
         os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),

@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc csv output -> profiles/decoder_counters.json (what bench.py's roofline object quotes).
+"""rocprofv3 --pmc csv output -> profiles/current/decoder_counters.json (what bench.py's roofline object quotes).
 
     python tools/pmc_to_json.py <dir with pmc_* runs of tools/prof_render.py> <frames per run> [out.json]
 
@@ -71,7 +71,8 @@ def cost_volume(acc, rows, frames, out):
     def per_launch(name):
         return c[name] / n[name] if name in c else None
 
-    res = dict(kernel=k, build_hash=cost_volume_source_hash(), frames_profiled=frames, launch_rays=65536,
+    n_launch = max(n.values())
+    res = dict(kernel=k, build_hash=cost_volume_source_hash(), frames_profiled=frames, launch_rays=65536, launches_profiled=n_launch,
                source=f"tools/profile_round.sh -> {os.path.basename(out)} (rocprofv3 --pmc passes over tools/prof_render.py)")
     cycles = per_launch("GRBM_GUI_ACTIVE")
     if cycles:
@@ -81,12 +82,16 @@ def cost_volume(acc, rows, frames, out):
                       ("SQ_INSTS_VMEM_RD", "vmem_rd_insts_per_launch"), ("TA_TA_BUSY_sum", "ta_busy_cycles_sum_per_launch"),
                       ("TCP_TOTAL_CACHE_ACCESSES_sum", "l1_accesses_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
                       ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_cycles_per_launch"), ("SQ_WAIT_ANY", "wait_any_quadcycles_per_launch"),
+                      ("SQ_WAIT_INST_ANY", "wait_inst_quadcycles_per_launch"), ("SQ_INSTS_SALU", "salu_insts_per_launch"),
+                      ("SQ_INSTS_MFMA", "mfma_insts_per_launch"), ("SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_cycles_per_launch"),
                       ("SQ_WAVE_CYCLES", "wave_quadcycles_per_launch")):
         v = per_launch(name)
         if v is not None:
             res[key] = v
     if cycles and "valu_active_quadcycles_per_launch" in res:
         res["valu_busy_frac"] = round(4 * res["valu_active_quadcycles_per_launch"] / (1024 * cycles), 4)
+    if cycles and res.get("mfma_busy_cycles_per_launch"):  # the matrix form (cost_volume_mm_kernel): matrix pipe busy over 1024 SIMDs
+        res["mfma_busy_frac"] = round(res["mfma_busy_cycles_per_launch"] / (1024 * cycles), 4)
     if cycles and "ta_busy_cycles_sum_per_launch" in res:
         res["ta_busy_frac"] = round(res["ta_busy_cycles_sum_per_launch"] / (256 * cycles), 4)
     if "l1_accesses_per_launch" in res:
@@ -100,4 +105,4 @@ def cost_volume(acc, rows, frames, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "profiles", "decoder_counters.json"))
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else os.path.join(REPO, "profiles", "current", "decoder_counters.json"))

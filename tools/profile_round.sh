@@ -2,8 +2,8 @@
 # One command that regenerates every profile-derived number of a round ON THE GPU BOX:
 #   tools/profile_round.sh r2_01
 # -> gpurun_out/<tag>/{kernel_stats.md, bench_kernel_stats.md, pmc_summary.txt, decoder_counters.json, cost_volume_counters.json}; copy
-# the ones to be judged into profiles/ (profiles/<tag>_kernel_stats.md, profiles/<tag>_pmc_summary.txt, profiles/decoder_counters.json,
-# profiles/cost_volume_counters.json).
+# the ones to be judged into profiles/ (profiles/current/<tag>_kernel_stats.md, profiles/current/<tag>_pmc_summary.txt, profiles/current/decoder_counters.json,
+# profiles/current/cost_volume_counters.json).
 # Kernel trace and PMC counters are collected in SEPARATE rocprofv3 runs (no sys / hip tracing with --pmc).
 TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; export TMPDIR=/tmp
