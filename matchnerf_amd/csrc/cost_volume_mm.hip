@@ -27,11 +27,14 @@
 //
 // OPERAND IMAGE (mnerf_cost_volume_operands; caller-owned buffer of mnerf_cost_volume_operand_bytes bytes):
 //   header  float gain[2][CVM_MAX_MAPS] | float inv_gain[2][CVM_MAX_MAPS] | u32 absmax_bits[2][CVM_MAX_MAPS]
-//   scale s [map = 2 pair + side][row pair rp][x block xb][channel tile ct (4)][hi | lo][32 channels][8 x fp16]
-//           the 8 values of (rp, xb, channel) are texels (row 2 rp + r, column 4 xb + c) at index 4 r + c, scaled by the map's
-//           gain (largest magnitude in [2^14, 2^15)); rows / columns outside the map and one extra row pair are zero-filled.
-//   = 4 KiB per (row pair, x block), the same bytes as the fp32 map.  A chunk = row pairs (p, p + 1) x one x block: lanes 0-31
-//   read 512 contiguous bytes per (channel tile, hi | lo) of row pair p, lanes 32-63 of row pair p + 1.
+//   scale s [map = 2 pair + side][row pair rp][column x][hi | lo][128 channels] dwords: one dword = the two fp16 values of texels
+//           (row 2 rp, column x) and (row 2 rp + 1, column x) of that channel, scaled by the map's gain (largest magnitude in
+//           [2^14, 2^15)); a row pair is fw + 3 columns wide (three zero columns) and one zero row pair follows the last.
+//   = 1 KiB per (row pair, column), the same bytes as the fp32 map.  A chunk = row pairs (p, p + 1) x FOUR CONSECUTIVE COLUMNS
+//   starting at ANY column: lanes 0-31 read 128 contiguous bytes per (column, hi | lo, channel tile) of row pair p, lanes 32-63 of
+//   row pair p + 1; the four dwords of a lane (one per column) are the A operand as they arrive (K index = 2 column + row).
+//   Anchoring a tile's chunks at its leftmost texel column - not at an aligned block of four - is what makes ONE chunk per
+//   (depth index, map) the rule at the DTU shape (tools/exp/cvmm_chunks.py: 1.00 chunks against 1.53 with aligned blocks).
 #include <stdlib.h>
 
 #include "cv_walk.hpp"
@@ -44,12 +47,12 @@ typedef unsigned cvm_u4 __attribute__((ext_vector_type(4)));
 
 #define CVM_MAX_MAPS (MNERF_MAX_VIEWS * (MNERF_MAX_VIEWS - 1))  // 2 sides x 120 pairs
 #define CVM_HDR_BYTES 8192
-#define CVM_CELL_BYTES 4096  // one (row pair, x block): 8 texels x 128 channels x (hi + lo) fp16
+#define CVM_COL_BYTES 1024   // one (row pair, column): 2 texels x 128 channels x (hi + lo) fp16
 #define CVM_TARGET_EXP 15    // largest |texel| of a map is scaled into [2^14, 2^15)
 #define CVM_UV_MAX_VIEWS MNERF_MAX_VIEWS
 
 struct CvmLayout {
-  int nrp[2], nxb[2];         // row pairs (incl. the zero one past the end), x blocks
+  int nrp[2], rs[2];          // row pairs (incl. the zero one past the end), columns per row pair (fw + 3 zero columns)
   size_t map_bytes[2], off[2], total;
 };
 
@@ -60,10 +63,10 @@ __host__ __device__ inline CvmLayout cvm_layout(const mnerf_scene& sc) {
   for (int s = 0; s < 2; ++s) {
     if (s < sc.n_scales) {
       L.nrp[s] = (sc.fh[s] + 1) / 2 + 1;  // + the zero pair a chunk's second half reads past the last row
-      L.nxb[s] = (sc.fw[s] + 3) / 4;
-      L.map_bytes[s] = (size_t)L.nrp[s] * L.nxb[s] * CVM_CELL_BYTES;
+      L.rs[s] = sc.fw[s] + 3;
+      L.map_bytes[s] = (size_t)L.nrp[s] * L.rs[s] * CVM_COL_BYTES;
     } else {
-      L.nrp[s] = L.nxb[s] = 0;
+      L.nrp[s] = L.rs[s] = 0;
       L.map_bytes[s] = 0;
     }
     L.off[s] = o;
@@ -99,15 +102,15 @@ __device__ __forceinline__ int cvm_gain_exp(float m) {
 }
 
 // ============================================================================ pre-pass 2: split + re-layout
-// one thread per (map, row pair, x block, channel): 8 texels of one channel -> hi8 | lo8
+// one thread per (map, row pair, column, channel): the two texels of a column -> one hi dword, one lo dword
 __global__ __launch_bounds__(256) void cvm_split_kernel(mnerf_scene sc, char* __restrict__ opnd) {
   const CvmLayout L = cvm_layout(sc);
   const int maps = sc.n_views * (sc.n_views - 1);
   const int s = (int)blockIdx.y >= maps ? 1 : 0, m = (int)blockIdx.y - s * maps;
   const int fh = sc.fh[s], fw = sc.fw[s];
   const int cell = (int)blockIdx.x * 2 + (int)(threadIdx.x >> 7), ch = threadIdx.x & 127;
-  if (cell >= L.nrp[s] * L.nxb[s]) return;
-  const int rp = cell / L.nxb[s], xb = cell - rp * L.nxb[s];
+  if (cell >= L.nrp[s] * L.rs[s]) return;
+  const int rp = cell / L.rs[s], x = cell - rp * L.rs[s];
   float* gain = reinterpret_cast<float*>(opnd);
   const unsigned* absmax_bits = reinterpret_cast<const unsigned*>(opnd + 2 * 2 * CVM_MAX_MAPS * 4);
   const int e = cvm_gain_exp(__uint_as_float(absmax_bits[s * CVM_MAX_MAPS + m]));
@@ -117,23 +120,21 @@ __global__ __launch_bounds__(256) void cvm_split_kernel(mnerf_scene sc, char* __
     gain[2 * CVM_MAX_MAPS + s * CVM_MAX_MAPS + m] = ldexpf(1.0f, -e);
   }
   const float* src = sc.feat[s] + (size_t)m * fh * fw * FEAT_C + ch;
-  cvm_h8 hi, lo;
+  cvm_h2 hi, lo;
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int y = 2 * rp + r, x = 4 * xb + c;
-      float v = 0.0f;
-      if (y < fh && x < fw) v = src[((size_t)y * fw + x) * FEAT_C];
-      v = v * g;                                        // exact (power of two) unless the product leaves the fp32 range
-      v = fminf(fmaxf(v, -65504.0f), 65504.0f);         // (only non-finite texels reach the clamp: NaN -> -65504)
-      const _Float16 h = (_Float16)v;                   // RNE
-      hi[4 * r + c] = h;
-      lo[4 * r + c] = (_Float16)(v - (float)h);
-    }
-  char* dst = opnd + L.off[s] + (size_t)m * L.map_bytes[s] + (size_t)cell * CVM_CELL_BYTES + (size_t)(ch >> 5) * 1024 + (size_t)(ch & 31) * 16;
-  *reinterpret_cast<cvm_h8*>(dst) = hi;
-  *reinterpret_cast<cvm_h8*>(dst + 512) = lo;
+  for (int r = 0; r < 2; ++r) {
+    const int y = 2 * rp + r;
+    float v = 0.0f;
+    if (y < fh && x < fw) v = src[((size_t)y * fw + x) * FEAT_C];
+    v = v * g;                                        // exact (power of two) unless the product leaves the fp32 range
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);         // (only non-finite texels reach the clamp: NaN -> -65504)
+    const _Float16 h = (_Float16)v;                   // RNE
+    hi[r] = h;
+    lo[r] = (_Float16)(v - (float)h);
+  }
+  char* dst = opnd + L.off[s] + (size_t)m * L.map_bytes[s] + (size_t)cell * CVM_COL_BYTES + (size_t)ch * 4;
+  *reinterpret_cast<cvm_h2*>(dst) = hi;
+  *reinterpret_cast<cvm_h2*>(dst + 512) = lo;
 }
 
 // ============================================================================ the kernel
@@ -149,10 +150,11 @@ __device__ __forceinline__ float cvm_fold_pair(float x, float y) {
 }
 
 // bilinear footprint of one ray in one map: top-left texel (xy = y0 << 16 | x0) and the four weights as two packed fp16 pairs
-// (row y0 / row y0 + 1: (weight of x0, weight of x0 + 1)), hi and lo terms.  bilin_setup()'s arithmetic (cv_walk.hpp).
+// (column x0 / column x0 + 1: (weight of row y0, weight of row y0 + 1)), hi and lo terms.  bilin_setup()'s arithmetic
+// (cv_walk.hpp).
 struct CvmTap {
   unsigned xy;
-  unsigned top_hi, bot_hi, top_lo, bot_lo;
+  unsigned c0_hi, c1_hi, c0_lo, c1_lo;
 };
 
 __device__ __forceinline__ unsigned cvm_pack_h2(float a, float b) {
@@ -184,15 +186,15 @@ __device__ __forceinline__ CvmTap cvm_tap(float u, float v, int h, int w, int& x
   x0 = (int)x0f;
   y0 = (int)y0f;
   t.xy = ((unsigned)y0 << 16) | (unsigned)x0;
-  t.top_hi = cvm_pack_h2(w00, w01);
-  t.bot_hi = cvm_pack_h2(w10, w11);
-  t.top_lo = cvm_pack_h2(cvm_resid_lo(w00, t.top_hi), cvm_resid_hi(w01, t.top_hi));
-  t.bot_lo = cvm_pack_h2(cvm_resid_lo(w10, t.bot_hi), cvm_resid_hi(w11, t.bot_hi));
+  t.c0_hi = cvm_pack_h2(w00, w10);
+  t.c1_hi = cvm_pack_h2(w01, w11);
+  t.c0_lo = cvm_pack_h2(cvm_resid_lo(w00, t.c0_hi), cvm_resid_hi(w10, t.c0_hi));
+  t.c1_lo = cvm_pack_h2(cvm_resid_lo(w01, t.c1_hi), cvm_resid_hi(w11, t.c1_hi));
   return t;
 }
 
-// Wave-uniform chunk range of one map.  Chunks are addressed on a grid anchored at the rays' smallest row pair / x block:
-// chunk (cr, cx) = row pairs p_lo + 2 cr, + 1 and x block xb_lo + cx.  `mask` holds one bit per chunk of the first 8 x 8 window
+// Wave-uniform chunk range of one map.  Chunks are addressed on a grid anchored at the rays' smallest row pair and leftmost
+// texel column: chunk (cr, cx) = row pairs p_lo + 2 cr, + 1 and columns xb_lo + 4 cx .. + 3  (xb_lo is a COLUMN, any alignment).  `mask` holds one bit per chunk of the first 8 x 8 window
 // of that grid (bit 8 cr + cx) that some ray's footprint touches: the chunk loop walks its set bits with scalar instructions.
 // A footprint wider than the window (`big`: magnifying or degenerate projections) takes the general loop over [p_lo, p_hi] x
 // [xb_lo, xb_hi].  (A footprint's second row / column beyond the map's last one carries weight exactly 0 - the coordinate was
@@ -207,17 +209,17 @@ struct CvmBox {
 // footprints (CvmTap, per lane) are read from the wave's LDS scratch when the side becomes the current one.
 struct CvmSide {
   const char* map;  // the map's operand image
-  int nxb;          // x blocks per row pair
+  int rs;           // columns per row pair in the operand image
   int item;         // view * n_scales + scale: index of the footprints / chunk range in the scratch
   CvmBox box;
   int p, xb;        // the side's first chunk
 };
 
-// a ray touches chunk (row pairs p, p + 1; x block xb) iff its 2 x 2 footprint intersects rows [2 p, 2 p + 4) x columns
-// [4 xb, 4 xb + 4)   (general loop only)
+// a ray touches chunk (row pairs p, p + 1; columns xb .. xb + 3) iff its 2 x 2 footprint intersects rows [2 p, 2 p + 4) x
+// columns [xb, xb + 4)   (general loop only)
 __device__ __forceinline__ bool cvm_occupied(const CvmTap& t, int p, int xb) {
   const int y0 = (int)(t.xy >> 16), x0 = (int)(t.xy & 0xffffu);
-  const bool mine = (unsigned)(y0 - 2 * p + 1) <= 4u && (unsigned)(x0 - 4 * xb + 1) <= 4u;
+  const bool mine = (unsigned)(y0 - 2 * p + 1) <= 4u && (unsigned)(x0 - xb + 1) <= 4u;
   return __builtin_amdgcn_ballot_w64(mine) != 0;
 }
 
@@ -226,35 +228,32 @@ __device__ __forceinline__ void cvm_pop(unsigned long long& m, const CvmBox& box
   const int bit = __builtin_ctzll(m);
   m &= m - 1;
   p = box.p_lo + 2 * (bit >> 3);
-  xb = box.xb_lo + (bit & 7);
+  xb = box.xb_lo + 4 * (bit & 7);
 }
 
-// B operand (hi and lo) of one chunk for this lane: rows 2 (p + half), 2 (p + half) + 1; columns 4 xb .. 4 xb + 3.
-// A row's packed pair E = (w(x0), w(x0 + 1)) lands at columns dx, dx + 1 of the four, the footprint's top row in row dy of the
-// lane's two: every output dword is ONE v_perm_b32 of (top, bottom) with a byte selector that depends on (dy, dx) only
-// (0x0c = constant zero, so a footprint that misses the chunk gives zeros by itself).  The four selectors of a (dy, dx) come
-// from a 35-entry table in LDS with one ds_read_b128.
+// B operand (hi and lo) of one chunk for this lane: rows 2 (p + half), 2 (p + half) + 1; columns xb .. xb + 3; operand dword c =
+// (weight of the upper row, weight of the lower row) in column xb + c  (K index 2 c + row, as the A operand).
+// A column's packed pair C = (w(y0), w(y0 + 1)) lands in the dword of column dx (C0) / dx + 1 (C1), shifted by the row offset dy
+// of the footprint's top row in the lane's row pair: every output dword is ONE v_perm_b32 of (C0, C1) with a byte selector
+// that depends on (dy, dx) only (0x0c = constant zero, so a footprint that misses the chunk gives zeros by itself).  The four
+// selectors of a (dy, dx) come from a 35-entry table in LDS with one ds_read_b128.
 #define CVM_LUT_ROWS 5  // dy clamped to [-2, 2]
-#define CVM_LUT_COLS 7  // k = dx + 1 clamped to [-1, 5]
+#define CVM_LUT_COLS 7  // dx clamped to [-2, 4]
 #define CVM_LUT_BYTES 576
-__device__ inline unsigned cvm_lut_word(int dyv, int kv, int slot, int d) {
-  // slot 0 (row 2 (p + half)): top if dy == 0, bottom if dy == -1; slot 1 (the row below): bottom if dy == 0, top if dy == 1
-  const int rowsrc = slot == 0 ? (dyv == 0 ? 1 : (dyv == -1 ? 0 : -1)) : (dyv == 0 ? 0 : (dyv == 1 ? 1 : -1));
-  if (rowsrc < 0) return 0x0c0c0c0cu;
-  const int kk = kv - 2 * d;  // columns 2, 3 see the pair two columns further left
-  const unsigned col = kk == 0 ? 0x0c0c0302u : (kk == 1 ? 0x03020100u : (kk == 2 ? 0x01000c0cu : 0x0c0c0c0cu));
-  unsigned out = 0;
-  for (int b = 0; b < 4; ++b) {
-    unsigned byte = (col >> (8 * b)) & 0xffu;
-    if (byte != 0x0cu && rowsrc == 1) byte += 4;  // v_perm_b32: bytes 4-7 = first source (top), 0-3 = second (bottom)
-    out |= byte << (8 * b);
-  }
-  return out;
+__device__ inline unsigned cvm_lut_word(int dyv, int dxv, int c) {
+  const int t = c - dxv;  // 0: column x0 (C0 = first source of v_perm_b32: bytes 4-7), 1: column x0 + 1 (C1: bytes 0-3)
+  if (t != 0 && t != 1) return 0x0c0c0c0cu;
+  const unsigned lo = t == 0 ? 0x0504u : 0x0100u, hi = t == 0 ? 0x0706u : 0x0302u;  // selectors of the pair's two halves
+  // dy = 0: the lane's rows are (y0, y0 + 1) -> (upper, lower); dy = 1: (-, y0) -> (0, upper); dy = -1: (y0 + 1, -) -> (lower, 0)
+  if (dyv == 0) return (hi << 16) | lo;
+  if (dyv == 1) return (lo << 16) | 0x0c0cu;
+  if (dyv == -1) return (0x0c0cu << 16) | hi;
+  return 0x0c0c0c0cu;
 }
 __device__ __forceinline__ void cvm_lut_init(unsigned* lut) {  // whole workgroup; the caller synchronises
   for (int t = threadIdx.x; t < CVM_LUT_ROWS * CVM_LUT_COLS * 4; t += blockDim.x) {
-    const int e = t >> 2, which = t & 3;
-    lut[t] = cvm_lut_word(e / CVM_LUT_COLS - 2, e % CVM_LUT_COLS - 1, which >> 1, which & 1);
+    const int e = t >> 2, c = t & 3;
+    lut[t] = cvm_lut_word(e / CVM_LUT_COLS - 2, e % CVM_LUT_COLS - 2, c);
   }
 }
 
@@ -264,26 +263,34 @@ __device__ __forceinline__ void cvm_weights(const CvmTap& t, int p, int xb, int 
                                             cvm_h8& bl) {
   const int y0 = (int)(t.xy >> 16), x0 = (int)(t.xy & 0xffffu);
   const int dy = y0 - 2 * (p + half);
-  const int k = x0 - 4 * xb + 1;
-  const cvm_u4 sel = lut[(cvm_med3(dy, -2, 2) + 2) * CVM_LUT_COLS + cvm_med3(k, -1, 5) + 1];
+  const int dx = x0 - xb;
+  const cvm_u4 sel = lut[(cvm_med3(dy, -2, 2) + 2) * CVM_LUT_COLS + cvm_med3(dx, -2, 4) + 2];
   cvm_u4 H, Lo;
-  H.x = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.x), H.y = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.y);
-  H.z = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.z), H.w = __builtin_amdgcn_perm(t.top_hi, t.bot_hi, sel.w);
-  Lo.x = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.x), Lo.y = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.y);
-  Lo.z = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.z), Lo.w = __builtin_amdgcn_perm(t.top_lo, t.bot_lo, sel.w);
+  H.x = __builtin_amdgcn_perm(t.c0_hi, t.c1_hi, sel.x), H.y = __builtin_amdgcn_perm(t.c0_hi, t.c1_hi, sel.y);
+  H.z = __builtin_amdgcn_perm(t.c0_hi, t.c1_hi, sel.z), H.w = __builtin_amdgcn_perm(t.c0_hi, t.c1_hi, sel.w);
+  Lo.x = __builtin_amdgcn_perm(t.c0_lo, t.c1_lo, sel.x), Lo.y = __builtin_amdgcn_perm(t.c0_lo, t.c1_lo, sel.y);
+  Lo.z = __builtin_amdgcn_perm(t.c0_lo, t.c1_lo, sel.z), Lo.w = __builtin_amdgcn_perm(t.c0_lo, t.c1_lo, sel.w);
   bh = __builtin_bit_cast(cvm_h8, H);
   bl = __builtin_bit_cast(cvm_h8, Lo);
 }
 
 __device__ __forceinline__ cvm_f16 cvm_mfma(cvm_h8 a, cvm_h8 b, cvm_f16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// A operands of a chunk for this lane (lanes 0-31: row pair p, lanes 32-63: row pair p + 1): + 1024 ct + 512 (hi | lo).
-// Wave-uniform part (scalar registers) + the lane's offset inside the chunk (one register per side: cvm_lane_off)
+// A operands of a chunk for this lane (lanes 0-31: row pair p, lanes 32-63: row pair p + 1): + 1024 column + 512 (hi | lo) +
+// 128 channel tile.  Wave-uniform part (scalar registers) + the lane's offset inside the chunk (one register per side)
 __device__ __forceinline__ const char* cvm_chunk_base(const CvmSide& s, int p, int xb) {
-  return s.map + (size_t)((unsigned)(p * s.nxb + xb) * (unsigned)CVM_CELL_BYTES);
+  return s.map + (size_t)((unsigned)(p * s.rs + xb) * (unsigned)CVM_COL_BYTES);
 }
-__device__ __forceinline__ unsigned cvm_lane_off(int nxb, int n, int half) {
-  return (unsigned)(half * nxb) * (unsigned)CVM_CELL_BYTES + (unsigned)n * 16u;
+__device__ __forceinline__ unsigned cvm_lane_off(int rs, int n, int half) {
+  return (unsigned)(half * rs) * (unsigned)CVM_COL_BYTES + (unsigned)n * 4u;
+}
+// the A operands of channel tile ct: hi = the four columns' hi dwords, lo likewise (16 dword loads with immediate offsets)
+__device__ __forceinline__ void cvm_load_ct(cvm_u4& h, cvm_u4& l, const char* src, int ct) {
+  const char* q = src + ct * 128;
+  h.x = *reinterpret_cast<const unsigned*>(q), h.y = *reinterpret_cast<const unsigned*>(q + 1024);
+  h.z = *reinterpret_cast<const unsigned*>(q + 2048), h.w = *reinterpret_cast<const unsigned*>(q + 3072);
+  l.x = *reinterpret_cast<const unsigned*>(q + 512), l.y = *reinterpret_cast<const unsigned*>(q + 1536);
+  l.z = *reinterpret_cast<const unsigned*>(q + 2560), l.w = *reinterpret_cast<const unsigned*>(q + 3584);
 }
 
 // channel tiles per side run: all four (128 channels): the rays' weights of a chunk are built once.  (Two passes over 64
@@ -300,7 +307,7 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
                                              const CvmTap& tap, const char* next_first, const cvm_u4* __restrict__ lut, int n, int half,
                                              int fh, int fw) {
   cvm_h8 bh, bl;
-  const unsigned loff = cvm_lane_off(s.nxb, n, half);
+  const unsigned loff = cvm_lane_off(s.rs, n, half);
   if (!s.box.big) {
     unsigned long long m = s.box.mask;
     int p, xb;
@@ -322,8 +329,7 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
       z = cvm_mfma(l, bh, z);
       z = cvm_mfma(h, bl, z);
       acc[ct] = cvm_mfma(h, bh, z);
-      ah[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024);
-      al[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024 + 512);
+      cvm_load_ct(ah[ct], al[ct], nsrc, ct);
     }
     while (more) {
       p = pn, xb = xn;
@@ -340,8 +346,7 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
         acc[ct] = cvm_mfma(l, bh, acc[ct]);
         acc[ct] = cvm_mfma(h, bl, acc[ct]);
         acc[ct] = cvm_mfma(h, bh, acc[ct]);
-        ah[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024);
-        al[ct] = *reinterpret_cast<const cvm_u4*>(nsrc + ct * 1024 + 512);
+        cvm_load_ct(ah[ct], al[ct], nsrc, ct);
       }
     }
     return;
@@ -352,21 +357,22 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
     int ymax = (int)(tap.xy >> 16), xmax = (int)(tap.xy & 0xffffu);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ymax = max(ymax, __shfl_xor(ymax, off, 64)), xmax = max(xmax, __shfl_xor(xmax, off, 64));
-    p_hi = __builtin_amdgcn_readfirstlane(min(ymax + 1, fh - 1) >> 1), xb_hi = __builtin_amdgcn_readfirstlane(min(xmax + 1, fw - 1) >> 2);
+    p_hi = __builtin_amdgcn_readfirstlane(min(ymax + 1, fh - 1) >> 1), xb_hi = __builtin_amdgcn_readfirstlane(min(xmax + 1, fw - 1));  // a COLUMN
   }
 #pragma unroll
   for (int ct = 0; ct < CVM_NCT; ++ct)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
   for (int p = s.box.p_lo; p <= p_hi; p += 2)
-    for (int xb = s.box.xb_lo; xb <= xb_hi; ++xb) {
+    for (int xb = s.box.xb_lo; xb <= xb_hi; xb += 4) {
       if (!cvm_occupied(tap, p, xb)) continue;
       const char* src = cvm_chunk_base(s, p, xb) + loff;
       cvm_weights(tap, p, xb, half, lut, bh, bl);
 #pragma unroll
       for (int ct = 0; ct < CVM_NCT; ++ct) {
-        const cvm_h8 h = __builtin_bit_cast(cvm_h8, *reinterpret_cast<const cvm_u4*>(src + ct * 1024));
-        const cvm_h8 l = __builtin_bit_cast(cvm_h8, *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512));
+        cvm_u4 hu, lu;
+        cvm_load_ct(hu, lu, src, ct);
+        const cvm_h8 h = __builtin_bit_cast(cvm_h8, hu), l = __builtin_bit_cast(cvm_h8, lu);
         acc[ct] = cvm_mfma(l, bh, acc[ct]);
         acc[ct] = cvm_mfma(h, bl, acc[ct]);
         acc[ct] = cvm_mfma(h, bh, acc[ct]);
@@ -374,8 +380,7 @@ __device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&a
     }
 #pragma unroll
   for (int ct = 0; ct < CVM_NCT; ++ct) {
-    ah[ct] = *reinterpret_cast<const cvm_u4*>(next_first + ct * 1024);
-    al[ct] = *reinterpret_cast<const cvm_u4*>(next_first + ct * 1024 + 512);
+    cvm_load_ct(ah[ct], al[ct], next_first, ct);
   }
 }
 
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       int x0, y0;
       const CvmTap t = cvm_tap(p2.x, p2.y, sc.fh[s], sc.fw[s], x0, y0);
       cvm_u4 wv;
-      wv.x = t.top_hi, wv.y = t.bot_hi, wv.z = t.top_lo, wv.w = t.bot_lo;
+      wv.x = t.c0_hi, wv.y = t.c1_hi, wv.z = t.c0_lo, wv.w = t.c1_lo;
       tapw[i * 32 + n] = wv;
       tapxy[i * 32 + n] = t.xy;
       // chunk grid anchor and occupancy: minimum / OR over the 32 rays = the two DPP rows of the half-wave
@@ -586,10 +591,10 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       // the other row of this half-wave: lanes 16 apart (ds_swizzle BitMode: and 0x1f, or 0, xor 0x10)
       xmin = min(xmin, __builtin_amdgcn_ds_swizzle(xmin, 0x401F));
       ymin = min(ymin, __builtin_amdgcn_ds_swizzle(ymin, 0x401F));
-      const int p_lo = ymin >> 1, xb_lo = xmin >> 2;
+      const int p_lo = ymin >> 1, xb_lo = xmin;  // first row pair, leftmost COLUMN
       // this ray's chunks on the grid anchored at (p_lo, xb_lo): rows cra, crb x columns cxa, cxb (bit 8 cr + cx; window 8 x 8)
       const int cra = ((y0 >> 1) - p_lo) >> 1, crb = ((y1 >> 1) - p_lo) >> 1;
-      const int cxa = (x0 >> 2) - xb_lo, cxb = (x1 >> 2) - xb_lo;
+      const int cxa = (x0 - xb_lo) >> 2, cxb = (x1 - xb_lo) >> 2;
       const unsigned long long ob = __builtin_amdgcn_ballot_w64(crb > 7 || cxb > 7);
       const bool big = (half ? (unsigned)(ob >> 32) : (unsigned)ob) != 0u;  // uniform over the half-wave
       unsigned long long mk = (1ull << ((8 * cra + cxa) & 63)) | (1ull << ((8 * cra + cxb) & 63)) | (1ull << ((8 * crb + cxa) & 63)) |
@@ -627,13 +632,13 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       CvmTap t;
       const cvm_u4 wv = tapw[i * 32 + n];
       t.xy = tapxy[i * 32 + n];
-      t.top_hi = wv.x, t.bot_hi = wv.y, t.top_lo = wv.z, t.bot_lo = wv.w;
+      t.c0_hi = wv.x, t.c1_hi = wv.y, t.c0_lo = wv.z, t.c1_lo = wv.w;
       return t;
     };
     auto side_of = [&](const char* map, int view, int s) {
       CvmSide o;
       o.map = map;
-      o.nxb = L.nxb[s];
+      o.rs = L.rs[s];
       o.item = view * NS + s;
       const int4 bx = boxes[o.item];
       o.box.p_lo = __builtin_amdgcn_readfirstlane(bx.x), o.box.xb_lo = __builtin_amdgcn_readfirstlane(bx.y);
@@ -654,18 +659,17 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     int pr = grid.pair_begin, a = grid.a0, b = grid.b0, s = 0;
     CvmSide sa = side_of(mp0, a, 0);
     {
-      const char* src = cvm_chunk_base(sa, sa.p, sa.xb) + cvm_lane_off(sa.nxb, n, half);
+      const char* src = cvm_chunk_base(sa, sa.p, sa.xb) + cvm_lane_off(sa.rs, n, half);
 #pragma unroll
       for (int ct = 0; ct < CVM_NCT; ++ct) {
-        ah[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024);
-        al[ct] = *reinterpret_cast<const cvm_u4*>(src + ct * 1024 + 512);
+        cvm_load_ct(ah[ct], al[ct], src, ct);
       }
     }
     const int n_units = (grid.pair_end - grid.pair_begin) * NS;
     for (int u = 0; u < n_units; ++u) {
       const char* map_a = s == 0 ? mp0 : mp1;
       const CvmSide sb = side_of(map_a + L.map_bytes[s], b, s);
-      const char* first_b = cvm_chunk_base(sb, sb.p, sb.xb) + cvm_lane_off(sb.nxb, n, half);
+      const char* first_b = cvm_chunk_base(sb, sb.p, sb.xb) + cvm_lane_off(sb.rs, n, half);
       cvm_f16 fa[CVM_NCT], fb[CVM_NCT];
       CVM_T(2)
       cvm_side_run(fa, ah, al, sa, tap_of(sa.item), first_b, lut, n, half, sc.fh[s], sc.fw[s]);
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       }
       const bool last = u == n_units - 1;
       const CvmSide sn = last ? sb : side_of(s == 0 ? mp0 : mp1, a, s);
-      const char* first_n = cvm_chunk_base(sn, sn.p, sn.xb) + cvm_lane_off(sn.nxb, n, half);
+      const char* first_n = cvm_chunk_base(sn, sn.p, sn.xb) + cvm_lane_off(sn.rs, n, half);
       CVM_T(2)
       cvm_side_run(fb, ah, al, sb, tap_of(sb.item), first_n, lut, n, half, sc.fh[s_cur], sc.fw[s_cur]);
       CVM_T(4)
@@ -756,7 +760,7 @@ extern "C" int mnerf_cost_volume_operands(const mnerf_scene* scene, void* opnd, 
   unsigned* absmax_bits = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(opnd) + 2 * 2 * CVM_MAX_MAPS * 4);
   hipLaunchKernelGGL(cvm_absmax_kernel, dim3(32, (unsigned)(maps * scene->n_scales)), dim3(256), 0, st, *scene, absmax_bits);
   int cells = 0;
-  for (int s = 0; s < scene->n_scales; ++s) cells = cells > L.nrp[s] * L.nxb[s] ? cells : L.nrp[s] * L.nxb[s];
+  for (int s = 0; s < scene->n_scales; ++s) cells = cells > L.nrp[s] * L.rs[s] ? cells : L.nrp[s] * L.rs[s];
   hipLaunchKernelGGL(cvm_split_kernel, dim3((unsigned)((cells + 1) / 2), (unsigned)(maps * scene->n_scales)), dim3(256), 0, st, *scene,
                      reinterpret_cast<char*>(opnd));
   return mnerf_check_launch("mnerf_cost_volume_operands");

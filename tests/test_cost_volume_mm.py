@@ -112,12 +112,12 @@ def test_operand_image_round_trips_the_maps(hip):
     off = 8192
     for s, f in enumerate(feats_gpu):
         P, _, fh, fw, C = f.shape
-        nrp, nxb = (fh + 1) // 2 + 1, (fw + 3) // 4
-        map_bytes = nrp * nxb * 4096
+        nrp, rs = (fh + 1) // 2 + 1, fw + 3  # row pairs (+ a zero one), columns per row pair (+ three zero ones)
+        map_bytes = nrp * rs * 1024
         for m in range(2 * P):
-            cells = raw[off:off + map_bytes].view(np.float16).reshape(nrp, nxb, 4, 2, 32, 2, 4).astype(np.float64)
-            val = cells[:, :, :, 0] + cells[:, :, :, 1]                         # [rp, xb, ct, ch32, r, c]
-            img = val.transpose(0, 4, 1, 5, 2, 3).reshape(nrp * 2, nxb * 4, 128)  # [y, x, channel]
+            cells = raw[off:off + map_bytes].view(np.float16).reshape(nrp, rs, 2, 128, 2).astype(np.float64)
+            val = cells[:, :, 0] + cells[:, :, 1]                                # [rp, x, channel, row in pair]
+            img = val.transpose(0, 3, 1, 2).reshape(nrp * 2, rs, 128)            # [y, x, channel]
             ref = f[m // 2, m % 2].cpu().numpy().astype(np.float64)
             gm = float(gain[s, m])
             assert gm > 0 and np.log2(gm) == np.round(np.log2(gm))
