@@ -274,11 +274,21 @@ __device__ __forceinline__ void cvm_weights(const CvmTap& t, int p, int xb, int 
   bl = __builtin_bit_cast(cvm_h8, Lo);
 }
 
+#if CVM_EXP == 5
+__device__ __forceinline__ cvm_f16 cvm_mfma(cvm_h8 a, cvm_h8 b, cvm_f16 c) {
+  c[0] += (float)a[0] * (float)b[0], c[5] += (float)a[2] * (float)b[3], c[9] += (float)a[4] * (float)b[5], c[14] += (float)a[6] * (float)b[7];
+  return c;
+}
+#else
 __device__ __forceinline__ cvm_f16 cvm_mfma(cvm_h8 a, cvm_h8 b, cvm_f16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+#endif
 
 // A operands of a chunk for this lane (lanes 0-31: row pair p, lanes 32-63: row pair p + 1): + 1024 column + 512 (hi | lo) +
 // 128 channel tile.  Wave-uniform part (scalar registers) + the lane's offset inside the chunk (one register per side)
 __device__ __forceinline__ const char* cvm_chunk_base(const CvmSide& s, int p, int xb) {
+#if CVM_EXP == 6
+  return s.map + (size_t)((unsigned)((p & 1) * s.rs + (xb & 3)) * (unsigned)CVM_COL_BYTES);
+#endif
   return s.map + (size_t)((unsigned)(p * s.rs + xb) * (unsigned)CVM_COL_BYTES);
 }
 __device__ __forceinline__ unsigned cvm_lane_off(int rs, int n, int half) {
@@ -293,95 +303,55 @@ __device__ __forceinline__ void cvm_load_ct(cvm_u4& h, cvm_u4& l, const char* sr
   l.z = *reinterpret_cast<const unsigned*>(q + 2560), l.w = *reinterpret_cast<const unsigned*>(q + 3584);
 }
 
-// channel tiles per side run: all four (128 channels): the rays' weights of a chunk are built once.  (Two passes over 64
-// channels each - 64 accumulator registers per side - were measured: the compiler still needs ~190 registers, two waves per
-// SIMD either way, and every per-chunk cost is paid twice: 8.3-8.5 against 7.9 ms per frame.)
-#define CVM_NCT 4
+// ---------------------------------------------------------------------------------------------------------------------------
+// One UNIT = one (pair, scale) for the wave's 32 rays at one depth index, CHANNEL TILE BY CHANNEL TILE and software-pipelined:
+//   the A operands of BOTH sides and all four 32-channel tiles live in registers (ha, la, hb, lb: 64 registers) and are
+//   re-requested FOR THE NEXT UNIT tile by tile, as soon as the matrix instructions that read them have been issued - every
+//   operand load has a whole unit (several thousand cycles) to arrive, instead of one side's matrix run (~400);
+//   the matrix instructions of tile t + 1 (two accumulators of 16 registers per side, double-buffered: 64 instead of 128) are
+//   issued in the same straight-line block as the dot products of tile t, so that ONE wave keeps the matrix pipe and the
+//   vector ALU busy at the same time (before: 24 matrix instructions, then ~290 vector instructions, the two waves of a SIMD
+//   rarely in complementary phases: removing the matrix instructions altogether did not change the kernel's time).
+// Removal experiments behind this form (tools/exp/patches/README.md, 3 views, 7.1 ms): no matrix instructions 7.3 ms, no dot
+// products 6.1, every operand load a cache hit 6.5, no row write-out 6.5, no units at all 1.1.
+// A unit whose footprints need more than one chunk per side (rare at the DTU shape: tools/exp/cvmm_chunks.py) takes the same
+// code with the further chunks added per tile (operands loaded on demand, weights rebuilt).
 
-// F^T (128 channels x the wave's 32 rays) of one side: every occupied chunk of the rays' footprints, in raster order.
-// On entry (ah, al) hold the A operands of the side's first chunk; the operands of the chunk after the current one - the side's
-// next chunk, else the first chunk of the side that follows in the kernel's sequence (`next_first`, a complete per-lane address)
-// - are requested as soon as the matrix instructions that read the registers have been issued: their latency is covered by
-// this chunk's matrix work and, at the end of a unit, by the dot products.
-__device__ __forceinline__ void cvm_side_run(cvm_f16 (&acc)[CVM_NCT], cvm_u4 (&ah)[CVM_NCT], cvm_u4 (&al)[CVM_NCT], const CvmSide& s,
-                                             const CvmTap& tap, const char* next_first, const cvm_u4* __restrict__ lut, int n, int half,
-                                             int fh, int fw) {
+__device__ __forceinline__ cvm_f16 cvm_mfma3(cvm_u4 ah, cvm_u4 al, cvm_h8 bh, cvm_h8 bl, cvm_f16 c) {
+  const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah), l = __builtin_bit_cast(cvm_h8, al);
+  c = cvm_mfma(l, bh, c);
+  c = cvm_mfma(h, bl, c);
+  return cvm_mfma(h, bh, c);
+}
+
+// every chunk of a side for channel tile ct, operands loaded on demand (the unit copy for sides with more than one chunk)
+__device__ __forceinline__ void cvm_all_chunks(cvm_f16& acc, const CvmSide& s, const CvmTap& tap, unsigned loff, int ct,
+                                               const cvm_u4* __restrict__ lut, int half, int fh, int fw) {
   cvm_h8 bh, bl;
-  const unsigned loff = cvm_lane_off(s.rs, n, half);
+  cvm_u4 hu, lu;
   if (!s.box.big) {
     unsigned long long m = s.box.mask;
-    int p, xb;
-    cvm_pop(m, s.box, p, xb);  // = (s.p, s.xb), whose operands are in (ah, al)
-    int pn = p, xn = xb;
-    bool more = m != 0;
-    const char* nsrc = next_first;
-    if (more) {
-      cvm_pop(m, s.box, pn, xn);
-      nsrc = cvm_chunk_base(s, pn, xn) + loff;
-    }
-    cvm_weights(tap, p, xb, half, lut, bh, bl);
-#pragma unroll
-    for (int ct = 0; ct < CVM_NCT; ++ct) {
-      cvm_f16 z;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-      const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
-      z = cvm_mfma(l, bh, z);
-      z = cvm_mfma(h, bl, z);
-      acc[ct] = cvm_mfma(h, bh, z);
-      cvm_load_ct(ah[ct], al[ct], nsrc, ct);
-    }
-    while (more) {
-      p = pn, xb = xn;
-      more = m != 0;
-      nsrc = next_first;
-      if (more) {
-        cvm_pop(m, s.box, pn, xn);
-        nsrc = cvm_chunk_base(s, pn, xn) + loff;
-      }
+    while (m) {
+      int p, xb;
+      cvm_pop(m, s.box, p, xb);
+      cvm_load_ct(hu, lu, cvm_chunk_base(s, p, xb) + loff, ct);
       cvm_weights(tap, p, xb, half, lut, bh, bl);
-#pragma unroll
-      for (int ct = 0; ct < CVM_NCT; ++ct) {
-        const cvm_h8 h = __builtin_bit_cast(cvm_h8, ah[ct]), l = __builtin_bit_cast(cvm_h8, al[ct]);
-        acc[ct] = cvm_mfma(l, bh, acc[ct]);
-        acc[ct] = cvm_mfma(h, bl, acc[ct]);
-        acc[ct] = cvm_mfma(h, bh, acc[ct]);
-        cvm_load_ct(ah[ct], al[ct], nsrc, ct);
-      }
+      acc = cvm_mfma3(hu, lu, bh, bl, acc);
     }
     return;
   }
-  // general loop (a footprint wider than the 8 x 8 chunk window): every chunk of the rays' range, operands loaded on demand
-  int p_hi, xb_hi;
-  {
-    int ymax = (int)(tap.xy >> 16), xmax = (int)(tap.xy & 0xffffu);
+  // a footprint wider than the 8 x 8 chunk window: every occupied chunk of the rays' range
+  int ymax = (int)(tap.xy >> 16), xmax = (int)(tap.xy & 0xffffu);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ymax = max(ymax, __shfl_xor(ymax, off, 64)), xmax = max(xmax, __shfl_xor(xmax, off, 64));
-    p_hi = __builtin_amdgcn_readfirstlane(min(ymax + 1, fh - 1) >> 1), xb_hi = __builtin_amdgcn_readfirstlane(min(xmax + 1, fw - 1));  // a COLUMN
-  }
-#pragma unroll
-  for (int ct = 0; ct < CVM_NCT; ++ct)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[ct][i] = 0.0f;
+  for (int off = 32; off > 0; off >>= 1) ymax = max(ymax, __shfl_xor(ymax, off, 64)), xmax = max(xmax, __shfl_xor(xmax, off, 64));
+  const int p_hi = __builtin_amdgcn_readfirstlane(min(ymax + 1, fh - 1) >> 1), x_hi = __builtin_amdgcn_readfirstlane(min(xmax + 1, fw - 1));
   for (int p = s.box.p_lo; p <= p_hi; p += 2)
-    for (int xb = s.box.xb_lo; xb <= xb_hi; xb += 4) {
+    for (int xb = s.box.xb_lo; xb <= x_hi; xb += 4) {
       if (!cvm_occupied(tap, p, xb)) continue;
-      const char* src = cvm_chunk_base(s, p, xb) + loff;
+      cvm_load_ct(hu, lu, cvm_chunk_base(s, p, xb) + loff, ct);
       cvm_weights(tap, p, xb, half, lut, bh, bl);
-#pragma unroll
-      for (int ct = 0; ct < CVM_NCT; ++ct) {
-        cvm_u4 hu, lu;
-        cvm_load_ct(hu, lu, src, ct);
-        const cvm_h8 h = __builtin_bit_cast(cvm_h8, hu), l = __builtin_bit_cast(cvm_h8, lu);
-        acc[ct] = cvm_mfma(l, bh, acc[ct]);
-        acc[ct] = cvm_mfma(h, bl, acc[ct]);
-        acc[ct] = cvm_mfma(h, bh, acc[ct]);
-      }
+      acc = cvm_mfma3(hu, lu, bh, bl, acc);
     }
-#pragma unroll
-  for (int ct = 0; ct < CVM_NCT; ++ct) {
-    cvm_load_ct(ah[ct], al[ct], next_first, ct);
-  }
 }
 
 // One cosine from the two half-wave partial sums of (dot, |a|^2, |b|^2) of TWO groups x / y: lower half-wave <- group x,
@@ -395,24 +365,28 @@ __device__ __forceinline__ float cvm_cos_pair(float dx, float dy, float ax, floa
   return d * (__builtin_amdgcn_rsqf(fmaxf(a, ea2)) * __builtin_amdgcn_rsqf(fmaxf(b, eb2)));
 }
 
-// cosines of one unit from the two maps' interpolated features: slot i of a lane = group 2 i + half.
-// G = channel groups of the scale (1, 2, 4, 8).
-__device__ __forceinline__ void cvm_cosines(float (&cacc)[4], const cvm_f16 (&fa)[CVM_NCT], const cvm_f16 (&fb)[CVM_NCT], float ea2,
-                                            float eb2, int G) {
-  // three dot products per 16-channel granule (this lane's 8 channels of it: registers 8 (q & 1) .. + 7 of tile q >> 1)
-  float dot[8], na[8], nb[8];
+// three dot products per 16-channel granule of one channel tile (this lane's 8 channels of a granule: registers 0-7 / 8-15)
+__device__ __forceinline__ void cvm_dots(const cvm_f16& fa, const cvm_f16& fb, float* dot, float* na, float* nb) {
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int ct = q >> 1, r0 = (q & 1) * 8;
-    float d = fa[ct][r0] * fb[ct][r0], a = fa[ct][r0] * fa[ct][r0], b = fb[ct][r0] * fb[ct][r0];
+  for (int g2 = 0; g2 < 2; ++g2) {
+    const int r0 = 8 * g2;
+#if CVM_EXP == 4
+    dot[g2] = fa[r0] + fb[r0 + 1], na[g2] = fa[r0 + 2], nb[g2] = fb[r0 + 3];
+#else
+    float d = fa[r0] * fb[r0], a = fa[r0] * fa[r0], b = fb[r0] * fb[r0];
 #pragma unroll
     for (int r = 1; r < 8; ++r) {
-      d = __builtin_fmaf(fa[ct][r0 + r], fb[ct][r0 + r], d);
-      a = __builtin_fmaf(fa[ct][r0 + r], fa[ct][r0 + r], a);
-      b = __builtin_fmaf(fb[ct][r0 + r], fb[ct][r0 + r], b);
+      d = __builtin_fmaf(fa[r0 + r], fb[r0 + r], d);
+      a = __builtin_fmaf(fa[r0 + r], fa[r0 + r], a);
+      b = __builtin_fmaf(fb[r0 + r], fb[r0 + r], b);
     }
-    dot[q] = d, na[q] = a, nb[q] = b;
+    dot[g2] = d, na[g2] = a, nb[g2] = b;
+#endif
   }
+}
+
+// cosines of one unit from the granules' sums: slot i of a lane = group 2 i + half.  G = channel groups of the scale (1, 2, 4, 8)
+__device__ __forceinline__ void cvm_cosines(float (&cacc)[4], float (&dot)[8], float (&na)[8], float (&nb)[8], float ea2, float eb2, int G) {
   if (G == 8) {  // granule = group
 #pragma unroll
     for (int i = 0; i < 4; ++i) cacc[i] += cvm_cos_pair(dot[2 * i], dot[2 * i + 1], na[2 * i], na[2 * i + 1], nb[2 * i], nb[2 * i + 1], ea2, eb2);
@@ -435,6 +409,101 @@ __device__ __forceinline__ void cvm_cosines(float (&cacc)[4], const cvm_f16 (&fa
   cacc[0] += cvm_cos_pair(dot[0] + dot[1], 0.0f, na[0] + na[1], 0.0f, nb[0] + nb[1], 0.0f, ea2, eb2);  // (upper half-wave: 0)
 }
 
+#ifndef CVM_SCHED
+#define CVM_SCHED 0  // interleave hint for the blocks that hold the matrix instructions of tile t + 1 and the dot products of tile t
+#endif
+
+// The unit.  On entry (ha, la) / (hb, lb) hold the A operands of the two sides' first chunks, all four channel tiles; on exit
+// (unless `last`) those of the NEXT unit's sides (`next_a`, `next_b`: complete per-lane addresses of their first chunks).
+// MORE: some side has further chunks (wave-uniform; compiled as a second copy of the unit so that the common copy stays
+// straight-line code).
+template <bool MORE>
+__device__ __forceinline__ void cvm_unit_run(float (&cacc)[4], cvm_u4 (&ha)[4], cvm_u4 (&la)[4], cvm_u4 (&hb)[4], cvm_u4 (&lb)[4],
+                                             const CvmSide& sa, const CvmSide& sb, const CvmTap& tap_a, const CvmTap& tap_b,
+                                             const char* next_a, const char* next_b, float ea2, float eb2, int G,
+                                             const cvm_u4* __restrict__ lut, int n, int half, int fh, int fw) {
+  cvm_h8 wah, wal, wbh, wbl;
+  cvm_weights(tap_a, sa.p, sa.xb, half, lut, wah, wal);
+  cvm_weights(tap_b, sb.p, sb.xb, half, lut, wbh, wbl);
+  float dot[8], na[8], nb[8];
+  cvm_f16 fa0, fb0, fa1, fb1;
+  // matrix instructions of tile ct (first chunks), then the next unit's operands of that tile
+  auto tile = [&](int ct, cvm_f16& fa, cvm_f16& fb) {
+    const cvm_h8 h_a = __builtin_bit_cast(cvm_h8, ha[ct]), l_a = __builtin_bit_cast(cvm_h8, la[ct]);
+    const cvm_h8 h_b = __builtin_bit_cast(cvm_h8, hb[ct]), l_b = __builtin_bit_cast(cvm_h8, lb[ct]);
+    cvm_f16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+    fa = cvm_mfma(l_a, wah, z);
+    fb = cvm_mfma(l_b, wbh, z);
+    fa = cvm_mfma(h_a, wal, fa);
+    fb = cvm_mfma(h_b, wbl, fb);
+    fa = cvm_mfma(h_a, wah, fa);
+    fb = cvm_mfma(h_b, wbh, fb);
+  };
+  auto request = [&](int ct) {  // (no branch around the loads after a depth index's last unit: `next` is then the unit's own
+    cvm_load_ct(ha[ct], la[ct], next_a, ct);  // first chunks - one wasted, cached request per depth index keeps the unit ONE
+    cvm_load_ct(hb[ct], lb[ct], next_b, ct);  // straight-line block that the scheduler can interleave)
+  };
+  // the dot products of a tile stay where they are written (next to the following tile's matrix instructions) instead of being
+  // sunk to the cosines
+#define CVM_PIN(q) asm volatile("" : "+v"(dot[q]), "+v"(dot[q + 1]), "+v"(na[q]), "+v"(na[q + 1]), "+v"(nb[q]), "+v"(nb[q + 1]));
+#if CVM_SCHED
+#define CVM_INTERLEAVE()                                         \
+  _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);           \
+  }
+#else
+#define CVM_INTERLEAVE()
+#endif
+  if constexpr (MORE) {
+    // tile after tile in a rolled loop, every chunk's operands loaded on demand (the prefetched first chunks are not used: the
+    // loop could only index them dynamically), then the next unit's operands
+    const unsigned loff_a = cvm_lane_off(sa.rs, n, half), loff_b = cvm_lane_off(sb.rs, n, half);
+#pragma unroll 1
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fa0[i] = 0.0f, fb0[i] = 0.0f;
+      cvm_all_chunks(fa0, sa, tap_a, loff_a, ct, lut, half, fh, fw);
+      cvm_all_chunks(fb0, sb, tap_b, loff_b, ct, lut, half, fh, fw);
+      float d2[2], a2[2], b2[2];
+      cvm_dots(fa0, fb0, d2, a2, b2);
+      switch (ct) {  // (wave-uniform; keeps the sums in registers)
+        case 0: dot[0] = d2[0], dot[1] = d2[1], na[0] = a2[0], na[1] = a2[1], nb[0] = b2[0], nb[1] = b2[1]; break;
+        case 1: dot[2] = d2[0], dot[3] = d2[1], na[2] = a2[0], na[3] = a2[1], nb[2] = b2[0], nb[3] = b2[1]; break;
+        case 2: dot[4] = d2[0], dot[5] = d2[1], na[4] = a2[0], na[5] = a2[1], nb[4] = b2[0], nb[5] = b2[1]; break;
+        default: dot[6] = d2[0], dot[7] = d2[1], na[6] = a2[0], na[7] = a2[1], nb[6] = b2[0], nb[7] = b2[1]; break;
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) request(ct);
+  } else {
+    tile(0, fa0, fb0);
+    request(0);
+    tile(1, fa1, fb1);
+    cvm_dots(fa0, fb0, dot + 0, na + 0, nb + 0);
+    CVM_PIN(0)
+    CVM_INTERLEAVE()
+    request(1);
+    tile(2, fa0, fb0);
+    cvm_dots(fa1, fb1, dot + 2, na + 2, nb + 2);
+    CVM_PIN(2)
+    CVM_INTERLEAVE()
+    request(2);
+    tile(3, fa1, fb1);
+    cvm_dots(fa0, fb0, dot + 4, na + 4, nb + 4);
+    CVM_PIN(4)
+    CVM_INTERLEAVE()
+    request(3);
+    cvm_dots(fa1, fb1, dot + 6, na + 6, nb + 6);
+  }
+#undef CVM_INTERLEAVE
+#undef CVM_PIN
+  cvm_cosines(cacc, dot, na, nb, ea2, eb2, G);
+}
+
+
 struct CvmGrid {
   int tile_y0, ntx, n_tiles, nsg, spw;  // first tile row, tiles per row, tiles, sample groups per tile, samples per wave and item
   int stage_rows;                       // rows assembled in LDS (0: many views - the scratch would cost the second workgroup of a CU)
@@ -454,6 +523,9 @@ __host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, 
 #endif
 #ifndef CVM_WG_WAVES
 #define CVM_WG_WAVES 4  // waves per workgroup: wave w runs on SIMD w % 4, so waves w and w + 4 share a SIMD
+#endif
+#ifndef CVM_EXP
+#define CVM_EXP 0  // timing experiments (tools/exp): 1 no row write-out, 2 no colour taps, 3 no units
 #endif
 #ifndef CVM_PRIO
 #define CVM_PRIO 0
@@ -546,7 +618,11 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       if (row_wr && first_block) {  // (a later pair block only needs the projections)
         const Bilin b = bilin_setup(u, w_, H, W);
         const float4* img = reinterpret_cast<const float4*>(sc.images) + (size_t)v * H * W;
+#if CVM_EXP == 2
+        const float4 t00 = make_float4(u, w_, z, 0.f), t01 = t00, t10 = t00, t11 = t00;
+#else
         const float4 t00 = img[b.o00], t01 = img[b.o01], t10 = img[b.o10], t11 = img[b.o11];
+#endif
         const float gx = u * 2.0f - 1.0f, gy = w_ * 2.0f - 1.0f;
         const float m = (gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f) ? 1.0f : 0.0f;
         out[sumG + 3 * v + 0] = bilin4(t00.x, t01.x, t10.x, t11.x, b);
@@ -617,8 +693,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     cvw_handoff();
 
     CVM_T(1)
-    // ---- pass 2: the sides of all units in one sequence - per unit (pair, scale): side a, side b - each side's first chunk
-    // requested while the side before it is still being worked on
+    // ---- pass 2: the units in the kernel's order (pair, scale), each one's operands requested during the unit before it
     float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
     if (!first_block && row_wr) {  // a later pair block continues the raw sums the blocks before it left in the rows
 #pragma unroll
@@ -638,7 +713,8 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     auto side_of = [&](const char* map, int view, int s) {
       CvmSide o;
       o.map = map;
-      o.rs = L.rs[s];
+      o.rs = s == 0 ? L.rs[0] : L.rs[1];  // (no dynamic index: the layout would be read from scratch memory, and a scratch
+                                          // load's wait also waits for every operand load in flight)
       o.item = view * NS + s;
       const int4 bx = boxes[o.item];
       o.box.p_lo = __builtin_amdgcn_readfirstlane(bx.x), o.box.xb_lo = __builtin_amdgcn_readfirstlane(bx.y);
@@ -652,51 +728,57 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       }
       return o;
     };
-    cvm_u4 ah[CVM_NCT], al[CVM_NCT];
+    auto first_of = [&](const CvmSide& sd) { return cvm_chunk_base(sd, sd.p, sd.xb) + cvm_lane_off(sd.rs, n, half); };
+    auto has_more = [&](const CvmSide& sd) { return sd.box.big || (sd.box.mask & (sd.box.mask - 1)) != 0; };
     // running map pointers per scale: side a of the current pair (side b follows it in memory, the next pair's sides after that)
     const char* mp0 = opnd + L.off[0] + (size_t)(2 * grid.pair_begin) * L.map_bytes[0];
     const char* mp1 = opnd + L.off[1] + (size_t)(2 * grid.pair_begin) * L.map_bytes[1];
     int pr = grid.pair_begin, a = grid.a0, b = grid.b0, s = 0;
-    CvmSide sa = side_of(mp0, a, 0);
+    CvmSide sa = side_of(mp0, a, 0), sb = side_of(mp0 + L.map_bytes[0], b, 0);
+    cvm_u4 ha[4], la[4], hb[4], lb[4];
     {
-      const char* src = cvm_chunk_base(sa, sa.p, sa.xb) + cvm_lane_off(sa.rs, n, half);
+      const char* fa_ = first_of(sa);
+      const char* fb_ = first_of(sb);
 #pragma unroll
-      for (int ct = 0; ct < CVM_NCT; ++ct) {
-        cvm_load_ct(ah[ct], al[ct], src, ct);
-      }
+      for (int ct = 0; ct < 4; ++ct) cvm_load_ct(ha[ct], la[ct], fa_, ct), cvm_load_ct(hb[ct], lb[ct], fb_, ct);
     }
+#if CVM_EXP == 3
+    const int n_units = 0;
+#else
     const int n_units = (grid.pair_end - grid.pair_begin) * NS;
+#endif
     for (int u = 0; u < n_units; ++u) {
-      const char* map_a = s == 0 ? mp0 : mp1;
-      const CvmSide sb = side_of(map_a + L.map_bytes[s], b, s);
-      const char* first_b = cvm_chunk_base(sb, sb.p, sb.xb) + cvm_lane_off(sb.rs, n, half);
-      cvm_f16 fa[CVM_NCT], fb[CVM_NCT];
       CVM_T(2)
-      cvm_side_run(fa, ah, al, sa, tap_of(sa.item), first_b, lut, n, half, sc.fh[s], sc.fw[s]);
-      CVM_T(3)
-      // the unit after this one: next scale of the pair, else the next pair.  The last unit of the depth index re-requests its
-      // own first chunk (one wasted request per depth index keeps the chunk loop free of conditional loads).
       const float ga = gain[s * CVM_MAX_MAPS + 2 * pr], gb = gain[s * CVM_MAX_MAPS + 2 * pr + 1];
+      const float ea = 1e-8f * ga, eb = 1e-8f * gb;  // clamps of the two norms in the scaled sums: (eps gain)^2
       const int G = s == 0 ? G0 : G1;
       const int s_cur = s;
+      // the unit after this one: next scale of the pair, else the next pair
       if (++s == NS) {
         s = 0, ++pr;
         mp0 += 2 * L.map_bytes[0], mp1 += 2 * L.map_bytes[1];
         if (++b == V) ++a, b = a + 1;
       }
       const bool last = u == n_units - 1;
-      const CvmSide sn = last ? sb : side_of(s == 0 ? mp0 : mp1, a, s);
-      const char* first_n = cvm_chunk_base(sn, sn.p, sn.xb) + cvm_lane_off(sn.rs, n, half);
-      CVM_T(2)
-      cvm_side_run(fb, ah, al, sb, tap_of(sb.item), first_n, lut, n, half, sc.fh[s_cur], sc.fw[s_cur]);
-      CVM_T(4)
-      // clamps of the two norms in the scaled sums: (eps gain)^2
-      const float ea = 1e-8f * ga, eb = 1e-8f * gb;
-      if (s_cur == 0)
-        cvm_cosines(c0, fa, fb, ea * ea, eb * eb, G);
+      const char* mpn = s == 0 ? mp0 : mp1;
+      const CvmSide na_ = last ? sa : side_of(mpn, a, s);
+      const CvmSide nb_ = last ? sb : side_of(mpn + (s == 0 ? L.map_bytes[0] : L.map_bytes[1]), b, s);
+      const CvmTap tap_a = tap_of(sa.item), tap_b = tap_of(sb.item);
+      float cu[4] = {0.f, 0.f, 0.f, 0.f};
+      if (has_more(sa) || has_more(sb))
+        cvm_unit_run<true>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half,
+                           sc.fh[s_cur], sc.fw[s_cur]);
       else
-        cvm_cosines(c1, fa, fb, ea * ea, eb * eb, G);
-      sa = sn;
+        cvm_unit_run<false>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half,
+                            sc.fh[s_cur], sc.fw[s_cur]);
+      if (s_cur == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c0[i] += cu[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c1[i] += cu[i];
+      }
+      sa = na_, sb = nb_;
       CVM_T(5)
     }
     if (row_wr) {
@@ -710,7 +792,7 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     // the 32 rows leave as 16-byte pieces, consecutive lanes on consecutive pieces of a row (a row is cond_stride / 4 pieces:
     // the scattered 4-byte stores of one value per lane cost the memory pipeline ~20 instructions of 32 partial lines each)
     cvw_handoff();
-    if (grid.stage_rows) {
+    if (grid.stage_rows && CVM_EXP != 1) {
       const int ppr = cond_stride >> 2;  // pieces per row (cond_stride is a multiple of 8)
       for (int c = lane; c < 32 * ppr; c += 64) {
         const int r = c / ppr, part = c - r * ppr;
