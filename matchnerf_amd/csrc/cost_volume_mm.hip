@@ -409,15 +409,13 @@ __device__ __forceinline__ void cvm_cosines(float (&cacc)[4], float (&dot)[8], f
   cacc[0] += cvm_cos_pair(dot[0] + dot[1], 0.0f, na[0] + na[1], 0.0f, nb[0] + nb[1], 0.0f, ea2, eb2);  // (upper half-wave: 0)
 }
 
-#ifndef CVM_SCHED
-#define CVM_SCHED 0  // interleave hint for the blocks that hold the matrix instructions of tile t + 1 and the dot products of tile t
-#endif
 
 // The unit.  On entry (ha, la) / (hb, lb) hold the A operands of the two sides' first chunks, all four channel tiles; on exit
-// (unless `last`) those of the NEXT unit's sides (`next_a`, `next_b`: complete per-lane addresses of their first chunks).
+// (REQ) those of the NEXT unit's sides (`next_a`, `next_b`: complete per-lane addresses of their first chunks).  REQ = false is
+// the copy for a depth index's last unit (peeled off the unit loop: a branch around the requests inside the unit cost 40 %).
 // MORE: some side has further chunks (wave-uniform; compiled as a second copy of the unit so that the common copy stays
 // straight-line code).
-template <bool MORE>
+template <bool MORE, bool REQ>
 __device__ __forceinline__ void cvm_unit_run(float (&cacc)[4], cvm_u4 (&ha)[4], cvm_u4 (&la)[4], cvm_u4 (&hb)[4], cvm_u4 (&lb)[4],
                                              const CvmSide& sa, const CvmSide& sb, const CvmTap& tap_a, const CvmTap& tap_b,
                                              const char* next_a, const char* next_b, float ea2, float eb2, int G,
@@ -441,22 +439,15 @@ __device__ __forceinline__ void cvm_unit_run(float (&cacc)[4], cvm_u4 (&ha)[4], 
     fa = cvm_mfma(h_a, wah, fa);
     fb = cvm_mfma(h_b, wbh, fb);
   };
-  auto request = [&](int ct) {  // (no branch around the loads after a depth index's last unit: `next` is then the unit's own
-    cvm_load_ct(ha[ct], la[ct], next_a, ct);  // first chunks - one wasted, cached request per depth index keeps the unit ONE
-    cvm_load_ct(hb[ct], lb[ct], next_b, ct);  // straight-line block that the scheduler can interleave)
+  auto request = [&](int ct) {
+    if constexpr (REQ) {
+      cvm_load_ct(ha[ct], la[ct], next_a, ct);
+      cvm_load_ct(hb[ct], lb[ct], next_b, ct);
+    }
   };
   // the dot products of a tile stay where they are written (next to the following tile's matrix instructions) instead of being
   // sunk to the cosines
 #define CVM_PIN(q) asm volatile("" : "+v"(dot[q]), "+v"(dot[q + 1]), "+v"(na[q]), "+v"(na[q + 1]), "+v"(nb[q]), "+v"(nb[q + 1]));
-#if CVM_SCHED
-#define CVM_INTERLEAVE()                                         \
-  _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
-    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);           \
-  }
-#else
-#define CVM_INTERLEAVE()
-#endif
   if constexpr (MORE) {
     // tile after tile in a rolled loop, every chunk's operands loaded on demand (the prefetched first chunks are not used: the
     // loop could only index them dynamically), then the next unit's operands
@@ -484,21 +475,17 @@ __device__ __forceinline__ void cvm_unit_run(float (&cacc)[4], cvm_u4 (&ha)[4], 
     tile(1, fa1, fb1);
     cvm_dots(fa0, fb0, dot + 0, na + 0, nb + 0);
     CVM_PIN(0)
-    CVM_INTERLEAVE()
     request(1);
     tile(2, fa0, fb0);
     cvm_dots(fa1, fb1, dot + 2, na + 2, nb + 2);
     CVM_PIN(2)
-    CVM_INTERLEAVE()
     request(2);
     tile(3, fa1, fb1);
     cvm_dots(fa0, fb0, dot + 4, na + 4, nb + 4);
     CVM_PIN(4)
-    CVM_INTERLEAVE()
     request(3);
     cvm_dots(fa1, fb1, dot + 6, na + 6, nb + 6);
   }
-#undef CVM_INTERLEAVE
 #undef CVM_PIN
   cvm_cosines(cacc, dot, na, nb, ea2, eb2, G);
 }
@@ -643,16 +630,17 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     // (the range is a minimum / maximum over the 32 rays = the two DPP rows of the half-wave)
     for (int it = 0; 2 * it < items; ++it) {
       const int i = min(2 * it + half, items - 1);  // (an odd item count: the upper half-wave repeats the last item)
-      const int v = i / NS, s = i - v * NS;
+      const int v = NS == 2 ? i >> 1 : i, s = i - v * NS;  // (n_scales is 1 or 2)
       const float2 p2 = uv[v * 32 + n];
       int x0, y0;
-      const CvmTap t = cvm_tap(p2.x, p2.y, sc.fh[s], sc.fw[s], x0, y0);
+      const int fh_s = s == 0 ? sc.fh[0] : sc.fh[1], fw_s = s == 0 ? sc.fw[0] : sc.fw[1];
+      const CvmTap t = cvm_tap(p2.x, p2.y, fh_s, fw_s, x0, y0);
       cvm_u4 wv;
       wv.x = t.c0_hi, wv.y = t.c1_hi, wv.z = t.c0_lo, wv.w = t.c1_lo;
       tapw[i * 32 + n] = wv;
       tapxy[i * 32 + n] = t.xy;
       // chunk grid anchor and occupancy: minimum / OR over the 32 rays = the two DPP rows of the half-wave
-      const int y1 = min(y0 + 1, sc.fh[s] - 1), x1 = min(x0 + 1, sc.fw[s] - 1);
+      const int y1 = min(y0 + 1, fh_s - 1), x1 = min(x0 + 1, fw_s - 1);
       int xmin = x0, ymin = y0;
 #define CVM_MM_STEP(CTRL)                                                                                                    \
   {                                                                                                                          \
@@ -747,30 +735,34 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
 #else
     const int n_units = (grid.pair_end - grid.pair_begin) * NS;
 #endif
-    for (int u = 0; u < n_units; ++u) {
+    // one unit; REQ: not the depth index's last one - the next unit's sides are looked up and their operands requested
+    auto unit = [&](auto req_tag) {
+      constexpr bool REQ = decltype(req_tag)::value;
       CVM_T(2)
       const float ga = gain[s * CVM_MAX_MAPS + 2 * pr], gb = gain[s * CVM_MAX_MAPS + 2 * pr + 1];
       const float ea = 1e-8f * ga, eb = 1e-8f * gb;  // clamps of the two norms in the scaled sums: (eps gain)^2
       const int G = s == 0 ? G0 : G1;
       const int s_cur = s;
-      // the unit after this one: next scale of the pair, else the next pair
-      if (++s == NS) {
-        s = 0, ++pr;
-        mp0 += 2 * L.map_bytes[0], mp1 += 2 * L.map_bytes[1];
-        if (++b == V) ++a, b = a + 1;
+      const int fh_u = s == 0 ? sc.fh[0] : sc.fh[1], fw_u = s == 0 ? sc.fw[0] : sc.fw[1];
+      CvmSide na_ = sa, nb_ = sb;
+      if constexpr (REQ) {  // the unit after this one: next scale of the pair, else the next pair
+        if (++s == NS) {
+          s = 0, ++pr;
+          mp0 += 2 * L.map_bytes[0], mp1 += 2 * L.map_bytes[1];
+          if (++b == V) ++a, b = a + 1;
+        }
+        const char* mpn = s == 0 ? mp0 : mp1;
+        na_ = side_of(mpn, a, s);
+        nb_ = side_of(mpn + (s == 0 ? L.map_bytes[0] : L.map_bytes[1]), b, s);
       }
-      const bool last = u == n_units - 1;
-      const char* mpn = s == 0 ? mp0 : mp1;
-      const CvmSide na_ = last ? sa : side_of(mpn, a, s);
-      const CvmSide nb_ = last ? sb : side_of(mpn + (s == 0 ? L.map_bytes[0] : L.map_bytes[1]), b, s);
       const CvmTap tap_a = tap_of(sa.item), tap_b = tap_of(sb.item);
       float cu[4] = {0.f, 0.f, 0.f, 0.f};
       if (has_more(sa) || has_more(sb))
-        cvm_unit_run<true>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half,
-                           sc.fh[s_cur], sc.fw[s_cur]);
+        cvm_unit_run<true, REQ>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half, fh_u,
+                                fw_u);
       else
-        cvm_unit_run<false>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half,
-                            sc.fh[s_cur], sc.fw[s_cur]);
+        cvm_unit_run<false, REQ>(cu, ha, la, hb, lb, sa, sb, tap_a, tap_b, first_of(na_), first_of(nb_), ea * ea, eb * eb, G, lut, n, half, fh_u,
+                                 fw_u);
       if (s_cur == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) c0[i] += cu[i];
@@ -780,7 +772,9 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       }
       sa = na_, sb = nb_;
       CVM_T(5)
-    }
+    };
+    for (int u = 0; u + 1 < n_units; ++u) unit(std::true_type{});
+    if (n_units > 0) unit(std::false_type{});
     if (row_wr) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -794,13 +788,20 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
     cvw_handoff();
     if (grid.stage_rows && CVM_EXP != 1) {
       const int ppr = cond_stride >> 2;  // pieces per row (cond_stride is a multiple of 8)
+      const int ppr_sh = (ppr & (ppr - 1)) == 0 ? __builtin_ctz(ppr) : -1;  // a power of two: shifts instead of a division
       for (int c = lane; c < 32 * ppr; c += 64) {
-        const int r = c / ppr, part = c - r * ppr;
+        const int r = ppr_sh >= 0 ? c >> ppr_sh : c / ppr, part = c - r * ppr;
         const int rpx = txi * 8 + (r & 7), rpy = (grid.tile_y0 + tyi) * 4 + (r >> 3);
         const int rpix = rpy * W + rpx;
+#if CVM_EXP == 7  // same bytes, one contiguous block per wave and depth index (is it the access pattern?)
+        if (rpx < W && rpy < H && rpix >= R.ray_begin && rpix < R.ray_begin + R.n_rays)
+          *reinterpret_cast<v4f*>(cond + (((size_t)tile * S + j) * 32) * cond_stride + 4 * c) =
+              *reinterpret_cast<const v4f*>(rows + r * cond_stride + 4 * part);
+#else
         if (rpx < W && rpy < H && rpix >= R.ray_begin && rpix < R.ray_begin + R.n_rays)
           *reinterpret_cast<v4f*>(cond + ((size_t)(rpix - R.ray_begin) * S + j) * cond_stride + 4 * part) =
               *reinterpret_cast<const v4f*>(rows + r * cond_stride + 4 * part);
+#endif
       }
     }
     CVM_T(6)

@@ -8,9 +8,10 @@ cd /tmp; rm -rf /tmp/pmcmm_* /tmp/trace_mm
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
 B="SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT"
 E="TA_TA_BUSY_sum TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"
-F="FETCH_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"
+F="FETCH_SIZE TCC_HIT_sum TCP_TCC_READ_REQ_sum"
+G="WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_sum"
 i=0
-for C_ in "$A" "$B" "$E" "$F"; do
+for C_ in "$A" "$B" "$E" "$F" "$G"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc $C_ -d /tmp/pmcmm_$i -- python $R/tools/prof_render.py 1 $CFG > $O/pmc_$i.log 2>&1
 done
