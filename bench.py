@@ -492,8 +492,9 @@ def main():
                            "interpolation of every (pair, scale) as v_mfma_f32_32x32x16_f16 over 4x4-texel chunks of a split-fp16 "
                            "operand image; dot products, cosines, colours, masks on the vector ALU)") if mm_form else
                           "cost_volume_lean_kernel<8,false,false> (epipolar register-quad walk, group cosines, colours, masks; 0 MFMA)",
-                "bound": ("none of its three units saturated (vector memory path 0.6, vector ALU 0.5, matrix pipe 0.25 busy): "
-                          "latency-bound at two waves per SIMD (256 registers: 128 accumulators + operands); DESIGN.md section 4") if mm_form
+                "bound": ("vector-ALU issue (0.67 busy in the profiled pass; matrix pipe 0.24, texture-address units 0.56): the 192 "
+                          "dot-product FMAs per lane and unit + the per-depth set-up; operands are requested a unit ahead and the matrix "
+                          "instructions of a channel tile are interleaved with the previous tile's dot products (DESIGN.md section 4)") if mm_form
                          else "vector-memory pipeline (texture-address unit / vector L1 -> registers) and vector ALU, co-bound",
                 "avg_launch_ms": round(cvk["avg_ms"], 4), "launch_rays": int(cvk["rays"] / cvk["launches"]),
                 "counters_source": cvc.get("source") if cv_fresh else

@@ -53,7 +53,7 @@ static mnerf_tuning read_tuning() {
   t.cv_mm = env_int("MNERF_CV_MM", 1);            // matrix form of the cost volume where it applies (cost_volume_mm.hip)
   t.cv_mm_spw = env_int("MNERF_CV_MM_SPW", 4);
   t.cv_uvpair = env_int("MNERF_CV_UVPAIR", -1);
-  t.cv_pair_block = env_int("MNERF_CV_PAIR_BLOCK", 8);
+  t.cv_pair_block = env_int("MNERF_CV_PAIR_BLOCK", -1);
   t.cv_grid = env_int("MNERF_CV_GRID", 0);        // 0 = the variant's default cap
   t.wa_min4 = env_int("MNERF_WA_MIN4", 200);      // 128-query workgroups once they (nearly) fill the 256 CUs
   t.wa_xcd = env_int("MNERF_WA_XCD", 1);          // query blocks of a window share an XCD (its L2 holds the K / V images)

@@ -36,7 +36,7 @@ static inline bool mnerf_aligned16(const void* p) { return (((uintptr_t)p) & 15u
 struct mnerf_tuning {
   int decoder_grid, decoder_stagger, decoder_stagger_mode;
   int cv_variant, cv_grid;
-  int cv_pair_block;  // MNERF_CV_PAIR_BLOCK (default 8): view pairs per launch of the many-view cost volume (0: all in one)
+  int cv_pair_block;  // MNERF_CV_PAIR_BLOCK: view pairs per launch of the many-view cost volume (0: all in one; default -1: 8 for the walk, all in one for the matrix form)
   int cv_mm;      // MNERF_CV_MM (default 1): the matrix form of the cost volume (cost_volume_mm.hip) where it applies (scene->feat_op given, contiguous pixels)
   int cv_mm_spw;  // MNERF_CV_MM_SPW (default 4): samples per wave and work item of the matrix form (an item = one 8x4-pixel tile x 4 x spw samples)
   int cv_uvpair;  // MNERF_CV_UVPAIR (default -1 = by LDS footprint): 1 / 0 force the per-pair projection scratch of the walk on / off

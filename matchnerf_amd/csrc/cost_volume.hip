@@ -638,7 +638,8 @@ extern "C" int mnerf_cost_volume(const mnerf_scene* scene, const mnerf_rays* ray
       // Infinity Cache (cv_walk.hpp "PAIR BLOCKS"; 8 pairs x 2 sides x 13.1 MB at 512x640 = 210 MB).  Same stream: the blocks
       // run in order, each continues the cosine sums the previous one left in the rows.  MNERF_CV_PAIR_BLOCK: pairs per
       // launch (default 8; 0 = all pairs in one launch, the round-3 form).
-      const int blk = mnerf_tune().cv_pair_block > 0 ? mnerf_tune().cv_pair_block : n_pairs;
+      const int pb = mnerf_tune().cv_pair_block;
+      const int blk = pb > 0 ? pb : (pb < 0 ? 8 : n_pairs);  // (-1 = default: 8 pairs per launch of the walk)
       for (int p0 = 0; p0 < n_pairs; p0 += blk)
         hipLaunchKernelGGL((cost_volume_lean_kernel<8, true>), dim3((unsigned)wgs), dim3(256), lds, (hipStream_t)stream,
                            *scene, *rays, cond_stride, cond, p0, p0 + blk < n_pairs ? p0 + blk : n_pairs);

@@ -871,6 +871,8 @@ int mnerf_cost_volume_mm_launch(const mnerf_scene* scene, const mnerf_rays* rays
   // Many views: one launch per BLOCK of view pairs over all rays (cv_walk.hpp "PAIR BLOCKS": the maps a launch gathers from
   // then fit the Infinity Cache and, per XCD band, come close to its L2); the raw cosine sums travel through the rows.
   const int n_pairs = scene->n_views * (scene->n_views - 1) / 2;
+  // (the matrix form requests its operands a whole unit ahead and does not need the maps of a launch to fit a cache: all pairs in
+  // one launch unless MNERF_CV_PAIR_BLOCK / the knob asks for blocks - 10 views: 67.8 ms in one launch, 77.8 in blocks of 8)
   int blk = mnerf_tune().cv_pair_block > 0 ? mnerf_tune().cv_pair_block : n_pairs;
   if (scene->n_views <= 5) blk = n_pairs;  // (what the walk does: up to 10 pairs x 2 sides x 13.1 MB at 512x640 = 262 MB)
   // rows are assembled in LDS unless that scratch is what keeps a second workgroup off the CU (160 KiB of LDS; from 7 views on)
