@@ -68,6 +68,10 @@ PRODUCTS_PER_MAC = {"f16x3": 3, "bf16x6": 6, "f32": 1, "f16": 1}
 # ceiling of each matrix path in ALGORITHMIC TFLOP/s: the pipe's dense peak / products per MAC
 PATH_CEILING_TFLOPS = {"f16x3": DENSE16_MFMA_PEAK_TFLOPS / 3, "bf16x6": DENSE16_MFMA_PEAK_TFLOPS / 6,
                        "f32": F32_MFMA_PEAK_TFLOPS, "f16": DENSE16_MFMA_PEAK_TFLOPS}
+# the matrix pipe's rate as MEASURED on this pool's boxes (tools/exp/ubench/mfma_rates.hip, profiles/current/r6_mfma_rates.log:
+# a loop of nothing but independent v_mfma_f32_32x32x16_f16, two waves per SIMD: 38.9 cycles per instruction at the nominal
+# clock instead of 32 = 2070 TFLOP/s chip): reported NEXT TO the guide's peak, never instead of it
+MEASURED_DENSE16_TFLOPS = 2070.0
 SHADER_CLOCK_HZ = 2.4e9          # ibid. ("256 CU x 2.4 GHz"); profiled passes run 1.9-2.0 GHz, so clock-based fractions are lower bounds
 L1_PEAK_BYTES = 64 * 256 * SHADER_CLOCK_HZ  # vector L1 -> registers: 64 B per clock and CU
 
@@ -592,6 +596,10 @@ def main():
                         "2500/3 = 833, bf16x6: 2500/6 = 417) or the f32-MFMA peak 157.3 (f32)",
                 "math": math, "algorithmic_tflops": round(algorithmic, 2),
                 "frac_of_dense_16bit_peak": round(algorithmic / DENSE16_MFMA_PEAK_TFLOPS, 4),
+                "frac_of_measured_matrix_rate": (round(issued_launch / secs / 1e12 / MEASURED_DENSE16_TFLOPS, 4) if math != "f32" else None),
+                "measured_matrix_rate_what": "the matrix FLOPs actually issued / launch time against 2070 TFLOP/s, the rate a loop of "
+                                             "independent v_mfma_f32_32x32x16_f16 reaches on these boxes (profiles/current/"
+                                             "r6_mfma_rates.log): the trunk's matrix phases run at that rate (DESIGN.md section 9)",
                 "mfma_pipe_frac": round(issued_launch / secs / 1e12 / DENSE16_MFMA_PEAK_TFLOPS, 4) if math != "f32"
                 else round(algorithmic / F32_MFMA_PEAK_TFLOPS, 4),
                 "mfma_pipe_what": f"matrix FLOPs actually issued ({ppm} products per MLP MAC) / launch time vs the "
