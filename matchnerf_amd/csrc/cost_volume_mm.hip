@@ -537,8 +537,8 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) char cvm_smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform: the depth index and
+  const int n = lane & 31, half = lane >> 5;                                                      //  what derives from it stay scalar)
   const int S = R.n_samples, V = sc.n_views, NS = sc.n_scales;
   const int W = R.width, H = R.height;
   const int items = V * NS;
@@ -644,8 +644,8 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       int xmin = x0, ymin = y0;
 #define CVM_MM_STEP(CTRL)                                                                                                    \
   {                                                                                                                          \
-    xmin = min(xmin, __builtin_amdgcn_update_dpp(xmin, xmin, CTRL, 0xF, 0xF, false));                                         \
-    ymin = min(ymin, __builtin_amdgcn_update_dpp(ymin, ymin, CTRL, 0xF, 0xF, false));                                         \
+    xmin = min(xmin, __builtin_amdgcn_update_dpp(0x7fffffff, xmin, CTRL, 0xF, 0xF, false)); /* old = the identity: one v_min_i32_dpp */ \
+    ymin = min(ymin, __builtin_amdgcn_update_dpp(0x7fffffff, ymin, CTRL, 0xF, 0xF, false));                                         \
   }
       CVM_MM_STEP(0xB1)   // quad_perm [1,0,3,2]
       CVM_MM_STEP(0x4E)   // quad_perm [2,3,0,1]
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
       unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
 #define CVM_OR_STEP(CTRL)                                                                             \
   {                                                                                                   \
-    mlo |= (unsigned)__builtin_amdgcn_update_dpp((int)mlo, (int)mlo, CTRL, 0xF, 0xF, false);          \
-    mhi |= (unsigned)__builtin_amdgcn_update_dpp((int)mhi, (int)mhi, CTRL, 0xF, 0xF, false);          \
+    mlo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mlo, CTRL, 0xF, 0xF, false);                 \
+    mhi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)mhi, CTRL, 0xF, 0xF, false);                 \
   }
       CVM_OR_STEP(0xB1)
       CVM_OR_STEP(0x4E)
