@@ -512,7 +512,7 @@ __host__ __device__ inline size_t cvm_wave_lds_bytes(int n_views, int n_scales, 
 #define CVM_WG_WAVES 4  // waves per workgroup: wave w runs on SIMD w % 4, so waves w and w + 4 share a SIMD
 #endif
 #ifndef CVM_EXP
-#define CVM_EXP 0  // timing experiments (tools/exp): 1 no row write-out, 2 no colour taps, 3 no units
+#define CVM_EXP 0  // timing experiments (tools/exp): 1 no row write-out, 2 no colour taps, 3 no units, 4 no dot products, 5 no matrix instructions, 6 cached operands, 8 no direct row writes (many views)
 #endif
 #ifndef CVM_PRIO
 #define CVM_PRIO 0
@@ -575,7 +575,11 @@ __global__ __launch_bounds__(64 * CVM_WG_WAVES, CVM_WAVES_PER_SIMD) void cost_vo
   const int pix = min(py, H - 1) * W + min(px, W - 1);
   const int ray_geo = pix - R.ray_begin;                                           // make_ray: pixel = ray_begin + ray
   const int ray = max(0, min(ray_geo, R.n_rays - 1));                              // rows / stratified offsets: a ray of the launch
+#if CVM_EXP == 8  // no direct row writes (many views)
+  const bool row_wr = grid.stage_rows;
+#else
   const bool row_wr = grid.stage_rows || (px < W && py < H && ray_geo >= 0 && ray_geo < R.n_rays);  // direct rows: live rays only
+#endif
   const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
   const int G0 = sc.n_group[0], G1 = NS > 1 ? sc.n_group[1] : 0;
   const int sumG = G0 + G1;
