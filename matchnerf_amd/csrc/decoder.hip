@@ -2097,7 +2097,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
   } while (0)
 #endif
 #define PP_SYNC() PP_STAMPED(__syncthreads())
-#define PP_TSYNC() PP_STAMPED(wave_group_sync(team_ctr_lds, 4, team_epoch, lane0))
+#define PP_TSYNC() PP_STAMPED(wave_group_sync(team_ctr_lds, 4, team_epoch, (int)hw_lane()))
 #define PP_NOSYNC() PP_STAMPED((void)0)
 // MNERF_PP_DMA_VOFF (round 5, default 1): a stage's requests take ONE stream base (D.wstream) and add the piece's byte offset to the
 // per-lane offset in the vector ALU (glds16_sv) instead of ~200 distinct loop-invariant `stream + constant` pointers, which the
@@ -2105,8 +2105,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
 // (gpurun_out/r5_3): 17.11 -> 16.99 ms per frame at S = 64, 36.9 -> 36.5 at S = 128.
   // `half`: 0 / 1 = the even / odd 1-KiB pieces of a stage (the two teams share the issue cost), 2 = all of them
   auto stage_dma = [&](int s, int half) {
-    unsigned voff = (unsigned)lane0 * 16u;
-    asm volatile("" : "+v"(voff));
+    const unsigned voff = hw_lane() * 16u;  // (not `lane0`: see hw_lane)
     int twl = tw;  // opaque: the requests' offsets are computed where they are used (see stage_piece)
     asm volatile("" : "+s"(twl));
     for (int i = 0; i < 2; ++i) {
@@ -2138,8 +2137,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     asm volatile("" : "+s"(twl));
     const int pce = 2 * twl + half + 8 * (k % 5);
     if (pcs > 0 && pce < pcs) {
-      unsigned vo = (unsigned)lane0 * 16u;
-      asm volatile("" : "+v"(vo));
+      const unsigned vo = hw_lane() * 16u;
       glds16_s(PP_SEG_SRC(s, i) + pce * 256, vo, __builtin_amdgcn_readfirstlane(PP_SLOT_LDS(s, i) + (unsigned)pce * 1024u));
     }
   };
@@ -2255,8 +2253,7 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
     // Everything that depends only on the lane index is re-derived per tile from an OPAQUE copy of it: hoisted out of the
     // tile loop these values (sample indices, LDS addresses, pointers) stay live across all 28 phases, the register
     // allocator parks them in scratch, and phase V_0 became a chain of ~20 scratch reloads (7 k cycles, measured).
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
+    const int lane = (int)hw_lane();
     const int n = lane & 31, hl = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
     // ------------------------------------------------------------ per-lane sample identity

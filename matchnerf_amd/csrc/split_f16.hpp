@@ -104,6 +104,15 @@ __device__ __forceinline__ void segment_wait() { asm volatile("s_waitcnt vmcnt(0
 // Outstanding VMEM / LDS-DMA traffic is NOT waited for (the ping-pong decoder keeps weight and row DMAs in flight across these
 // syncs; data that arrives by DMA is published by the issuing wave's own segment_wait() before it arrives here).
 // Everything is asm volatile with a memory clobber: the compiler moves no LDS access across it.
+// The lane index straight from the hardware (v_mbcnt), behind a volatile asm: a value the compiler can neither hoist out of a loop nor
+// keep alive across it.  The ping-pong decoder used `tid & 63` from the kernel's first lines at every weight request and every team
+// sync; live across all 28 phases it was parked in scratch memory, and each vector phase began with a scratch reload + s_waitcnt
+// vmcnt(0) (a few hundred exposed cycles, twelve times per tile) in front of its first request.
+__device__ __forceinline__ unsigned hw_lane() {
+  unsigned v;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(v));
+  return v;
+}
 __device__ __forceinline__ void wave_group_sync(unsigned ctr_lds_byte_addr, int n_waves, int& epoch, int lane) {
   epoch += n_waves;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
