@@ -454,6 +454,23 @@ int mnerf_conv_stem(const float* wstream, int32_t ew, const float* in, const flo
 /* max |x| of n floats merged into the absmax region `out` (atomic maxima; zero it first) */
 int mnerf_absmax(const float* x, int64_t n, float* out, void* stream);
 
+/* Backward of Conv2d(c_in, c_out, ksize, stride, padding = ksize / 2) for the training path of the GMFlow backbone / up-sampler
+ * (what autograd runs for models/gmflow/backbone.py:6-122, superres.py:5-38 under coach.py:215-243); exact-fp32 products on
+ * v_mfma_f32_32x32x2_f32, NCHW fp32 (matchnerf_amd/csrc/conv_backward.hip).  Built: c_in, c_out in {32, 64, 96, 128}, ksize 1 / 3,
+ * stride 1 / 2.  h_in, w_in: the convolution's INPUT size; dy is [n_img, c_out, h_out, w_out] with h_out = (h_in + 2 (ksize/2) -
+ * ksize) / stride + 1.
+ *   mnerf_conv2d_backward_data  : dx [n_img, c_in, h_in, w_in] = conv_transpose(dy, W).  w_tap_major: the weight permuted to
+ *                                 [ky][kx][c_out][c_in] (torch: weight.permute(2, 3, 0, 1).contiguous()).  dx is overwritten.
+ *   mnerf_conv2d_backward_weight: dw [c_out, c_in, ksize, ksize] (torch's layout, overwritten) = sum over images and positions;
+ *                                 partial sums of row chunks go through `workspace` (mnerf_conv2d_backward_weight_workspace_bytes)
+ *                                 and are added in chunk order: bit-reproducible. */
+int mnerf_conv2d_backward_data(const float* dy, const float* w_tap_major, float* dx, int32_t n_img, int32_t c_in, int32_t c_out,
+                               int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream);
+size_t mnerf_conv2d_backward_weight_workspace_bytes(int32_t n_img, int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in,
+                                                    int32_t ksize, int32_t stride);
+int mnerf_conv2d_backward_weight(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int32_t n_img,
+                                 int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream);
+
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
  * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):
  *   message = norm1(merge(attn));  [ffn:] message = norm2(mlp.2(GELU(mlp.0(cat[source, message]))));  out = source + message

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libmnerf_hip.so")
-SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "cost_volume.hip", "cost_volume_mm.hip", "decoder.hip", "decoder_backward.hip", "decoder_fused", "encoder_backward.hip", "encoder_block.hip",
+SOURCES = ["api.cpp", "backward.hip", "composite.hip", "conv.hip", "conv_backward.hip", "cost_volume.hip", "cost_volume_mm.hip", "decoder.hip", "decoder_backward.hip", "decoder_fused", "encoder_backward.hip", "encoder_block.hip",
            "geometry.hip", "instance_norm.hip", "qkv.hip", "render_chunk.hip", "window_attention.hip", "window_attention_backward.hip"]
 # objects that are a second compilation of another source: object name -> (source, extra flags).
 # decoder_fused: the one-launch ray chunk (decoder.hip, MNERF_DECODER_PART=1).  Its workgroups run the cost-volume walk on

@@ -29,7 +29,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
            "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
 
@@ -194,6 +194,12 @@ def load():
     lib.mnerf_conv_wstream_floats.argtypes = [i32, i32, i32]
     lib.mnerf_conv2d.restype = C.c_int
     lib.mnerf_conv2d.argtypes = [C.POINTER(ConvLayer), fp, i32, i32, fp, fp, fp, fp, i32, fp, i32, i32, i32, vp]
+    lib.mnerf_conv2d_backward_data.restype = C.c_int
+    lib.mnerf_conv2d_backward_data.argtypes = [fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_conv2d_backward_weight_workspace_bytes.restype = C.c_size_t
+    lib.mnerf_conv2d_backward_weight_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
+    lib.mnerf_conv2d_backward_weight.restype = C.c_int
+    lib.mnerf_conv2d_backward_weight.argtypes = [fp, fp, fp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.mnerf_conv_stem_wstream_floats.restype = i64
     lib.mnerf_conv_stem_wstream_floats.argtypes = []
     lib.mnerf_conv_stem.restype = C.c_int
@@ -892,6 +898,40 @@ def absmax(x, out, stream=None):
     with _on(x.device, stream) as st:
         check(lib.mnerf_absmax(_ptr(x), x.numel(), _ptr(out), st), "mnerf_absmax")
     return out
+
+
+def conv2d_backward_data(dy, weight, h_in, w_in, stride, stream=None):
+    """dX of Conv2d(c_in, c_out, k, stride, padding=k//2) (csrc/conv_backward.hip).  dy [N,c_out,Ho,Wo], weight [c_out,c_in,k,k]
+    -> [N,c_in,h_in,w_in]."""
+    import torch
+    lib = load()
+    _f32c(dy, "dy")
+    c_out, c_in, k, _ = weight.shape
+    n = dy.shape[0]
+    wt = weight.detach().permute(2, 3, 0, 1).contiguous()
+    dx = torch.empty(n, c_in, h_in, w_in, device=dy.device, dtype=torch.float32)
+    with _on(dy.device, stream) as st:
+        check(lib.mnerf_conv2d_backward_data(_ptr(dy), _ptr(wt), _ptr(dx), n, c_in, c_out, int(h_in), int(w_in), int(k), int(stride), st),
+              "mnerf_conv2d_backward_data")
+    return dx
+
+
+def conv2d_backward_weight(x, dy, ksize, stride, stream=None):
+    """dW of the same convolution: x [N,c_in,H,W], dy [N,c_out,Ho,Wo] -> [c_out,c_in,k,k]."""
+    import torch
+    lib = load()
+    _f32c(x, "x"), _f32c(dy, "dy")
+    n, c_in, h, w = x.shape
+    c_out = dy.shape[1]
+    nbytes = int(lib.mnerf_conv2d_backward_weight_workspace_bytes(n, c_in, c_out, h, w, int(ksize), int(stride)))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    if stream is not None:
+        ws.record_stream(stream)
+    dw = torch.empty(c_out, c_in, ksize, ksize, device=x.device, dtype=torch.float32)
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), ws.data_ptr(), nbytes, n, c_in, c_out, h, w, int(ksize), int(stride),
+                                               st), "mnerf_conv2d_backward_weight")
+    return dw
 
 
 def conv_stem(x, wstream, ew, in_absmax, out=None, stream=None):

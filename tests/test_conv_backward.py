@@ -1,0 +1,55 @@
+"""Backward of the backbone / up-sampler convolutions (csrc/conv_backward.hip) against torch's own conv gradients in float64 on the
+CPU: every (channels, filter, stride) combination the GMFlow CNN has, odd sizes, borders, bit-reproducibility of the weight gradient."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, dy, stride):
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(x64, w64, None, stride, w.shape[2] // 2)
+    assert y.shape == dy.shape, (y.shape, dy.shape)
+    y.backward(dy.double())
+    return x64.grad, w64.grad
+
+
+CASES = [  # (n, c_in, c_out, h, w, k, stride)
+    (2, 64, 64, 20, 40, 3, 1), (1, 64, 96, 21, 37, 3, 2), (2, 96, 96, 12, 24, 3, 1), (1, 96, 128, 16, 24, 3, 2),
+    (1, 128, 128, 9, 13, 3, 1), (2, 64, 96, 10, 18, 1, 2), (1, 96, 128, 11, 15, 1, 2), (2, 128, 128, 8, 10, 1, 1),
+    (1, 32, 64, 7, 5, 3, 1), (1, 128, 32, 6, 70, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_backward_matches_torch_float64(case):
+    from matchnerf_amd import hip
+    n, ci, co, h, w, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    # gradients over many binades, as a real loss produces them
+    dy = torch.randn(n, co, ho, wo, generator=g) * 2.0 ** torch.randint(-20, -4, (n, co, 1, 1), generator=g).float()
+    dx_ref, dw_ref = _ref(x, wt, dy, s)
+    dx = hip.conv2d_backward_data(dy.cuda(), wt.cuda(), h, w, s).cpu().double()
+    dw = hip.conv2d_backward_weight(x.cuda(), dy.cuda(), k, s).cpu().double()
+    assert (dx - dx_ref).abs().max() <= 2e-6 * dx_ref.abs().max(), case
+    assert (dw - dw_ref).abs().max() <= 2e-6 * dw_ref.abs().max(), case
+    again = hip.conv2d_backward_weight(x.cuda(), dy.cuda(), k, s).cpu().double()
+    assert torch.equal(again, dw)
+
+
+def test_conv_backward_at_the_backbone_shape():
+    """layer1's convolution at the DTU shape (3 x 64 x 256 x 320): the weight gradient's chunked reduction over 768 rows"""
+    from matchnerf_amd import hip
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 64, 256, 320, generator=g).cuda()
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).cuda()
+    dy = (torch.randn(3, 64, 256, 320, generator=g) * 1e-4).cuda()
+    dx = hip.conv2d_backward_data(dy, wt, 256, 320, 1)
+    dw = hip.conv2d_backward_weight(x, dy, 3, 1)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wt.double(), dy.double(), 1, 1)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), 1, 1)
+    assert (dx.double() - ref_dx).abs().max() <= 2e-6 * ref_dx.abs().max()
+    assert (dw.double() - ref_dw).abs().max() <= 5e-6 * ref_dw.abs().max()
