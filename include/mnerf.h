@@ -408,6 +408,12 @@ int mnerf_window_attention_backward_stats(const float* q, const float* k, const 
 int mnerf_instance_norm(const float* x, const float* residual, float* out, int64_t planes, int64_t plane_size,
                         float eps, int32_t relu_inner, int32_t relu_outer, float* out_absmax, void* stream);
 
+/* Backward of out = [relu](InstanceNorm(x)) (training path; what autograd runs for F.instance_norm + F.relu in
+ * models/gmflow/backbone.py:27-35, 101-103): dx from x (the norm's INPUT, the statistics are re-derived) and dy.  relu: the forward
+ * applied a ReLU to the normalised value.  x, dy, dx: [planes][plane_size] fp32; dx may alias dy. */
+int mnerf_instance_norm_backward(const float* x, const float* dy, float* dx, int64_t planes, int64_t plane_size, float eps,
+                                 int32_t relu, void* stream);
+
 /* Convolutions of the GMFlow backbone / up-sampler (models/gmflow/backbone.py:6-122, superres.py:5-38) as implicit
  * GEMMs with fp32-grade split-fp16 products (matchnerf_amd/csrc/conv.hip).  Built: c_in a multiple of 32, c_out 64 /
  * 96 / 128, 1x1 and 3x3 filters with padding ksize/2, stride 1 / 2.
@@ -470,6 +476,17 @@ size_t mnerf_conv2d_backward_weight_workspace_bytes(int32_t n_img, int32_t c_in,
                                                     int32_t ksize, int32_t stride);
 int mnerf_conv2d_backward_weight(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int32_t n_img,
                                  int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream);
+/* The training FORWARD of the same convolutions in exact fp32 (the gradients' arithmetic; no weight stream to re-pack after every
+ * optimizer step): y [n_img, c_out, h_out, w_out] = conv(x, W) + bias.  w_tap_major: the weight permuted to [ky][kx][c_in][c_out]
+ * (torch: weight.permute(2, 3, 1, 0).contiguous()); bias [c_out] or NULL.  c_in: any count up to 128 (the stem: 3), c_out a
+ * multiple of 32 up to 128, ksize 1 / 3 / 7, stride 1 / 2. */
+int mnerf_conv2d_forward_f32(const float* x, const float* w_tap_major, const float* bias, float* y, int32_t n_img, int32_t c_in,
+                             int32_t c_out, int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream);
+/* Weight gradient of the stem Conv2d(3, 64, 7, stride 2, padding 3) (backbone.py:45): dw [64, 3, 7, 7]; x [n_img, 3, h_in, w_in],
+ * dy [n_img, 64, (h_in - 1) / 2 + 1, (w_in - 1) / 2 + 1].  (Its data gradient is the gradient of the images: never needed.) */
+size_t mnerf_conv_stem_backward_weight_workspace_bytes(int32_t n_img, int32_t h_in, int32_t w_in);
+int mnerf_conv_stem_backward_weight(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int32_t n_img,
+                                    int32_t h_in, int32_t w_in, void* stream);
 
 /* K7 — what follows the window attention inside one GMFlow transformer layer, as one kernel
  * (TransformerLayer.forward, models/gmflow/transformer.py:176-185):

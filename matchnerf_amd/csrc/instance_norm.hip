@@ -161,3 +161,52 @@ extern "C" int mnerf_instance_norm(const float* x, const float* residual, float*
 #undef IN_LAUNCH
   return mnerf_check_launch("mnerf_instance_norm");
 }
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+// y = [relu](IN(x)):  g = dy where the output passed the ReLU (xhat > 0), else 0;
+//   dx = rstd (g - mean(g) - xhat mean(g xhat)),   xhat = (x - mean) rstd   (biased variance, no affine: backbone.py:12-14)
+// One workgroup per plane, the statistics of x are re-derived as the forward derives them (mean, then the centred variance), so the
+// training path keeps nothing but x itself from the forward.  Five passes over a plane that stays in L2 (327 KB at most).
+__global__ __launch_bounds__(512) void instance_norm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                                     int plane_size, float eps, int relu) {
+  __shared__ float red[8];
+  const size_t base = (size_t)blockIdx.x * plane_size;
+  const float* xs = x + base;
+  const float* gs = dy + base;
+  const float inv_n = 1.0f / (float)plane_size;
+  float s = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 512) s += xs[j];
+  const float mean = in_block_sum<512>(s, red) * inv_n;
+  float q = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 512) {
+    const float a = xs[j] - mean;
+    q += a * a;
+  }
+  const float rstd = 1.0f / sqrtf(in_block_sum<512>(q, red) * inv_n + eps);
+  float sg = 0.0f, sgx = 0.0f;
+  for (int j = threadIdx.x; j < plane_size; j += 512) {
+    const float xh = (xs[j] - mean) * rstd;
+    const float g = (relu && !(xh > 0.0f)) ? 0.0f : gs[j];
+    sg += g;
+    sgx += g * xh;
+  }
+  const float mg = in_block_sum<512>(sg, red) * inv_n;
+  const float mgx = in_block_sum<512>(sgx, red) * inv_n;
+  for (int j = threadIdx.x; j < plane_size; j += 512) {
+    const float xh = (xs[j] - mean) * rstd;
+    const float g = (relu && !(xh > 0.0f)) ? 0.0f : gs[j];
+    dx[base + j] = rstd * (g - mg - xh * mgx);
+  }
+}
+
+extern "C" int mnerf_instance_norm_backward(const float* x, const float* dy, float* dx, int64_t planes, int64_t plane_size, float eps,
+                                            int32_t relu, void* stream) {
+  MNERF_REQUIRE(planes >= 0 && planes <= 0x7fffffffLL && plane_size >= 1 && plane_size <= 0x7fffffffLL, MNERF_E_RANGE,
+                "mnerf_instance_norm_backward: planes=%lld plane_size=%lld", (long long)planes, (long long)plane_size);
+  MNERF_REQUIRE(eps >= 0.0f, MNERF_E_RANGE, "mnerf_instance_norm_backward: eps=%g", (double)eps);
+  if (planes == 0) return MNERF_OK;
+  MNERF_REQUIRE(x && dy && dx, MNERF_E_NULL, "mnerf_instance_norm_backward: NULL buffer");
+  hipLaunchKernelGGL(instance_norm_backward_kernel, dim3((unsigned)planes), dim3(512), 0, (hipStream_t)stream, x, dy, dx, (int)plane_size, eps,
+                     relu);
+  return mnerf_check_launch("mnerf_instance_norm_backward");
+}

@@ -29,7 +29,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
            "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
 
@@ -190,6 +190,8 @@ def load():
     lib.mnerf_window_attention_images.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_instance_norm.restype = C.c_int
     lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, fp, vp]
+    lib.mnerf_instance_norm_backward.restype = C.c_int
+    lib.mnerf_instance_norm_backward.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, vp]
     lib.mnerf_conv_wstream_floats.restype = i64
     lib.mnerf_conv_wstream_floats.argtypes = [i32, i32, i32]
     lib.mnerf_conv2d.restype = C.c_int
@@ -200,6 +202,12 @@ def load():
     lib.mnerf_conv2d_backward_weight_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.mnerf_conv2d_backward_weight.restype = C.c_int
     lib.mnerf_conv2d_backward_weight.argtypes = [fp, fp, fp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_conv2d_forward_f32.restype = C.c_int
+    lib.mnerf_conv2d_forward_f32.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_conv_stem_backward_weight_workspace_bytes.restype = C.c_size_t
+    lib.mnerf_conv_stem_backward_weight_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.mnerf_conv_stem_backward_weight.restype = C.c_int
+    lib.mnerf_conv_stem_backward_weight.argtypes = [fp, fp, fp, vp, C.c_size_t, i32, i32, i32, vp]
     lib.mnerf_conv_stem_wstream_floats.restype = i64
     lib.mnerf_conv_stem_wstream_floats.argtypes = []
     lib.mnerf_conv_stem.restype = C.c_int
@@ -900,6 +908,19 @@ def absmax(x, out, stream=None):
     return out
 
 
+def instance_norm_backward(x, dy, relu, eps=1e-5, stream=None):
+    """dx of out = [relu](InstanceNorm2d(x)) (no affine): x, dy [N,C,H,W] -> [N,C,H,W] (csrc/instance_norm.hip)."""
+    import torch
+    lib = load()
+    _f32c(x, "x"), _f32c(dy, "dy")
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_instance_norm_backward(_ptr(x), _ptr(dy), _ptr(dx), n * c, h * w, float(eps), int(bool(relu)), st),
+              "mnerf_instance_norm_backward")
+    return dx
+
+
 def conv2d_backward_data(dy, weight, h_in, w_in, stride, stream=None):
     """dX of Conv2d(c_in, c_out, k, stride, padding=k//2) (csrc/conv_backward.hip).  dy [N,c_out,Ho,Wo], weight [c_out,c_in,k,k]
     -> [N,c_in,h_in,w_in]."""
@@ -914,6 +935,41 @@ def conv2d_backward_data(dy, weight, h_in, w_in, stride, stream=None):
         check(lib.mnerf_conv2d_backward_data(_ptr(dy), _ptr(wt), _ptr(dx), n, c_in, c_out, int(h_in), int(w_in), int(k), int(stride), st),
               "mnerf_conv2d_backward_data")
     return dx
+
+
+def conv2d_forward_f32(x, weight, bias, stride, stream=None):
+    """Conv2d(c_in, c_out, k, stride, padding=k//2) in exact fp32 (the training forward; csrc/conv_backward.hip).
+    x [N,c_in,H,W], weight [c_out,c_in,k,k] -> [N,c_out,Ho,Wo]."""
+    import torch
+    lib = load()
+    _f32c(x, "x")
+    c_out, c_in, k, _ = weight.shape
+    n, _, h, w = x.shape
+    wt = weight.detach().permute(2, 3, 1, 0).contiguous()
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    y = torch.empty(n, c_out, ho, wo, device=x.device, dtype=torch.float32)
+    b = bias.detach().contiguous() if bias is not None else None
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_conv2d_forward_f32(_ptr(x), _ptr(wt), _ptr(b), _ptr(y), n, c_in, c_out, h, w, int(k), int(stride), st),
+              "mnerf_conv2d_forward_f32")
+    return y
+
+
+def conv_stem_backward_weight(x, dy, stream=None):
+    """dW [64,3,7,7] of the stem Conv2d(3, 64, 7, 2, 3): x [N,3,H,W], dy [N,64,(H-1)//2+1,(W-1)//2+1]."""
+    import torch
+    lib = load()
+    _f32c(x, "x"), _f32c(dy, "dy")
+    n, _, h, w = x.shape
+    nbytes = int(lib.mnerf_conv_stem_backward_weight_workspace_bytes(n, h, w))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    if stream is not None:
+        ws.record_stream(stream)
+    dw = torch.empty(64, 3, 7, 7, device=x.device, dtype=torch.float32)
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_conv_stem_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), ws.data_ptr(), nbytes, n, h, w, st),
+              "mnerf_conv_stem_backward_weight")
+    return dw
 
 
 def conv2d_backward_weight(x, dy, ksize, stride, stream=None):

@@ -53,3 +53,44 @@ def test_conv_backward_at_the_backbone_shape():
     ref_dw = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), 1, 1)
     assert (dx.double() - ref_dx).abs().max() <= 2e-6 * ref_dx.abs().max()
     assert (dw.double() - ref_dw).abs().max() <= 5e-6 * ref_dw.abs().max()
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(2, 5, 16, 24), (1, 3, 7, 9), (1, 2, 256, 320)])
+def test_instance_norm_backward_matches_autograd_float64(shape, relu):
+    from matchnerf_amd import hip
+    g = torch.Generator().manual_seed(sum(shape) + int(relu))
+    x = torch.randn(*shape, generator=g) * 3.0 + 0.5
+    dy = torch.randn(*shape, generator=g) * 1e-3
+    x64 = x.double().requires_grad_(True)
+    y = torch.nn.functional.instance_norm(x64)
+    if relu:
+        y = torch.relu(y)
+    y.backward(dy.double())
+    dx = hip.instance_norm_backward(x.cuda(), dy.cuda(), relu).cpu().double()
+    assert (dx - x64.grad).abs().max() <= 1e-5 * x64.grad.abs().max(), (shape, relu)
+
+
+@pytest.mark.parametrize("case", CASES + [(2, 3, 64, 30, 44, 7, 2), (1, 3, 64, 17, 23, 7, 2)])
+def test_conv_forward_f32_matches_torch_float64(case):
+    from matchnerf_amd import hip
+    n, ci, co, h, w, k, s = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5
+    bias = torch.randn(co, generator=g) if k == 1 else None
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), None if bias is None else bias.double(), s, k // 2)
+    y = hip.conv2d_forward_f32(x.cuda(), wt.cuda(), None if bias is None else bias.cuda(), s).cpu().double()
+    assert y.shape == ref.shape and (y - ref).abs().max() <= 2e-6 * ref.abs().max(), case
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 44), (1, 17, 23), (3, 64, 80)])
+def test_stem_weight_gradient_matches_torch_float64(shape):
+    from matchnerf_amd import hip
+    n, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, 3, h, w, generator=g)
+    dy = torch.randn(n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1, generator=g) * 1e-3
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy.double(), 2, 3)
+    dw = hip.conv_stem_backward_weight(x.cuda(), dy.cuda()).cpu().double()
+    assert (dw - ref).abs().max() <= 3e-6 * ref.abs().max(), shape
