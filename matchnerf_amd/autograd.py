@@ -168,6 +168,110 @@ def transformer_layer(layer, source, target, h, w, splits, shifted):
 # ----------------------------------------------------------------------------- K1..K5
 
 
+class _ConvFn(torch.autograd.Function):
+    """Conv2d(c_in, c_out, k, stride, padding=k//2) of the GMFlow backbone / up-sampler on the training path: forward, data gradient
+    and weight gradient on the exact-f32 matrix instruction (csrc/conv_backward.hip) - what autograd ran on MIOpen until round 6
+    (backbone.py:6-122, superres.py:5-38 under coach.py:215-243)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias = int(stride), bias is not None
+        return hip.conv2d_forward_f32(x, weight, bias, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        c_out, c_in, k, _ = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.conv2d_backward_data(dy, weight, x.shape[2], x.shape[3], ctx.stride)
+        if ctx.needs_input_grad[1]:
+            dw = hip.conv_stem_backward_weight(x, dy) if (c_in, k) == (3, 7) else hip.conv2d_backward_weight(x, dy, k, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None
+
+
+class _ConvFn16(torch.autograd.Function):
+    """The same node with the FORWARD - and, where the data gradient is itself a convolution the forward kernel builds (stride 1,
+    c_in 64 / 96 / 128), the DATA GRADIENT - on the split-fp16 convolution of inference (csrc/conv.hip: three fp16 products per
+    MAC at ~4 x the exact-f32 matrix rate), from weight streams packed on the device once per optimizer step
+    (packing.ConvPacker).  Stride-2 data gradients and all weight gradients stay on conv_backward.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pack):
+        x = x.contiguous()
+        ws_f, ws_b, ew = pack
+        c_out, c_in, k, _ = weight.shape
+        region = hip.absmax_regions(1, x.device)[0]
+        hip.absmax(x, region)
+        if (c_in, k) == (3, 7):
+            y = hip.conv_stem(x, ws_f, ew, region)
+        else:
+            y = hip.conv2d(x, ws_f, None if bias is None else bias.detach(), c_in, c_out, k, int(stride), ew, region)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias, ctx.ws_b, ctx.ew = int(stride), bias is not None, ws_b, ew
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        c_out, c_in, k, _ = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if ctx.ws_b is not None:
+                region = hip.absmax_regions(1, dy.device)[0]
+                hip.absmax(dy, region)
+                dx = hip.conv2d(dy, ctx.ws_b, None, c_out, c_in, k, 1, ctx.ew, region)
+            else:
+                dx = hip.conv2d_backward_data(dy, weight, x.shape[2], x.shape[3], ctx.stride)
+        if ctx.needs_input_grad[1]:
+            dw = hip.conv_stem_backward_weight(x, dy) if (c_in, k) == (3, 7) else hip.conv2d_backward_weight(x, dy, k, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+def conv2d(conv, x):
+    """``conv`` (an nn.Conv2d of a shape conv_backward.hip builds) applied to x [N,C,H,W] as one autograd node of HIP kernels; with
+    a ``_mnerf_train_pack`` on the module (gmflow: set per optimizer step) the split-fp16 kernels serve forward and data gradient"""
+    pack = getattr(conv, "_mnerf_train_pack", None)
+    if pack is not None:
+        return _ConvFn16.apply(x, conv.weight, conv.bias, conv.stride[0], pack)
+    return _ConvFn.apply(x, conv.weight, conv.bias, conv.stride[0])
+
+
+def conv2d_supported(conv):
+    k, s, ci, co = conv.kernel_size[0], conv.stride[0], conv.in_channels, conv.out_channels
+    return (co % 32 == 0 and co <= 128 and conv.padding[0] == k // 2 and s in (1, 2) and conv.dilation[0] == 1 and conv.groups == 1
+            and (((k in (1, 3)) and ci % 32 == 0 and ci <= 128) or (k, ci, co, s) == (7, 3, 64, 2)))
+
+
+class _InstanceNormFn(torch.autograd.Function):
+    """[relu](F.instance_norm(x)) (no affine, eps 1e-5): the fused forward kernel of inference, and a backward that re-derives the
+    plane statistics from x (csrc/instance_norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, relu):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.relu = bool(relu)
+        return hip.instance_norm(x, relu_inner=relu)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.instance_norm_backward(x, dy.contiguous(), ctx.relu), None
+
+
+def instance_norm(x, relu=False):
+    return _InstanceNormFn.apply(x, relu)
+
+
 def ray_directions_torch(kinv, c2w, ray_idx, width, legacy):
     """target-ray directions [R,3] (un-normalised, camera.py:255-278) for pixel indices ``ray_idx`` on the GPU"""
     dev = ray_idx.device

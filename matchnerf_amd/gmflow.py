@@ -39,6 +39,35 @@ def _fused_norm(x):
     return x.is_cuda and not torch.is_grad_enabled()
 
 
+def _train_hip(x):
+    """Training path (autograd on) of the CNN on this library's kernels - forward, data and weight gradients of every convolution and the
+    InstanceNorm backward (csrc/conv_backward.hip, instance_norm.hip; forward and stride-1 data gradients on the split-fp16
+    convolution of inference, csrc/conv.hip) - instead of torch's op chain (MIOpen convolutions, ATen norms).
+    ``MNERF_TRAIN_CNN=torch`` restores that chain, ``=f32`` keeps every convolution on the exact-f32 kernels."""
+    import os
+    return x.is_cuda and torch.is_grad_enabled() and os.environ.get("MNERF_TRAIN_CNN", "hip") != "torch"
+
+
+def _train_packs(owner, convs, device):
+    """Attach this step's split-fp16 weight streams (packing.ConvPacker: one gather + one device->host copy for all of them) to the
+    convolutions of ``owner``'s training path; re-packed when a parameter changed (``MNERF_TRAIN_CNN=f32``: none - exact-f32
+    kernels for the forward too)."""
+    import os
+    if os.environ.get("MNERF_TRAIN_CNN", "hip") == "f32":
+        for c in convs:
+            c._mnerf_train_pack = None
+        return
+    from . import packing
+    key = (tuple((int(c.weight._version), int(c.weight.data_ptr())) for c in convs), str(device))
+    if getattr(owner, "_train_pack_key", None) != key:
+        pk = getattr(owner, "_train_packer", None)
+        if pk is None or pk.device != torch.device(device) or len(pk.convs) != len(convs) or any(a is not b for a, b in zip(pk.convs, convs)):
+            pk = owner._train_packer = packing.ConvPacker(convs, device)
+        for c, pack in zip(convs, pk.pack()):
+            c._mnerf_train_pack = pack
+        owner._train_pack_key = key
+
+
 def _conv_out(conv, x):
     """library convolution result as a plain NCHW-contiguous fp32 tensor (what ``mnerf_instance_norm`` reads plane by plane)"""
     return conv(x).contiguous()
@@ -117,6 +146,13 @@ class ResidualBlock(nn.Module):
         return y, scal[1]
 
     def forward(self, x):
+        if _train_hip(x):
+            from . import autograd as AG
+            y = AG.instance_norm(AG.conv2d(self.conv1, x), relu=True)
+            y = AG.instance_norm(AG.conv2d(self.conv2, y), relu=True)
+            if self.downsample is not None:
+                x = AG.instance_norm(AG.conv2d(self.downsample[0], x))
+            return F.relu(x + y)
         y = F.relu(F.instance_norm(self.conv1(x)))
         y = F.relu(F.instance_norm(self.conv2(y)))
         if self.downsample is not None:
@@ -160,8 +196,14 @@ class CNNEncoder(nn.Module):
             if tokens_plus is not None:
                 return _hip_conv(self.conv2, x, amax, out_layout=hip.CONV_OUT_CHANNEL_LAST, add_channel_last=tokens_plus)
             return _hip_conv(self.conv2, x, amax)
-        x = F.relu(F.instance_norm(self.conv1(x)))
-        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        if _train_hip(x):
+            from . import autograd as AG
+            _train_packs(self, [m for m in self.modules() if isinstance(m, nn.Conv2d)], x.device)
+            x = AG.instance_norm(AG.conv2d(self.conv1, x), relu=True)
+            x = AG.conv2d(self.conv2, self.layer3(self.layer2(self.layer1(x))))
+        else:
+            x = F.relu(F.instance_norm(self.conv1(x)))
+            x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return x if tokens_plus is None else x.permute(0, 2, 3, 1) + tokens_plus.reshape(x.shape[2], x.shape[3], -1)
 
 
@@ -448,11 +490,17 @@ class UpSampler(nn.Module):
         return right
 
     def forward(self, x):
-        right = self.conv_l2rs[0](x)
+        if _train_hip(x):
+            from . import autograd as AG
+            _train_packs(self, list(self.conv_ls) + list(self.conv_l2rs), x.device)
+            conv = AG.conv2d
+        else:
+            conv = lambda m, t: m(t)  # noqa: E731
+        right = conv(self.conv_l2rs[0], x)
         left = x
         for i in range(self.n_blocks):
-            left = F.leaky_relu(self.conv_ls[i](F.interpolate(left, scale_factor=2.0, mode="nearest")), 0.2)
-            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + self.conv_l2rs[i + 1](left)
+            left = F.leaky_relu(conv(self.conv_ls[i], F.interpolate(left, scale_factor=2.0, mode="nearest")), 0.2)
+            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + conv(self.conv_l2rs[i + 1], left)
         return right
 
 

@@ -197,6 +197,84 @@ class TransformerPacker:
         return out
 
 
+_CONV_INDEX = {}  # (conv shapes, device) -> (int32 index [units, 512], spans)
+
+
+class ConvPacker:
+    """The split-fp16 weight streams of a list of nn.Conv2d (gmflow.pack_conv / pack_conv_stem) for the TRAINING path, from one gather:
+    per convolution the forward stream W[co, tap * c_in + c] and, for stride-1 convolutions whose data gradient is itself a
+    convolution the forward kernel builds (c_in 64 / 96 / 128), the stream of the flipped, transposed filter
+    W'[ci, tap' * c_out + co] = W[co, ci, k-1-ky', k-1-kx'] - ``mnerf_conv2d`` over dY with it IS dX.  One device->host copy per
+    pack (the exponents); the index depends on the shapes only."""
+
+    def __init__(self, convs, device):
+        self.device = torch.device(device)
+        self.convs = list(convs)
+        sig = (tuple((c.out_channels, c.in_channels, c.kernel_size[0], c.stride[0]) for c in self.convs), str(self.device))
+        if sig not in _CONV_INDEX:
+            _CONV_INDEX[sig] = self._build_index()
+        self.index, self.spans = _CONV_INDEX[sig]
+
+    @staticmethod
+    def has_backward_stream(conv):
+        return conv.stride[0] == 1 and conv.kernel_size[0] in (1, 3) and conv.in_channels in (64, 96, 128) and conv.out_channels % 32 == 0
+
+    def _build_index(self):
+        chunks, spans, off, pos = [], [], 0, 0
+        lane = np.arange(64)
+
+        def frag(flat_of, n_rows, n_cols, cols):
+            """[T * nmb units, 512]: positions of the fragment elements; flat_of(row, col) -> position in the concatenation (or the
+            zero slot, marked -1, for padding)"""
+            nmb = n_rows // 32
+            c = np.asarray(cols)                                           # [T, 2, 8]
+            col = np.broadcast_to(c[:, lane >> 5, :][:, None], (c.shape[0], nmb, 64, 8))
+            row = np.broadcast_to((lane & 31)[None, None, :, None] + 32 * np.arange(nmb)[None, :, None, None], col.shape)
+            flat = np.where(col < n_cols, flat_of(row, np.minimum(col, n_cols - 1)), -1)
+            return flat.reshape(-1, 512)
+
+        for conv in self.convs:
+            co, ci, k = conv.out_channels, conv.in_channels, conv.kernel_size[0]
+            base, off = off, off + co * ci * k * k
+
+            def fwd(row, col, base=base, ci=ci, k=k):      # row = co, col = tap * ci + c  ->  W[co][c][ky][kx]
+                tap, c = col // ci, col % ci
+                return base + ((row * ci + c) * k + tap // k) * k + tap % k
+
+            def bwd(row, col, base=base, ci=ci, co=co, k=k):  # row = ci, col = tap' * co + o  ->  W[o][ci][k-1-ky'][k-1-kx']
+                tap, o = col // co, col % co
+                return base + ((o * ci + row) * k + (k - 1 - tap // k)) * k + (k - 1 - tap % k)
+
+            n_f = k * k * ci
+            steps_f = (n_f + 15) // 16
+            chunks.append(frag(fwd, co, n_f, np.arange(steps_f * 16).reshape(-1, 2, 8)))
+            f_span = (pos, pos + chunks[-1].shape[0])
+            pos = f_span[1]
+            b_span = None
+            if self.has_backward_stream(conv):
+                n_b = k * k * co
+                chunks.append(frag(bwd, ci, n_b, np.arange(n_b).reshape(-1, 2, 8)))
+                b_span = (pos, pos + chunks[-1].shape[0])
+                pos = b_span[1]
+            spans.append((f_span, b_span))
+        idx = np.concatenate(chunks, 0)
+        idx = np.where(idx < 0, off, idx)  # the zero slot behind the last weight
+        assert idx.max() <= off < 2 ** 31
+        return torch.from_numpy(idx.astype(np.int32)).to(self.device), spans
+
+    def pack(self):
+        """-> per convolution (forward stream, backward stream or None, ew): float32-word views of one fresh buffer"""
+        ts = [c.weight.detach() for c in self.convs]
+        ews = [exponent_of_absmax(float(m)) for m in torch.stack(torch._foreach_norm(ts, float("inf"))).tolist()]
+        scaled = torch._foreach_mul(ts, [float(2.0 ** e) for e in ews])
+        flat = torch.cat([t.reshape(-1) for t in scaled] + [ts[0].new_zeros(1)])
+        g = flat[self.index.long()]
+        hi = g.to(torch.float16)
+        lo = (g - hi.to(torch.float32)).to(torch.float16)
+        words = torch.stack([hi, lo], 1).reshape(-1).view(torch.float32)
+        return [(words[f[0] * 512:f[1] * 512], None if b is None else words[b[0] * 512:b[1] * 512], e) for (f, b), e in zip(self.spans, ews)]
+
+
 class DecoderPacker:
     """The conditional-NeRF decoder's split-fp16 weight stream (cond_nerf.pack_wstream_h) assembled on the device, with NO
     device->host copy at all: this stream carries its scale exponents in the stage headers (float [128] = 2^-ew, [129] = ew), so
