@@ -476,6 +476,12 @@ size_t mnerf_conv2d_backward_weight_workspace_bytes(int32_t n_img, int32_t c_in,
                                                     int32_t ksize, int32_t stride);
 int mnerf_conv2d_backward_weight(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int32_t n_img,
                                  int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream);
+/* The weight gradient on the 16-bit matrix pipe: operands as two fp16 terms with one power-of-two gain per tensor, three products per
+ * MAC, fp32 accumulation (the forward kernels' arithmetic).  x_absmax / dy_absmax: absmax regions (MNERF_ABSMAX_FLOATS floats, see
+ * mnerf_conv2d) holding max |x| and max |dy| - filled by mnerf_absmax or the tensors' producers.  Same workspace. */
+int mnerf_conv2d_backward_weight_f16x3(const float* x, const float* dy, const float* x_absmax, const float* dy_absmax, float* dw,
+                                       void* workspace, size_t workspace_bytes, int32_t n_img, int32_t c_in, int32_t c_out, int32_t h_in,
+                                       int32_t w_in, int32_t ksize, int32_t stride, void* stream);
 /* The training FORWARD of the same convolutions in exact fp32 (the gradients' arithmetic; no weight stream to re-pack after every
  * optimizer step): y [n_img, c_out, h_out, w_out] = conv(x, W) + bias.  w_tap_major: the weight permuted to [ky][kx][c_in][c_out]
  * (torch: weight.permute(2, 3, 1, 0).contiguous()); bias [c_out] or NULL.  c_in: any count up to 128 (the stem: 3), c_out a

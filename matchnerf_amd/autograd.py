@@ -212,25 +212,30 @@ class _ConvFn16(torch.autograd.Function):
             y = hip.conv_stem(x, ws_f, ew, region)
         else:
             y = hip.conv2d(x, ws_f, None if bias is None else bias.detach(), c_in, c_out, k, int(stride), ew, region)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x, weight, region)
         ctx.stride, ctx.has_bias, ctx.ws_b, ctx.ew = int(stride), bias is not None, ws_b, ew
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, x_region = ctx.saved_tensors
         dy = dy.contiguous()
         c_out, c_in, k, _ = weight.shape
         dx = dw = db = None
+        dy_region = hip.absmax_regions(1, dy.device)[0]  # max |dy|: the gain of the split-fp16 operands of both gradients
+        hip.absmax(dy, dy_region)
         if ctx.needs_input_grad[0]:
             if ctx.ws_b is not None:
-                region = hip.absmax_regions(1, dy.device)[0]
-                hip.absmax(dy, region)
-                dx = hip.conv2d(dy, ctx.ws_b, None, c_out, c_in, k, 1, ctx.ew, region)
+                dx = hip.conv2d(dy, ctx.ws_b, None, c_out, c_in, k, 1, ctx.ew, dy_region)
             else:
                 dx = hip.conv2d_backward_data(dy, weight, x.shape[2], x.shape[3], ctx.stride)
         if ctx.needs_input_grad[1]:
-            dw = hip.conv_stem_backward_weight(x, dy) if (c_in, k) == (3, 7) else hip.conv2d_backward_weight(x, dy, k, ctx.stride)
+            if (c_in, k) == (3, 7):
+                dw = hip.conv_stem_backward_weight(x, dy)
+            elif os.environ.get("MNERF_TRAIN_WGRAD", "f16x3") == "f32":
+                dw = hip.conv2d_backward_weight(x, dy, k, ctx.stride)
+            else:
+                dw = hip.conv2d_backward_weight(x, dy, k, ctx.stride, x_region, dy_region)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None

@@ -26,6 +26,7 @@
 //     consume them.  Partial sums per chunk go to a workspace, a second kernel adds the chunks in a fixed order
 //     (bit-reproducible) and writes torch's [co][ci][ky][kx].
 #include "common.hpp"
+#include "split_f16.hpp"
 
 typedef float cb_f16 __attribute__((ext_vector_type(16)));
 
@@ -263,6 +264,97 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
+// The same decomposition on the 16-bit matrix pipe (round 6, second form): operands split into two fp16 terms with ONE power-of-two
+// gain per tensor (from the absmax regions their producers fill, common.hpp), three products per MAC, fp32 accumulation - the
+// arithmetic of the forward kernels (conv.hip).  A step is SIXTEEN positions (K = 16 per instruction: a lane holds eight
+// consecutive positions of its channel's row = 32 contiguous bytes): 27 matrix instructions of 32 cycles do what 72 exact-f32
+// instructions of 64 cycles did; the splits (~26 vector instructions per operand) are the price.  Partial sums are scaled back by
+// 2^-(ex + ed) at the store.  2^-22 relative to the tensor's largest magnitude per element: gradients whose magnitude lies more
+// than 22 binades below their tensor's maximum are lost (the forward has the same property).
+template <int K, int S>
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ x_absmax,
+                                                           const float* __restrict__ dy_absmax, float* __restrict__ part, ConvBwdGeom G, int chunks,
+                                                           int rows_per_chunk, long long n_waves) {
+  constexpr int NW = S * 7 + K;  // columns S (x + j) + kx - pad for j = 0..7, kx = 0..K-1
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (gw >= n_waves) return;
+  const int nn = lane & 31, kk = lane >> 5;
+  const int cobs = G.c_out / 32, cibs = G.c_in / 32;
+  long long t = gw;
+  const int cob = (int)(t % cobs);
+  t /= cobs;
+  const int cib = (int)(t % cibs);
+  const int chunk = (int)(t / cibs);
+  const int ex = gain_exp(mnerf_absmax_read(x_absmax)), ed = gain_exp(mnerf_absmax_read(dy_absmax));
+  const float gx = pow2i(ex), gd = pow2i(ed);
+  f32x16 acc[K][K];
+#pragma unroll
+  for (int p = 0; p < K; ++p)
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[p][q] = (f32x16)(0.0f);
+  const int row_end = min((chunk + 1) * rows_per_chunk, G.n * G.ho);
+  for (int r = chunk * rows_per_chunk; r < row_end; ++r) {
+    const int img = r / G.ho, yo = r - img * G.ho;
+    const float* arow = dy + (((size_t)img * G.c_out + cob * 32 + nn) * G.ho + yo) * G.wo;
+    const float* bplane = x + ((size_t)img * G.c_in + cib * 32 + nn) * G.h * G.w;
+    bool rowok[K];
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+      const int yi = S * yo + p - G.pad;
+      rowok[p] = yi >= 0 && yi < G.h;  // (wave-uniform)
+    }
+    float a[8], w[K][NW], an[8], wn[K][NW];
+    auto fetch = [&](int x0, float (&a_)[8], float (&w_)[K][NW]) {
+      const int xa = x0 + 8 * kk;
+      cb_window<8>(arow, xa, G.wo, a_);
+#pragma unroll
+      for (int p = 0; p < K; ++p)
+        if (rowok[p]) cb_window<NW>(bplane + (size_t)(S * yo + p - G.pad) * G.w, S * xa - G.pad, G.w, w_[p]);
+    };
+    fetch(0, a, w);
+    for (int x0 = 0; x0 < G.wo; x0 += 16) {
+      const bool more = x0 + 16 < G.wo;
+      if (more) fetch(x0 + 16, an, wn);
+      const PartsH A = split8h(a, gd);
+#pragma unroll
+      for (int p = 0; p < K; ++p) {
+        if (!rowok[p]) continue;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = w[p][S * j + q];
+          const PartsH B = split8h(v8, gx);
+          acc[p][q] = mfma16h(A.lo, B.hi, acc[p][q]);
+          acc[p][q] = mfma16h(A.hi, B.lo, acc[p][q]);
+          acc[p][q] = mfma16h(A.hi, B.hi, acc[p][q]);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = an[j];
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+#pragma unroll
+          for (int i = 0; i < NW; ++i) w[p][i] = wn[p][i];
+      }
+    }
+  }
+  const float unscale = pow2i(-(ex + ed));
+#pragma unroll
+  for (int p = 0; p < K; ++p)
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      float* dst = part + (((size_t)chunk * K * K + p * K + q) * G.c_out + cob * 32) * G.c_in + cib * 32 + nn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = 8 * (i >> 2) + 4 * kk + (i & 3);
+        dst[(size_t)m * G.c_in] = acc[p][q][i] * unscale;
+      }
+    }
+}
+
 // dW[co][ci][ky][kx] = sum over the chunks, in chunk order
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int chunks, int taps,
                                                                 int c_out, int c_in) {
@@ -449,10 +541,28 @@ extern "C" size_t mnerf_conv2d_backward_weight_workspace_bytes(int32_t n_img, in
   return (size_t)chunks * G.k * G.k * G.c_out * G.c_in * sizeof(float);
 }
 
+static int cb_wgrad_impl(const char* who, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax, float* dw,
+                         void* workspace, size_t workspace_bytes, int32_t n_img, int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in,
+                         int32_t ksize, int32_t stride, void* stream);
+
 extern "C" int mnerf_conv2d_backward_weight(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int32_t n_img,
                                             int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride,
                                             void* stream) {
-  const char* who = "mnerf_conv2d_backward_weight";
+  return cb_wgrad_impl("mnerf_conv2d_backward_weight", x, dy, nullptr, nullptr, dw, workspace, workspace_bytes, n_img, c_in, c_out, h_in, w_in,
+                       ksize, stride, stream);
+}
+
+extern "C" int mnerf_conv2d_backward_weight_f16x3(const float* x, const float* dy, const float* x_absmax, const float* dy_absmax, float* dw,
+                                                  void* workspace, size_t workspace_bytes, int32_t n_img, int32_t c_in, int32_t c_out,
+                                                  int32_t h_in, int32_t w_in, int32_t ksize, int32_t stride, void* stream) {
+  const char* who = "mnerf_conv2d_backward_weight_f16x3";
+  MNERF_REQUIRE(x_absmax && dy_absmax, MNERF_E_NULL, "%s: absmax region is NULL", who);
+  return cb_wgrad_impl(who, x, dy, x_absmax, dy_absmax, dw, workspace, workspace_bytes, n_img, c_in, c_out, h_in, w_in, ksize, stride, stream);
+}
+
+static int cb_wgrad_impl(const char* who, const float* x, const float* dy, const float* x_absmax, const float* dy_absmax, float* dw,
+                         void* workspace, size_t workspace_bytes, int32_t n_img, int32_t c_in, int32_t c_out, int32_t h_in, int32_t w_in,
+                         int32_t ksize, int32_t stride, void* stream) {
   ConvBwdGeom G;
   if (const int rc = cb_geom(who, G, n_img, c_in, c_out, h_in, w_in, ksize, stride)) return rc;
   MNERF_REQUIRE(dw, MNERF_E_NULL, "%s: dw is NULL", who);
@@ -469,7 +579,13 @@ extern "C" int mnerf_conv2d_backward_weight(const float* x, const float* dy, flo
   float* part = reinterpret_cast<float*>(workspace);
   const long long waves = (long long)chunks * (G.c_in / 32) * (G.c_out / 32);
   const dim3 grid((unsigned)((waves + 3) / 4));
-#define CB_WG(K_, S_) hipLaunchKernelGGL((conv_wgrad_kernel<K_, S_>), grid, dim3(256), 0, st, x, dy, part, G, chunks, rpc, waves)
+#define CB_WG(K_, S_)                                                                                                                       \
+  do {                                                                                                                                      \
+    if (x_absmax)                                                                                                                           \
+      hipLaunchKernelGGL((conv_wgrad16_kernel<K_, S_>), grid, dim3(256), 0, st, x, dy, x_absmax, dy_absmax, part, G, chunks, rpc, waves);   \
+    else                                                                                                                                    \
+      hipLaunchKernelGGL((conv_wgrad_kernel<K_, S_>), grid, dim3(256), 0, st, x, dy, part, G, chunks, rpc, waves);                          \
+  } while (0)
   if (ksize == 3 && stride == 1) CB_WG(3, 1);
   else if (ksize == 3) CB_WG(3, 2);
   else if (stride == 1) CB_WG(1, 1);

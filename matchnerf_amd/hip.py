@@ -29,7 +29,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_backward_weight_f16x3", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
            "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
 
@@ -202,6 +202,8 @@ def load():
     lib.mnerf_conv2d_backward_weight_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.mnerf_conv2d_backward_weight.restype = C.c_int
     lib.mnerf_conv2d_backward_weight.argtypes = [fp, fp, fp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp]
+    lib.mnerf_conv2d_backward_weight_f16x3.restype = C.c_int
+    lib.mnerf_conv2d_backward_weight_f16x3.argtypes = [fp, fp, fp, fp, fp, vp, C.c_size_t, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.mnerf_conv2d_forward_f32.restype = C.c_int
     lib.mnerf_conv2d_forward_f32.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.mnerf_conv_stem_backward_weight_workspace_bytes.restype = C.c_size_t
@@ -972,8 +974,9 @@ def conv_stem_backward_weight(x, dy, stream=None):
     return dw
 
 
-def conv2d_backward_weight(x, dy, ksize, stride, stream=None):
-    """dW of the same convolution: x [N,c_in,H,W], dy [N,c_out,Ho,Wo] -> [c_out,c_in,k,k]."""
+def conv2d_backward_weight(x, dy, ksize, stride, x_absmax=None, dy_absmax=None, stream=None):
+    """dW of the same convolution: x [N,c_in,H,W], dy [N,c_out,Ho,Wo] -> [c_out,c_in,k,k].  With the two absmax regions (max|x|,
+    max|dy|): three split-fp16 products per MAC on the 16-bit matrix pipe; without: exact-f32 matrix products."""
     import torch
     lib = load()
     _f32c(x, "x"), _f32c(dy, "dy")
@@ -985,8 +988,12 @@ def conv2d_backward_weight(x, dy, ksize, stride, stream=None):
         ws.record_stream(stream)
     dw = torch.empty(c_out, c_in, ksize, ksize, device=x.device, dtype=torch.float32)
     with _on(x.device, stream) as st:
-        check(lib.mnerf_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), ws.data_ptr(), nbytes, n, c_in, c_out, h, w, int(ksize), int(stride),
-                                               st), "mnerf_conv2d_backward_weight")
+        if x_absmax is not None and dy_absmax is not None:
+            check(lib.mnerf_conv2d_backward_weight_f16x3(_ptr(x), _ptr(dy), _ptr(x_absmax), _ptr(dy_absmax), _ptr(dw), ws.data_ptr(), nbytes, n,
+                                                         c_in, c_out, h, w, int(ksize), int(stride), st), "mnerf_conv2d_backward_weight_f16x3")
+        else:
+            check(lib.mnerf_conv2d_backward_weight(_ptr(x), _ptr(dy), _ptr(dw), ws.data_ptr(), nbytes, n, c_in, c_out, h, w, int(ksize),
+                                                   int(stride), st), "mnerf_conv2d_backward_weight")
     return dw
 
 

@@ -94,3 +94,20 @@ def test_stem_weight_gradient_matches_torch_float64(shape):
     ref = torch.nn.grad.conv2d_weight(x.double(), (64, 3, 7, 7), dy.double(), 2, 3)
     dw = hip.conv_stem_backward_weight(x.cuda(), dy.cuda()).cpu().double()
     assert (dw - ref).abs().max() <= 3e-6 * ref.abs().max(), shape
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_weight_gradient_on_the_16_bit_pipe_matches_torch_float64(case):
+    """split-fp16 operands (one gain per tensor from the absmax regions), three products per MAC: 22-bit operands"""
+    from matchnerf_amd import hip
+    n, ci, co, h, w, k, s = case
+    g = torch.Generator().manual_seed(sum(case) + 2)
+    x = (torch.randn(n, ci, h, w, generator=g) * 3.0).cuda()
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    dy = (torch.randn(n, co, ho, wo, generator=g) * 1e-4).cuda()
+    regs = hip.absmax_regions(2, x.device)
+    hip.absmax(x, regs[0]), hip.absmax(dy, regs[1])
+    ref = torch.nn.grad.conv2d_weight(x.cpu().double(), (co, ci, k, k), dy.cpu().double(), s, k // 2)
+    dw = hip.conv2d_backward_weight(x, dy, k, s, regs[0], regs[1]).cpu().double()
+    assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max(), case
+    assert torch.equal(hip.conv2d_backward_weight(x, dy, k, s, regs[0], regs[1]).cpu().double(), dw)
