@@ -204,26 +204,29 @@ class _ConvFn16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pack):
         x = x.contiguous()
-        ws_f, ws_b, ew = pack
         c_out, c_in, k, _ = weight.shape
-        region = hip.absmax_regions(1, x.device)[0]
+        # the two absmax regions of this node (max |x|, max |dy|): from the owner's per-step block if it handed one out
+        # (gmflow._train_packs: ONE zero fill per CNN forward instead of two per convolution)
+        regs = pack[3] if len(pack) > 3 and pack[3] is not None else hip.absmax_regions(2, x.device)
+        region = regs[0]
         hip.absmax(x, region)
+        ws_f, ws_b, ew = pack[:3]
         if (c_in, k) == (3, 7):
             y = hip.conv_stem(x, ws_f, ew, region)
         else:
             y = hip.conv2d(x, ws_f, None if bias is None else bias.detach(), c_in, c_out, k, int(stride), ew, region)
-        ctx.save_for_backward(x, weight, region)
+        ctx.save_for_backward(x, weight, regs)
         ctx.stride, ctx.has_bias, ctx.ws_b, ctx.ew = int(stride), bias is not None, ws_b, ew
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, x_region = ctx.saved_tensors
+        x, weight, regs = ctx.saved_tensors
+        x_region, dy_region = regs[0], regs[1]
         dy = dy.contiguous()
         c_out, c_in, k, _ = weight.shape
         dx = dw = db = None
-        dy_region = hip.absmax_regions(1, dy.device)[0]  # max |dy|: the gain of the split-fp16 operands of both gradients
-        hip.absmax(dy, dy_region)
+        hip.absmax(dy, dy_region)  # max |dy|: the gain of the split-fp16 operands of both gradients
         if ctx.needs_input_grad[0]:
             if ctx.ws_b is not None:
                 dx = hip.conv2d(dy, ctx.ws_b, None, c_out, c_in, k, 1, ctx.ew, dy_region)

@@ -63,9 +63,12 @@ def _train_packs(owner, convs, device):
         pk = getattr(owner, "_train_packer", None)
         if pk is None or pk.device != torch.device(device) or len(pk.convs) != len(convs) or any(a is not b for a, b in zip(pk.convs, convs)):
             pk = owner._train_packer = packing.ConvPacker(convs, device)
-        for c, pack in zip(convs, pk.pack()):
-            c._mnerf_train_pack = pack
+        owner._train_streams = pk.pack()
         owner._train_pack_key = key
+    # fresh (zeroed) absmax regions for this forward / backward pair: one fill for all convolutions
+    regs = hip.absmax_regions(2 * len(convs), device).reshape(len(convs), 2, -1)
+    for i, (c, st) in enumerate(zip(convs, owner._train_streams)):
+        c._mnerf_train_pack = (st[0], st[1], st[2], regs[i])
 
 
 def _conv_out(conv, x):
