@@ -93,3 +93,31 @@ def test_decoder_stream_assembled_with_torch_ops_equals_the_numpy_packer(legacy,
     ws, small, cs = dec._packed_on_device(64, torch.device("cpu"))
     assert cs == cond_stride and np.array_equal(ws.numpy().view(np.uint32), want.view(np.uint32))
     assert np.array_equal(small.numpy(), CN.pack_small(sd, 64, posenc))
+
+
+def test_conv_packer_equals_the_numpy_packers():
+    """packing.ConvPacker (training: all convolution streams from one gather) against gmflow.pack_conv / pack_conv_stem bit for
+    bit: forward streams of every shape the CNN has incl. the stem's padded matrix, and the backward stream = pack_conv of the
+    flipped, transposed filter (the data gradient of a stride-1 convolution as a convolution)."""
+    import numpy as np
+    import torch
+
+    from matchnerf_amd import gmflow, packing
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False), torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False), torch.nn.Conv2d(64, 96, 3, 2, 1),
+             torch.nn.Conv2d(96, 96, 3, 1, 1), torch.nn.Conv2d(96, 128, 1, 2), torch.nn.Conv2d(128, 128, 1, 1),
+             torch.nn.Conv2d(128, 128, 3, 1, 1)]
+    with torch.no_grad():
+        convs[3].weight.mul_(37.0)  # different exponents per tensor
+        convs[5].weight.mul_(1e-3)
+    out = packing.ConvPacker(convs, "cpu").pack()
+    n_bwd = 0
+    for c, (f, b, e) in zip(convs, out):
+        ws, ew = gmflow.pack_conv_stem(c.weight) if c.in_channels == 3 else gmflow.pack_conv(c.weight)
+        assert ew == e and np.array_equal(ws.view(np.uint32), f.numpy().view(np.uint32)), c
+        assert (b is not None) == packing.ConvPacker.has_backward_stream(c)
+        if b is not None:
+            ws2, ew2 = gmflow.pack_conv(c.weight.detach().flip(2, 3).permute(1, 0, 2, 3).contiguous())
+            assert ew2 == e and np.array_equal(ws2.view(np.uint32), b.numpy().view(np.uint32)), c
+            n_bwd += 1
+    assert n_bwd == 4
