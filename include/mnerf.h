@@ -414,6 +414,11 @@ int mnerf_instance_norm(const float* x, const float* residual, float* out, int64
 int mnerf_instance_norm_backward(const float* x, const float* dy, float* dx, int64_t planes, int64_t plane_size, float eps,
                                  int32_t relu, void* stream);
 
+/* F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) of the up-sampler's training path (superres.py:37) and its
+ * backward.  in [planes][h][w] -> out [planes][2h][2w] (+ add, same shape as out, or NULL); dout [planes][2h][2w] -> din. */
+int mnerf_upsample_bilinear2x(const float* in, const float* add, float* out, int64_t planes, int32_t h, int32_t w, void* stream);
+int mnerf_upsample_bilinear2x_backward(const float* dout, float* din, int64_t planes, int32_t h, int32_t w, void* stream);
+
 /* Convolutions of the GMFlow backbone / up-sampler (models/gmflow/backbone.py:6-122, superres.py:5-38) as implicit
  * GEMMs with fp32-grade split-fp16 products (matchnerf_amd/csrc/conv.hip).  Built: c_in a multiple of 32, c_out 64 /
  * 96 / 128, 1x1 and 3x3 filters with padding ksize/2, stride 1 / 2.

@@ -280,6 +280,23 @@ def instance_norm(x, relu=False):
     return _InstanceNormFn.apply(x, relu)
 
 
+class _UpBilinearAddFn(torch.autograd.Function):
+    """F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + left (superres.py:37) as one kernel each way"""
+
+    @staticmethod
+    def forward(ctx, right, left):
+        return hip.upsample_bilinear2x(right.contiguous(), left.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (hip.upsample_bilinear2x_backward(g) if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample_bilinear2x_add(right, left):
+    return _UpBilinearAddFn.apply(right, left)
+
+
 def ray_directions_torch(kinv, c2w, ray_idx, width, legacy):
     """target-ray directions [R,3] (un-normalised, camera.py:255-278) for pixel indices ``ray_idx`` on the GPU"""
     dev = ray_idx.device

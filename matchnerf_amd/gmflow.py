@@ -503,7 +503,10 @@ class UpSampler(nn.Module):
         left = x
         for i in range(self.n_blocks):
             left = F.leaky_relu(conv(self.conv_ls[i], F.interpolate(left, scale_factor=2.0, mode="nearest")), 0.2)
-            right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + conv(self.conv_l2rs[i + 1], left)
+            if conv is not None and _train_hip(x):
+                right = AG.upsample_bilinear2x_add(right, conv(self.conv_l2rs[i + 1], left))
+            else:
+                right = F.interpolate(right, scale_factor=2, mode="bilinear", align_corners=False) + conv(self.conv_l2rs[i + 1], left)
         return right
 
 

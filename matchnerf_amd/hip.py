@@ -29,7 +29,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_composite_backward", "mnerf_cost_volume_backward", "mnerf_decoder_backward", "mnerf_decoder_backward_workspace_bytes", "mnerf_debug_set_knob",
            "mnerf_decoder_wstream_floats", "mnerf_decoder_chunk", "mnerf_decoder_samples", "mnerf_render_workspace_bytes",
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
-           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_backward_weight_f16x3", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
+           "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_upsample_bilinear2x", "mnerf_upsample_bilinear2x_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_backward_weight_f16x3", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
            "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
 
@@ -190,6 +190,10 @@ def load():
     lib.mnerf_window_attention_images.argtypes = [fp, fp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.mnerf_instance_norm.restype = C.c_int
     lib.mnerf_instance_norm.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, i32, fp, vp]
+    lib.mnerf_upsample_bilinear2x.restype = C.c_int
+    lib.mnerf_upsample_bilinear2x.argtypes = [fp, fp, fp, i64, i32, i32, vp]
+    lib.mnerf_upsample_bilinear2x_backward.restype = C.c_int
+    lib.mnerf_upsample_bilinear2x_backward.argtypes = [fp, fp, i64, i32, i32, vp]
     lib.mnerf_instance_norm_backward.restype = C.c_int
     lib.mnerf_instance_norm_backward.argtypes = [fp, fp, fp, i64, i64, C.c_float, i32, vp]
     lib.mnerf_conv_wstream_floats.restype = i64
@@ -908,6 +912,32 @@ def absmax(x, out, stream=None):
     with _on(x.device, stream) as st:
         check(lib.mnerf_absmax(_ptr(x), x.numel(), _ptr(out), st), "mnerf_absmax")
     return out
+
+
+def upsample_bilinear2x(x, add=None, stream=None):
+    """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) (+ add): [N,C,H,W] -> [N,C,2H,2W]."""
+    import torch
+    lib = load()
+    _f32c(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    if add is not None:
+        _f32c(add, "add")
+    with _on(x.device, stream) as st:
+        check(lib.mnerf_upsample_bilinear2x(_ptr(x), _ptr(add), _ptr(out), n * c, h, w, st), "mnerf_upsample_bilinear2x")
+    return out
+
+
+def upsample_bilinear2x_backward(dout, stream=None):
+    """the adjoint: [N,C,2H,2W] -> [N,C,H,W]"""
+    import torch
+    lib = load()
+    _f32c(dout, "dout")
+    n, c, h2, w2 = dout.shape
+    din = torch.empty(n, c, h2 // 2, w2 // 2, device=dout.device, dtype=torch.float32)
+    with _on(dout.device, stream) as st:
+        check(lib.mnerf_upsample_bilinear2x_backward(_ptr(dout), _ptr(din), n * c, h2 // 2, w2 // 2, st), "mnerf_upsample_bilinear2x_backward")
+    return din
 
 
 def instance_norm_backward(x, dy, relu, eps=1e-5, stream=None):

@@ -111,3 +111,20 @@ def test_weight_gradient_on_the_16_bit_pipe_matches_torch_float64(case):
     dw = hip.conv2d_backward_weight(x, dy, k, s, regs[0], regs[1]).cpu().double()
     assert (dw - ref).abs().max() <= 1e-5 * ref.abs().max(), case
     assert torch.equal(hip.conv2d_backward_weight(x, dy, k, s, regs[0], regs[1]).cpu().double(), dw)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 7), (1, 2, 1, 4), (1, 1, 64, 80), (1, 2, 6, 1)])
+def test_bilinear_upsampling_and_its_adjoint_match_torch(shape):
+    from matchnerf_amd import hip
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    add = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g)
+    x64 = x.double().requires_grad_(True)
+    ref = F.interpolate(x64, scale_factor=2, mode="bilinear", align_corners=False) + add.double()
+    out = hip.upsample_bilinear2x(x.cuda(), add.cuda()).cpu().double()
+    assert (out - ref.detach()).abs().max() < 1e-6
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout.double())
+    din = hip.upsample_bilinear2x_backward(gout.cuda()).cpu().double()
+    assert (din - x64.grad).abs().max() < 1e-6
