@@ -210,7 +210,7 @@ extern "C" int mnerf_debug_gemm(const float* a, int64_t sa_i, int64_t sa_k, cons
   const char* who = "mnerf_debug_gemm";
   MNERF_REQUIRE(a && b && c, MNERF_E_NULL, "%s: NULL operand", who);
   MNERF_REQUIRE(I >= 1 && J >= 1 && K >= 1, MNERF_E_RANGE, "%s: I=%d J=%d K=%d", who, I, J, K);
-  MNERF_REQUIRE(mode >= 0 && mode <= 2 && (math == 0 || math == 1), MNERF_E_RANGE, "%s: mode=%d math=%d", who, mode, math);
+  MNERF_REQUIRE(mode >= 0 && mode <= 2 && math >= 0 && math <= 2, MNERF_E_RANGE, "%s: mode=%d math=%d", who, mode, math);
   gemm_with((hipStream_t)stream, a, sa_i, sa_k, b, sb_k, sb_j, c, sc_i, bias, I, J, K, mode, math);
   return mnerf_check_launch(who);
 }

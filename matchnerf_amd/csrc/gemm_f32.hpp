@@ -293,15 +293,179 @@ __global__ __launch_bounds__(256) void gemm_b6_kernel(GemmArgs g, int a_vec, int
   }
 }
 
+// ------------------------------------------------------------------ the same product with THREE products per MAC: split-fp16
+// Round 6 (the verdict's "3-product twin of gemm_b6 with per-row gains").  fp16 has 11 significand bits per term, so two terms carry
+// 22 bits and three products (lo.hi, hi.lo, hi.hi) give fp32-grade results - half the matrix instructions and two thirds of the LDS
+// traffic of the six-product split-bf16 form - but only 5 exponent bits: every A ROW and every B COLUMN of the tile gets its own
+// power-of-two gain (largest magnitude over the workgroup's K range -> [2^14, 2^15)), found by a pre-pass of the workgroup over its
+// own operands (a second read of TI x K + K x TJ values from L2; no extra launch, nothing handed over between kernels) and taken
+// out again at the store.  An element more than 22 binades below its row's largest magnitude is lost, whatever its own
+// magnitude: per-row / per-column scales of any spread are exact (tests/test_gemm_gpu.py), a row that holds 1e-9 next to 1e+3 is
+// not - the backward passes' operands (activations, gradients of one token / one channel) are not of that kind, and the
+// six-product form stays selectable (MNERF_GEMM_MATH=bf16x6).
+typedef _Float16 gemm_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gemm_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int gemm_gain_exp(float m) {  // e with m 2^e in [2^14, 2^15); 15 for m = 0
+  int e = __builtin_amdgcn_frexp_expf(m);
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return 15 - e;
+}
+__device__ __forceinline__ void gemm_split8h(const float (&v)[8], float gain, gemm_u32x4& H, gemm_u32x4& L) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const gemm_f32x2 ab = {v[2 * i] * gain, v[2 * i + 1] * gain};
+    const gemm_f16x2 h = __builtin_convertvector(ab, gemm_f16x2);
+    const gemm_f32x2 r = ab - __builtin_convertvector(h, gemm_f32x2);
+    H[i] = __builtin_bit_cast(unsigned, h);
+    L[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, gemm_f16x2));
+  }
+}
+
+template <bool A_KCONT, bool B_KCONT, int TI, int TJ>
+__global__ __launch_bounds__(256) void gemm_h3_kernel(GemmArgs g, int a_vec, int b_vec) {
+  constexpr int BI = TI / 64, BJ = TJ / 64, ITEMS = 2 * TI + 2 * TJ, NIT = ITEMS / 256;
+  static_assert(ITEMS % 256 == 0, "fetch items are dealt in rounds of 256");
+  __shared__ gemm_u32x4 S[2][2][2][TI + TJ];  // [buffer][hi | lo][k half][A rows | B rows]: 32 KiB at 128 x 128
+  __shared__ int rmax[TI + TJ], rexp[TI + TJ];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6, wi = w >> 1, wj = w & 1;
+  const int m = l & 31, kk2 = l >> 5;
+  const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
+  const int chunks = (g.K + 15) / 16, per = (chunks + gridDim.z - 1) / gridDim.z;
+  const int kb = blockIdx.z * per * 16;
+  const int ke = min(g.K, kb + per * 16);
+  float r[NIT][8];
+  auto fetch1 = [&](float (&v)[8], const float* base, long long s_row, long long s_k, int row, int n_rows, int k, bool kcont, int vec) {
+    const float* p = base + (long long)row * s_row + (long long)k * s_k;
+    if (row < n_rows && k + 8 <= ke) {
+      if (kcont && vec) {
+        const float4 u = *reinterpret_cast<const float4*>(p), x = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w, v[4] = x.x, v[5] = x.y, v[6] = x.z, v[7] = x.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[q * s_k];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = (row < n_rows && k + q < ke) ? p[q * s_k] : 0.0f;
+    }
+  };
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+      const int it = t + 256 * n;
+      if (it < 2 * TI)
+        fetch1(r[n], g.a, g.sa_i, g.sa_k, i0 + it % TI, g.I, k0 + 8 * (it / TI), A_KCONT, a_vec);
+      else
+        fetch1(r[n], g.b, g.sb_j, g.sb_k, j0 + (it - 2 * TI) % TJ, g.J, k0 + 8 * ((it - 2 * TI) / TJ), B_KCONT, b_vec);
+    }
+  };
+  auto slot_of = [&](int n) {
+    const int it = t + 256 * n;
+    return it < 2 * TI ? it % TI : TI + (it - 2 * TI) % TJ;
+  };
+  // ---- pre-pass: largest magnitude of every A row / B column of the tile over this workgroup's K range
+  for (int q = t; q < TI + TJ; q += 256) rmax[q] = 0;
+  float mx[NIT];
+#pragma unroll
+  for (int n = 0; n < NIT; ++n) mx[n] = 0.0f;
+  for (int k0 = kb; k0 < ke; k0 += 16) {
+    fetch(k0);
+#pragma unroll
+    for (int n = 0; n < NIT; ++n)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mx[n] = fmaxf(mx[n], fabsf(r[n][q]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NIT; ++n) atomicMax(&rmax[slot_of(n)], __float_as_int(mx[n]));  // (non-negative floats order as integers)
+  __syncthreads();
+  for (int q = t; q < TI + TJ; q += 256) rexp[q] = gemm_gain_exp(__int_as_float(rmax[q]));
+  float gain[NIT];
+#pragma unroll
+  for (int n = 0; n < NIT; ++n) gain[n] = ldexpf(1.0f, gemm_gain_exp(__int_as_float(rmax[slot_of(n)])));
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+      const int it = t + 256 * n;
+      const int kh = it < 2 * TI ? it / TI : (it - 2 * TI) / TJ;
+      gemm_u32x4 H, L;
+      gemm_split8h(r[n], gain[n], H, L);
+      S[buf][0][kh][slot_of(n)] = H, S[buf][1][kh][slot_of(n)] = L;
+    }
+  };
+  f32x16 acc[BI][BJ];
+#pragma unroll
+  for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < BJ; ++bj) acc[bi][bj] = (f32x16)(0.0f);
+  if (kb < ke) {
+    fetch(kb);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kb; k0 < ke; k0 += 16, buf ^= 1) {
+    const bool more = k0 + 16 < ke;
+    if (more) fetch(k0 + 16);  // in flight during the matrix instructions below
+    gemm_f16x8 a[BI][2], b[BJ][2];
+#pragma unroll
+    for (int term = 0; term < 2; ++term) {
+#pragma unroll
+      for (int q = 0; q < BI; ++q) a[q][term] = __builtin_bit_cast(gemm_f16x8, S[buf][term][kk2][wi * (TI / 2) + q * 32 + m]);
+#pragma unroll
+      for (int q = 0; q < BJ; ++q) b[q][term] = __builtin_bit_cast(gemm_f16x8, S[buf][term][kk2][TI + wj * (TJ / 2) + q * 32 + m]);
+    }
+    constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};  // lo.hi, hi.lo, hi.hi
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < BJ; ++bj)
+          acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[bi][TA[p]], b[bj][TB[p]], acc[bi][bj], 0, 0, 0);
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int bj = 0; bj < BJ; ++bj) {
+    const int js = wj * (TJ / 2) + bj * 32 + m;
+    const int j = j0 + js;
+    if (j >= g.J) continue;
+    const int ej = rexp[TI + js];
+    const float bias_j = (g.bias && blockIdx.z == 0) ? g.bias[j] : 0.0f;
+#pragma unroll
+    for (int bi = 0; bi < BI; ++bi)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int is = wi * (TI / 2) + bi * 32 + 8 * (rr >> 2) + kk2 * 4 + (rr & 3);
+        const int i = i0 + is;
+        if (i >= g.I) continue;
+        float* p = g.c + (long long)i * g.sc_i + j;
+        const float v = ldexpf(acc[bi][bj][rr], -(rexp[is] + ej)) + bias_j;
+        if (g.mode == 0) *p = v;
+        else if (g.mode == 1) *p += v;
+        else atomicAdd(p, v);
+      }
+  }
+}
+
 #ifndef MNERF_GEMM_TILE128
 #define MNERF_GEMM_TILE128 1  // 0: every product through the 64 x 64 kernel (round 3)
 #endif
-// MNERF_GEMM_MATH (environment, read once): "bf16x6" (default) = split-bf16 on the 16-bit matrix pipe for 128-tile products,
-// "f32" = the exact-f32 matrix instruction everywhere
-static int gemm_math_b6() {
+#ifndef MNERF_GEMM_DEFAULT_MATH
+#define MNERF_GEMM_DEFAULT_MATH 1
+#endif
+// MNERF_GEMM_MATH (environment, read once): "bf16x6" (default) = split-bf16, "f16x3" = split-fp16 with row gains (round 6: half the
+// matrix instructions, but its pre-pass reads the operands a second time and these products are bound by operand fetch and split,
+// not by the matrix pipe: 35.6 against 34.5 ms per training iteration - kept selectable and tested, not the default), both on the
+// 16-bit matrix pipe for products with I, J >= 128; "f32" = the exact-f32 matrix instruction everywhere
+static int gemm_math_b6() {  // 0: exact f32, 1: split-bf16 (six products), 2: split-fp16 with row gains (three products)
   static const int v = [] {
     const char* e = getenv("MNERF_GEMM_MATH");
-    return (e && !strcmp(e, "f32")) ? 0 : 1;
+    if (e && !strcmp(e, "f32")) return 0;
+    if (e && !strcmp(e, "bf16x6")) return 1;
+    if (e && !strcmp(e, "f16x3")) return 2;
+    return MNERF_GEMM_DEFAULT_MATH;
   }();
   return v;
 }
@@ -328,7 +492,10 @@ static void gemm_with(hipStream_t st, const float* a, long long sa_i, long long 
     const int b_vec = bk && sb_j % 4 == 0 && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
 #define GEMM_B6_LAUNCH(AK_, BK_)                                                                                              \
   do {                                                                                                                        \
-    if (T == 128) hipLaunchKernelGGL((gemm_b6_kernel<AK_, BK_, 128, 128>), grid, dim3(256), 0, st, g, a_vec, b_vec);           \
+    if (math_b6 == 2) {                                                                                                       \
+      if (T == 128) hipLaunchKernelGGL((gemm_h3_kernel<AK_, BK_, 128, 128>), grid, dim3(256), 0, st, g, a_vec, b_vec);         \
+      else hipLaunchKernelGGL((gemm_h3_kernel<AK_, BK_, 64, 64>), grid, dim3(256), 0, st, g, a_vec, b_vec);                     \
+    } else if (T == 128) hipLaunchKernelGGL((gemm_b6_kernel<AK_, BK_, 128, 128>), grid, dim3(256), 0, st, g, a_vec, b_vec);    \
     else hipLaunchKernelGGL((gemm_b6_kernel<AK_, BK_, 64, 64>), grid, dim3(256), 0, st, g, a_vec, b_vec);                       \
   } while (0)
     if (ak && bk) GEMM_B6_LAUNCH(true, true);

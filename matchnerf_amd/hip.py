@@ -850,7 +850,7 @@ def qkv_backward(w_q, w_k, w_v, x_q, x_kv, g_q, g_k, g_v, gw_q=None, gw_k=None, 
 
 def debug_gemm(a, b, bias=None, out=None, mode=0, math="bf16x6", stream=None):
     """Test hook (mnerf_debug_gemm): C (mode 0: =, 1: +=, 2: atomic +=) a @ b (+ bias) for 2-D fp32 tensors of ANY strides (views and
-    transposes go through as they are); ``math``: "bf16x6" (the library's default for 128-tile products) or "f32"."""
+    transposes go through as they are); ``math``: "bf16x6" (the library's default for products with I, J >= 128), "f16x3" (split-fp16 with row gains, round 6: selectable with MNERF_GEMM_MATH) or "f32"."""
     import torch
     lib = load()
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0] or a.dtype != torch.float32 or b.dtype != torch.float32:
@@ -867,7 +867,7 @@ def debug_gemm(a, b, bias=None, out=None, mode=0, math="bf16x6", stream=None):
                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     with _on(a.device, stream) as st:
         check(fn(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1), out.data_ptr(), out.stride(0),
-                 _ptr(bias), I, J, K, int(mode), {"f32": 0, "bf16x6": 1}[math], st), "mnerf_debug_gemm")
+                 _ptr(bias), I, J, K, int(mode), {"f32": 0, "bf16x6": 1, "f16x3": 2}[math], st), "mnerf_debug_gemm")
     return out
 
 

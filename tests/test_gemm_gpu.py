@@ -85,3 +85,42 @@ def test_small_products_keep_the_exact_f32_kernel():
     """below 128 x 128 the 64-tile exact-f32 kernel runs whatever the math argument says: identical bits"""
     a, b = operands(100, 64, 200, "nt", seed=2)
     assert torch.equal(hip.debug_gemm(a, b, math="bf16x6"), hip.debug_gemm(a, b, math="f32"))
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("shape", [(256, 128, 512), (300, 130, 77), (128, 640, 1281), (1280, 128, 128), (4096, 2048, 72), (4000, 2100, 40)])
+def test_split_fp16_gemm_with_row_gains_is_fp32_grade(layout, shape):
+    """round 6: three fp16 products per MAC, one power-of-two gain per A row / B column of the tile (gemm_h3_kernel)"""
+    I, J, K = shape
+    a, b = operands(I, J, K, layout, seed=I + K + 1)
+    ref = a.double() @ b.double()
+    c3 = hip.debug_gemm(a, b, math="f16x3")
+    e3, e32 = rel_err(c3, ref), rel_err(hip.debug_gemm(a, b, math="f32"), ref)
+    assert e3 < 4e-6 and e3 < 8 * e32 + 2e-7, (e3, e32)
+
+
+def test_split_fp16_gemm_row_and_column_scales_over_forty_binades():
+    """the case a one-gain-per-tensor fp16 split fails (test_magnitudes_spread_over_forty_binades): per-row / per-column gains
+    make it exact in the scales; every output element against ITS OWN magnitude scale"""
+    I, J, K = 256, 256, 384
+    a, b = operands(I, J, K, "nt", seed=6, spread=20)
+    ref = a.double() @ b.double()
+    scale = a.double().abs().amax(1, keepdim=True) * b.double().abs().amax(0, keepdim=True) * K ** 0.5
+    e3 = float(((hip.debug_gemm(a, b, math="f16x3").double() - ref).abs() / scale).max())
+    e32 = float(((hip.debug_gemm(a, b, math="f32").double() - ref).abs() / scale).max())
+    assert e3 < 1e-6 and e3 < 8 * e32 + 1e-8, (e3, e32)
+
+
+def test_split_fp16_gemm_modes_and_zero_rows():
+    I, J, K = 384, 256, 4096
+    a, b = operands(I, J, K, "nn", seed=12)
+    a[5] = 0.0  # an all-zero row: gain of a zero maximum
+    b[:, 7] = 0.0
+    ref = a.double() @ b.double()
+    bias = torch.randn(J, device="cuda")
+    assert rel_err(hip.debug_gemm(a, b, bias=bias, math="f16x3"), ref + bias.double()) < 4e-6
+    base = torch.randn(I, J, device="cuda")
+    assert rel_err(hip.debug_gemm(a, b, out=base.clone(), mode=1, math="f16x3"), ref + base.double()) < 4e-6
+    assert rel_err(hip.debug_gemm(a, b, out=base.clone(), mode=2, math="f16x3"), ref + base.double()) < 4e-6
+    c = hip.debug_gemm(a, b, math="f16x3")
+    assert float(c[5].abs().max()) == 0.0 and float(c[:, 7].abs().max()) == 0.0
