@@ -378,10 +378,12 @@ int mnerf_window_attention_images(const float* q, float* out, int32_t batch, int
 /* K6 backward — gradients of the (shifted-)window attention (what `loss.backward()` does to
  * models/gmflow/transformer.py:46-105 in coach.py:215-243), flash style: the [windows, L_w, L_w] score tensor is never
  * materialised.  q, k, v, out (the forward's result), g_out (gradient of `out`): [batch, h*w, 128] fp32; g_q, g_k, g_v
- * (same shape) are OVERWRITTEN.  fp32-grade matrix products (split-bf16: three bf16 terms per operand, six term products; MNERF_WA_BWD_MATH=f32:
- * the exact-f32 matrix instruction), no atomics (deterministic).  `workspace`: at least
- * mnerf_window_attention_backward_workspace_bytes(batch, h, w) bytes (three floats per token: row maximum, row sum of
- * exponentials, <g_out, out>). */
+ * (same shape) are OVERWRITTEN.  fp32-grade matrix products (MNERF_WA_BWD_MATH = "f16x3", the default: two fp16 terms per operand with
+ * power-of-two gains from the tensors' maxima, three term products; "bf16x6": three bf16 terms, six term products; "f32": the
+ * exact-f32 matrix instruction), deterministic (the only atomics are the maxima of the f16x3 form's gains).  `out` must be the
+ * forward's result for these q, k, v (the f16x3 gains bound <g_out, out> by the maxima of g_out and v).  `workspace`: at least
+ * mnerf_window_attention_backward_workspace_bytes(batch, h, w) bytes (four floats per token: row maximum, row sum of
+ * exponentials, <g_out, out>, |g_out|^2; + the four operand maxima). */
 int64_t mnerf_window_attention_backward_workspace_bytes(int32_t batch, int32_t h, int32_t w);
 int mnerf_window_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* g_out,
                                     float* g_q, float* g_k, float* g_v, int32_t batch, int32_t h, int32_t w,

@@ -72,7 +72,7 @@ def _forward_stats():
 class _WindowAttentionFn(torch.autograd.Function):
     """HIP forward (the inference kernel, publishing the softmax's row statistics) and HIP backward
     (mnerf_window_attention_backward_stats: flash style, the [windows, L_w, L_w] score tensor is never built; fp32-grade
-    split-bf16 products or, MNERF_WA_BWD_MATH=f32, exact fp32; deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
+    split-fp16 products (MNERF_WA_BWD_MATH: f16x3 default, bf16x6, or exact f32); deterministic).  MNERF_WA_BACKWARD=torch keeps the round 1-3
     form for comparison: re-evaluation of the op chain with torch ops under autograd (``_window_attention_torch``)."""
 
     @staticmethod

@@ -19,10 +19,10 @@
 //   wa_bwd_dkv_kernel  one workgroup per (window, 64-key tile): loops over the query tiles with S = Q K^T (lane = key,
 //                      registers = queries), so that P and dS in their accumulators are the B operands of
 //                      dV^T = dO^T P and dK^T = Q^T dS.
-// Two forms of the two kernels (MNERF_WA_BWD_MATH): the split-bf16 one further down (default: three bf16 terms per operand, six
-// term products, fp32-grade on the 16-bit matrix instruction) and this one, where every product is exact fp32 on
-// v_mfma_f32_32x32x2_f32; its tiles are staged in LDS channel-major ([channel][row], row stride 65 floats: conflict-free for both
-// operand roles).
+// Three forms of the two kernels (MNERF_WA_BWD_MATH): the split 16-bit ones further down — "f16x3" (two range-managed fp16 terms
+// per operand, three term products) and "bf16x6" (three bf16 terms, six term products), both fp32-grade on the 16-bit matrix
+// instructions — and this one ("f32"), where every product is exact fp32 on v_mfma_f32_32x32x2_f32; its tiles are staged in LDS
+// channel-major ([channel][row], row stride 65 floats: conflict-free for both operand roles).
 // Roll, window split / merge and the wrap-region mask are index arithmetic (wa_common.hpp: win_token), as in the forward.
 // No atomics: every output row is written by exactly one workgroup; results are deterministic.
 #include <stdlib.h>
@@ -39,18 +39,22 @@ __device__ __forceinline__ int wb_row(int r, int half) { return (r & 3) + 8 * (r
 
 __device__ __forceinline__ f32x16 wb_mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
-// D[token] = <dO[token], O[token]>
+// D[token] = <dO[token], O[token]>;  n2[token] = ||dO[token]||^2 (if n2: the f16x3 form's per-query gain)
 __global__ __launch_bounds__(256) void wa_bwd_rowdot_kernel(const float* __restrict__ g_out, const float* __restrict__ out,
-                                                            float* __restrict__ d, long long n_tokens) {
+                                                            float* __restrict__ d, float* __restrict__ n2, long long n_tokens) {
   const long long tok = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);  // 32 lanes per token, 4 channels per lane
   if (tok >= n_tokens) return;
   const int c4 = threadIdx.x & 31;
   const float4 a = reinterpret_cast<const float4*>(g_out + tok * WA_C)[c4];
   const float4 b = reinterpret_cast<const float4*>(out + tok * WA_C)[c4];
   float s = (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  float t = (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (c4 == 0) d[tok] = s;
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64), t += __shfl_xor(t, off, 64);
+  if (c4 == 0) {
+    d[tok] = s;
+    if (n2) n2[tok] = t;
+  }
 }
 
 // A tile = 64 rows (window-local indices i0 .. i0+63 of window (wy, wx)) x 128 channels, staged in LDS as [channel][row]; rows
@@ -133,6 +137,8 @@ struct WaBwdArgs {
   float *g_q, *g_k, *g_v;
   float *row_m, *row_l;   // [batch * h * w] row statistics (log2 domain maximum, sum of exponentials)
   const float* row_d;     // [batch * h * w] <dO, O>
+  const float* row_n2;    // [batch * h * w] ||dO||^2                                   (f16x3 form)
+  const unsigned* absmax; // bit patterns of max|q|, max|k|, max|v|, max|dO|            (f16x3 form)
   WinGeom G;
   int do_shift;
   float scale;            // 1 / sqrt(C)
@@ -394,35 +400,49 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_kernel(WaBwdArgs A) {
 }
 
 
-// ================================================================================================================ split-bf16 form
-// The same two kernels with every product on the 16-bit matrix instruction: each fp32 operand element as three bf16 terms (exact:
-// 3 x 8 significand bits), a product from the six term products that are not below 2^-24 of it, fp32 accumulation — the scheme of
-// gemm_b6_kernel (gemm_f32.hpp) and of the decoder's "bf16x6" path: fp32-grade gradients (the tests judge both forms against
-// float64 with one gate) at 2.7 x the matrix rate of v_mfma_f32_32x32x2_f32, with fp32's exponent range (no gains to manage).
+// ========================================================================================================= split 16-bit forms
+// The same two kernels with every product on the 16-bit matrix instructions, in two flavours of one template (NT = terms per
+// operand element):
+//   NT = 3  "bf16x6"  three bf16 terms per fp32 element (exact: 3 x 8 significand bits), a product from the six term products that
+//           are not below 2^-24 of it, fp32 accumulation — the scheme of gemm_b6_kernel (gemm_f32.hpp): fp32's exponent range, no
+//           gains to manage, 2.7 x the matrix rate of v_mfma_f32_32x32x2_f32.
+//   NT = 2  "f16x3"   two fp16 terms per element (22 significand bits), three term products hi.lo + lo.hi + hi.hi (the dropped
+//           lo.lo is below 2^-22 of the product) — the forward's and the decoder's scheme (split_f16.hpp): HALF the matrix
+//           instructions and about half the split arithmetic of bf16x6.  fp16 has a 5-bit exponent, so every operand carries an
+//           exact power-of-two gain:
+//             q, k, v, dO   one gain per TENSOR from its absolute maximum (wa_bwd_absmax4_kernel -> 4 words in the workspace, read
+//                           by every workgroup: max * gain in [2^14, 2^15)); hi + lo then represent an element to
+//                           max(2^-22 relative, 2^-39 of the tensor's maximum);
+//             P             2^15 (P <= 1);
+//             dS (dK pass)  |dS_ij| <= P_ij (|<dO_i, V_j>| + |<dO_i, O_i>|) <= 2 * 128 * max|dO| * max|V|: in gained units below 2^38,
+//                           so 2^-23 puts it below 2^15 whatever the data;
+//             dQ pass       the query is the LANE (a column of every B operand it supplies), so gains per query are free: its dO
+//                           row takes 2^(15 - e_i) with ||dO_i|| < 2^e_i (wa_bwd_rowdot_kernel publishes the norms) — a row 2^-24
+//                           below the tensor's maximum keeps its 22 bits — and dS^T a constant 2^-20:
+//                           |dS_ij| <= 2 ||dO_i|| sqrt(128) max|V| < 2^34.5 in gained units; folded into 1 / l_i.
+//           The accumulators hold gained results; every gain is a power of two and is multiplied back in exactly.
 //
 // Geometry.  A workgroup owns 128 STATIONARY rows (dK/dV kernel: keys, dQ kernel: queries), one 32-row block per wave, and loops
 // over 32-row STREAMING tiles of the other side.  Lane (n, half) of a 16-bit matrix instruction supplies 8 consecutive k of row /
 // column n, so an operand must be stored k-contiguous, and the backward needs the streaming tiles in BOTH orientations:
-//   role 1  [row][channel]  k = channels:  S = Q K^T, dP = dO V^T           -> R1: [term][32 rows][128 ch] bf16, row stride 272 B
+//   role 1  [row][channel]  k = channels:  S = Q K^T, dP = dO V^T           -> R1: [term][32 rows][128 ch] 16-bit, row stride 272 B
 //   role 2  [channel][row]  k = rows:      dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T
-//                                                                           -> R2: [term][128 ch][32 rows] bf16, row stride 80 B
+//                                                                           -> R2: [term][128 ch][32 rows] 16-bit, row stride 80 B
 // (strides chosen so that the 16 lanes of a ds_read_b128 group fall into distinct banks).  Role 2 stores the rows PERMUTED: the B
 // operand of those products is P / dS straight out of its accumulator registers — register r of lane (n, half) is row
 // f(r, half) = (r & 3) + 8 (r >> 2) + 4 half — so K16-step s of lane half h pairs slot j with row 16 s + 8 (j >> 2) + 4 h + (j & 3),
 // and position 16 s + 8 h + j of an R2 line holds exactly that row: one ds_read_b128 per fragment.
-// The stationary rows never touch LDS: each wave keeps the 8 K16-steps x 3 terms of its own 32 rows (x 2 tensors) in 192 registers
+// The stationary rows never touch LDS: each wave keeps the 8 K16-steps x NT terms of its own 32 rows (x 2 tensors) in registers
 // (one wave per SIMD, 512 registers), read from global memory once.  A streaming tile is fetched into registers one iteration ahead
 // (thread (row, 8-channel chunk): role 1's own shape), split and stored as R1, staged as fp32 [row][132] for the transposition, and
 // re-read by thread (channel, 16 rows) in permuted order to be split and stored as R2.
 // No cross-wave reduction, no atomics: a wave owns its 32 rows of the result; results are deterministic.
 #define WB6_R 128                // stationary rows per workgroup
 #define WB6_T 32                 // rows of a streaming tile
-#define WB6_R1_ROW 272           // bytes of an R1 row (128 bf16 + 16 pad)
+#define WB6_R1_ROW 272           // bytes of an R1 row (128 x 16 bit + 16 pad)
 #define WB6_R1_TERM (WB6_T * WB6_R1_ROW)
-#define WB6_R1_BYTES (3 * WB6_R1_TERM)
-#define WB6_R2_ROW 80            // bytes of an R2 line (32 bf16 + 16 pad)
+#define WB6_R2_ROW 80            // bytes of an R2 line (32 x 16 bit + 16 pad)
 #define WB6_R2_TERM (WA_C * WB6_R2_ROW)
-#define WB6_R2_BYTES (3 * WB6_R2_TERM)
 #define WB6_ST_LD 132            // floats per row of the fp32 staging tile
 #define WB6_ST_BYTES (WB6_T * WB6_ST_LD * 4)
 
@@ -434,46 +454,97 @@ __device__ __forceinline__ unsigned wb6_pk(float a, float b) {  // v_cvt_pk_bf16
   const wb6_f32x2 v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wb6_bf16x2));
 }
-struct Wb6Frag {
-  u32x4 t[3];  // hi | mid | lo: 8 bf16 each
+template <int NT>
+struct WbsFrag {
+  u32x4 t[NT];  // NT = 3: hi | mid | lo, 8 bf16 each;  NT = 2: hi | lo, 8 fp16 each
 };
-__device__ __forceinline__ Wb6Frag wb6_split8(const float (&v)[8]) {
-  Wb6Frag f;
+// 8 values -> their terms.  mult: the operand's power-of-two gain (NT = 2 only; bf16 has fp32's exponent range)
+template <int NT>
+__device__ __forceinline__ WbsFrag<NT> wbs_split8(const float (&v)[8], float mult) {
+  WbsFrag<NT> f;
+  if constexpr (NT == 3) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i], b = v[2 * i + 1];
-    const unsigned h = wb6_pk(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    const unsigned m = wb6_pk(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    f.t[0][i] = h;
-    f.t[1][i] = m;
-    f.t[2][i] = wb6_pk(sa, sb);
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[2 * i], b = v[2 * i + 1];
+      const unsigned h = wb6_pk(a, b);
+      const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+      const unsigned m = wb6_pk(ra, rb);
+      const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+      f.t[0][i] = h;
+      f.t[1][i] = m;
+      f.t[2][i] = wb6_pk(sa, sb);
+    }
+  } else {
+    const PartsH p = split8h(v, mult);
+    f.t[0] = __builtin_bit_cast(u32x4, p.hi);
+    f.t[1] = __builtin_bit_cast(u32x4, p.lo);
   }
   return f;
 }
-// acc += A . B from the six term products, smallest first
-__device__ __forceinline__ f32x16 wb6_mfma6(const Wb6Frag& a, const Wb6Frag& b, f32x16 acc) {
+// acc += A . B from the term products that matter, smallest first
+#ifndef WBS_EXP
+#define WBS_EXP 0  // removal experiments (wrong results, meaningful times): tools/exp/wa_bwd_removal.sh
+#endif
+template <int NT>
+__device__ __forceinline__ f32x16 wbs_mfma(const WbsFrag<NT>& a, const WbsFrag<NT>& b, f32x16 acc) {
+  if (WBS_EXP == 1) return acc;
+  if constexpr (NT == 3) {
 #define WB6_P(TA_, TB_) \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wb6_bf16x8, a.t[TA_]), __builtin_bit_cast(wb6_bf16x8, b.t[TB_]), acc, 0, 0, 0)
-  WB6_P(2, 0);
-  WB6_P(0, 2);
-  WB6_P(1, 1);
-  WB6_P(1, 0);
-  WB6_P(0, 1);
-  WB6_P(0, 0);
+    WB6_P(2, 0);
+    WB6_P(0, 2);
+    WB6_P(1, 1);
+    WB6_P(1, 0);
+    WB6_P(0, 1);
+    WB6_P(0, 0);
 #undef WB6_P
+  } else {
+#define WB6_P(TA_, TB_) acc = mfma16h(__builtin_bit_cast(f16x8, a.t[TA_]), __builtin_bit_cast(f16x8, b.t[TB_]), acc)
+    WB6_P(1, 0);
+    WB6_P(0, 1);
+    WB6_P(0, 0);
+#undef WB6_P
+  }
   return acc;
 }
-__device__ __forceinline__ Wb6Frag wb6_lds_frag(const unsigned char* base, int term_stride) {
-  Wb6Frag f;
+template <int NT>
+__device__ __forceinline__ WbsFrag<NT> wbs_lds_frag(const unsigned char* base, int term_stride) {
+  WbsFrag<NT> f;
 #pragma unroll
-  for (int t = 0; t < 3; ++t) f.t[t] = *reinterpret_cast<const u32x4*>(base + t * term_stride);
+  for (int t = 0; t < NT; ++t) f.t[t] = *reinterpret_cast<const u32x4*>(base + t * term_stride);
   return f;
+}
+template <int NT>
+__device__ __forceinline__ void wbs_pin(WbsFrag<NT>& f) {
+  if constexpr (NT == 3) asm volatile("" : "+v"(f.t[0]), "+v"(f.t[1]), "+v"(f.t[2]));
+  else asm volatile("" : "+v"(f.t[0]), "+v"(f.t[1]));
+}
+
+// ---- the gains of the f16x3 flavour
+// gain of a tensor from the bit pattern of its absolute maximum: max * gain in [2^14, 2^15) (2^15 for an all-zero tensor)
+__device__ __forceinline__ float wbs_tensor_gain(unsigned absmax_bits) { return pow2i(gain_exp(__uint_as_float(absmax_bits))); }
+#define WBS_P_GAIN 32768.0f               // P <= 1 (+ a rounding) -> below 2^15 + 1
+#define WBS_DS_GAIN 1.1920928955078125e-7f  // 2^-23: gained dS of the dK pass, below 2^38, -> below 2^15
+// absolute maxima of the four operand tensors as bit patterns (non-negative floats order like unsigned integers), out[4] zeroed
+// by the caller.  A maximum is the same in any order: deterministic with atomics.
+__global__ __launch_bounds__(256) void wa_bwd_absmax4_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, const float* __restrict__ g_out,
+                                                             long long n_float4, unsigned* __restrict__ out) {
+  const float* src = blockIdx.y == 0 ? q : blockIdx.y == 1 ? k : blockIdx.y == 2 ? v : g_out;
+  unsigned m = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_float4; i += (long long)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(src)[i];
+    m = max(max(m, __float_as_uint(x.x) & 0x7fffffffu), max(__float_as_uint(x.y) & 0x7fffffffu, __float_as_uint(x.z) & 0x7fffffffu));
+    m = max(m, __float_as_uint(x.w) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out + blockIdx.y, m);
 }
 
 // the 8 K16-steps of one stationary row (window-local index li; zero beyond the window): lane (n, half) holds channels 16 u + 8 half ..
-__device__ __forceinline__ void wb6_stationary(Wb6Frag (&f)[8], const float* __restrict__ src_seq, int tok, int half) {
+template <int NT>
+__device__ __forceinline__ void wbs_stationary(WbsFrag<NT> (&f)[8], const float* __restrict__ src_seq, int tok, int half, float mult) {
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -482,7 +553,7 @@ __device__ __forceinline__ void wb6_stationary(Wb6Frag (&f)[8], const float* __r
       const float4 b = reinterpret_cast<const float4*>(src_seq + (size_t)tok * WA_C + 16 * u + 8 * half)[1];
       v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
     }
-    f[u] = wb6_split8(v);
+    f[u] = wbs_split8<NT>(v, mult);
   }
 }
 
@@ -494,6 +565,7 @@ __device__ __forceinline__ void wb6_fetch(Wb6TileRegs& r, const float* __restric
                                           int tid) {
   const int li = i0 + (tid >> 3), c = tid & 7;
   r.v[0] = r.v[1] = r.v[2] = r.v[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WBS_EXP == 5) return;
   if (li < G.Lw) {
     int region;
     const int tok = win_token(G, wy, wx, li, region);
@@ -501,17 +573,19 @@ __device__ __forceinline__ void wb6_fetch(Wb6TileRegs& r, const float* __restric
     r.v[0] = p[2 * c], r.v[1] = p[2 * c + 1], r.v[2] = p[2 * (c + 8)], r.v[3] = p[2 * (c + 8) + 1];
   }
 }
-// registers -> R1 (split) and, if st, the fp32 staging tile
-__device__ __forceinline__ void wb6_store_r1(unsigned char* r1, float* st, const Wb6TileRegs& r, int tid) {
+// registers -> R1 (split) and, if st, the fp32 staging tile (raw values: the gain is applied where they are split)
+template <int NT>
+__device__ __forceinline__ void wbs_store_r1(unsigned char* r1, float* st, const Wb6TileRegs& r, int tid, float mult) {
+  if (WBS_EXP == 3) return;
   const int row = tid >> 3, c = tid & 7;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const float4 a = r.v[2 * q], b = r.v[2 * q + 1];
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const Wb6Frag f = wb6_split8(v);
+    const WbsFrag<NT> f = wbs_split8<NT>(v, mult);
     const int ch0 = 8 * (c + 8 * q);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(r1 + t * WB6_R1_TERM + row * WB6_R1_ROW + ch0 * 2) = f.t[t];
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(r1 + t * WB6_R1_TERM + row * WB6_R1_ROW + ch0 * 2) = f.t[t];
     if (st) {
       *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0) = a;
       *reinterpret_cast<float4*>(st + row * WB6_ST_LD + ch0 + 4) = b;
@@ -529,56 +603,61 @@ __device__ __forceinline__ void wb6_store_staging(float* st, const Wb6TileRegs& 
   }
 }
 // staging tile -> R2: thread t -> channel t & 127, K16-step t >> 7; both lane halves' fragments of that step
-__device__ __forceinline__ void wb6_build_r2(unsigned char* r2, const float* st, int tid) {
+template <int NT>
+__device__ __forceinline__ void wbs_build_r2(unsigned char* r2, const float* st, int tid, float mult) {
+  if (WBS_EXP == 2) return;
   const int ch = tid & 127, s = tid >> 7;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = st[(16 * s + 8 * (j >> 2) + 4 * h + (j & 3)) * WB6_ST_LD + ch];
-    const Wb6Frag f = wb6_split8(v);
+    const WbsFrag<NT> f = wbs_split8<NT>(v, mult);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(r2 + t * WB6_R2_TERM + ch * WB6_R2_ROW + (16 * s + 8 * h) * 2) = f.t[t];
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<u32x4*>(r2 + t * WB6_R2_TERM + ch * WB6_R2_ROW + (16 * s + 8 * h) * 2) = f.t[t];
   }
 }
 // S-type product: acc[rows = the tile's 32 rows][cols = this wave's stationary rows] over the 128 channels.  The fragments of
-// step u + 1 are requested before the six matrix instructions of step u (one wave per SIMD: nothing else hides an LDS round trip).
-__device__ __forceinline__ f32x16 wb6_tile_product(const unsigned char* r1, const Wb6Frag (&stat)[8], int n, int half) {
+// step u + 1 are requested before the matrix instructions of step u (one wave per SIMD: nothing else hides an LDS round trip).
+template <int NT>
+__device__ __forceinline__ f32x16 wbs_tile_product(const unsigned char* r1, const WbsFrag<NT> (&stat)[8], int n, int half) {
   f32x16 acc = (f32x16)(0.0f);
   const unsigned char* base = r1 + n * WB6_R1_ROW + 16 * half;
-  Wb6Frag cur = wb6_lds_frag(base, WB6_R1_TERM);
+  WbsFrag<NT> cur = wbs_lds_frag<NT>(base, WB6_R1_TERM);
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    Wb6Frag nxt = cur;
-    if (u + 1 < 8) nxt = wb6_lds_frag(base + 32 * (u + 1), WB6_R1_TERM);
+    WbsFrag<NT> nxt = cur;
+    if (u + 1 < 8) nxt = wbs_lds_frag<NT>(base + 32 * (u + 1), WB6_R1_TERM);
     __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks the reads to their use: read, wait, multiply, read, wait ...)
-    asm volatile("" : "+v"(cur.t[0]), "+v"(cur.t[1]), "+v"(cur.t[2]));
-    acc = wb6_mfma6(cur, stat[u], acc);
+    wbs_pin<NT>(cur);
+    acc = wbs_mfma<NT>(cur, stat[u], acc);
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
   }
   return acc;
 }
 // chain product: out^T[channel][col] += sum over the tile's 32 rows X^T[channel][row] s[row][col], s = accumulator registers
-__device__ __forceinline__ void wb6_chain_product(f32x16 (&out)[4], const unsigned char* r2, const f32x16& s, int n, int half) {
+// (mult: the gain of s, NT = 2)
+template <int NT>
+__device__ __forceinline__ void wbs_chain_product(f32x16 (&out)[4], const unsigned char* r2, const f32x16& s, int n, int half, float mult) {
   const unsigned char* base = r2 + n * WB6_R2_ROW + 16 * half;
-  Wb6Frag cur = wb6_lds_frag(base, WB6_R2_TERM);  // unit (st, mb) = (0, 0); in flight while s is split
-  Wb6Frag b[2];
+  WbsFrag<NT> cur = wbs_lds_frag<NT>(base, WB6_R2_TERM);  // unit (st, mb) = (0, 0); in flight while s is split
+  WbsFrag<NT> b[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = s[8 * st + j];
-    b[st] = wb6_split8(v);
+    b[st] = wbs_split8<NT>(v, mult);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int st = i >> 2, mb = i & 3;
-    Wb6Frag nxt = cur;
-    if (i + 1 < 8) nxt = wb6_lds_frag(base + 32 * ((i + 1) >> 2) + ((i + 1) & 3) * 32 * WB6_R2_ROW, WB6_R2_TERM);
+    WbsFrag<NT> nxt = cur;
+    if (i + 1 < 8) nxt = wbs_lds_frag<NT>(base + 32 * ((i + 1) >> 2) + ((i + 1) & 3) * 32 * WB6_R2_ROW, WB6_R2_TERM);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(cur.t[0]), "+v"(cur.t[1]), "+v"(cur.t[2]));
-    out[mb] = wb6_mfma6(cur, b[st], out[mb]);
+    wbs_pin<NT>(cur);
+    out[mb] = wbs_mfma<NT>(cur, b[st], out[mb]);
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
   }
@@ -594,26 +673,39 @@ __device__ __forceinline__ void wb6_store_rows(float* __restrict__ dst_row, cons
     }
 }
 
-// LDS of both kernels: R1 x 2 | R2 x 2 | staging x 2 | token ids, regions, statistics of the streaming tile
-#define WB6_OFF_R1(i_) ((i_) * WB6_R1_BYTES)
-#define WB6_OFF_R2(i_) (2 * WB6_R1_BYTES + (i_) * WB6_R2_BYTES)
-#define WB6_OFF_ST(i_) (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + (i_) * WB6_ST_BYTES)
-#define WB6_OFF_MISC (2 * WB6_R1_BYTES + 2 * WB6_R2_BYTES + 2 * WB6_ST_BYTES)
-static size_t wb6_lds_bytes() { return (size_t)WB6_OFF_MISC + 2 * WB6_T * sizeof(float4); }  // (statistics of two sub-tiles)
+// LDS of both kernels: R1 x N_R1 | R2 x 2 | staging x 2 | token ids, regions, statistics of the streaming tile.
+// bf16x6: 2 R1 regions (147 KiB in all); f16x3: its regions are 2/3 the size, so 4 R1 regions fit (142 KiB) and EVERY pass
+// takes two 32-row sub-tiles per set of barriers (one wave per SIMD: each barrier phase is an exposed LDS round trip).
+template <int NT>
+struct WbsLds {
+  static constexpr int N_R1 = NT == 2 ? 4 : 2;
+  static constexpr int R1_BYTES = NT * WB6_R1_TERM;
+  static constexpr int R2_BYTES = NT * WB6_R2_TERM;
+  static constexpr int off_r1(int i) { return i * R1_BYTES; }
+  static constexpr int off_r2(int i) { return N_R1 * R1_BYTES + i * R2_BYTES; }
+  static constexpr int off_st(int i) { return N_R1 * R1_BYTES + 2 * R2_BYTES + i * WB6_ST_BYTES; }
+  static constexpr int OFF_MISC = N_R1 * R1_BYTES + 2 * R2_BYTES + 2 * WB6_ST_BYTES;
+  static constexpr size_t BYTES = (size_t)OFF_MISC + 2 * WB6_T * sizeof(float4);  // (statistics of two sub-tiles)
+};
 
 // ---------------------------------------------------------------------------------------------------------------- dK, dV
 // Two launches, WHICH = 0: dV (S -> P -> dV^T = dO^T P), 1: dK (S, dP -> dS -> dK^T = Q^T dS).  One kernel for both needs the
-// stationary K and V fragments (192 registers) next to two 64-register results and the tile in flight: 512 registers and 71 spilled
-// ones, slower than the exact-f32 kernel.  Apart, the dV pass keeps only K (96 + 64) and the dK pass K and V (192 + 64); the price
-// is S twice (240 instead of 192 matrix instructions per 32 x 32 block pair).
-template <int WHICH>
-__global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
+// stationary K and V fragments (192 registers at NT = 3) next to two 64-register results and the tile in flight: 512 registers and
+// 71 spilled ones, slower than the exact-f32 kernel.  Apart, the dV pass keeps only K (96 + 64) and the dK pass K and V (192 + 64);
+// the price is S twice (240 instead of 192 matrix instructions per 32 x 32 block pair at NT = 3).
+template <int WHICH, int NT>
+__global__ __launch_bounds__(256, 1) void wa_bwd_dkv_split_kernel(WaBwdArgs A) {
+  using L = WbsLds<NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char wb6_smem[];
-  unsigned char* q_r1 = wb6_smem + WB6_OFF_R1(0);
-  unsigned char* do_r1 = wb6_smem + WB6_OFF_R1(1);
-  unsigned char* x_r2 = wb6_smem + WB6_OFF_R2(0);   // role 2 of the tensor the chain product reads: dO (dV pass) or Q (dK pass)
-  float* x_st = reinterpret_cast<float*>(wb6_smem + WB6_OFF_ST(0));
-  float4* q_info = reinterpret_cast<float4*>(wb6_smem + WB6_OFF_MISC);  // per query of the tile: maximum, 1 / sum, <dO, O>, wrap region
+  // NSUB 32-row sub-tiles per iteration (one set of barriers for all of them): 2 in the dV pass, whose LDS need per sub-tile is
+  // one R1, one R2 and one staging tile (the regions of the tensor it does not store are free), and in every f16x3 pass; 1 in
+  // the bf16x6 dK pass
+  constexpr int NSUB = (WHICH == 0 || NT == 2) ? 2 : 1;
+  unsigned char* q_r1 = wb6_smem + L::off_r1(0);
+  unsigned char* do_r1 = wb6_smem + L::off_r1(NSUB);
+  unsigned char* x_r2 = wb6_smem + L::off_r2(0);   // role 2 of the tensor the chain product reads: dO (dV pass) or Q (dK pass)
+  float* x_st = reinterpret_cast<float*>(wb6_smem + L::off_st(0));
+  float4* q_info = reinterpret_cast<float4*>(wb6_smem + L::OFF_MISC);  // per query of the tile: maximum, 1 / sum, <dO, O>, wrap region
 
   const WinGeom& G = A.G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -627,21 +719,30 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
   const float* vs = A.v + seq_off * WA_C;
   const float* gos = A.g_out + seq_off * WA_C;
 
+  // gains (NT = 2; all 1 otherwise): operands, the score's scale, <dO, O> in the units of the dP accumulator, the result
+  float g_q = 1.0f, g_k = 1.0f, g_v = 1.0f, g_do = 1.0f, x_gain = 1.0f;
+  if constexpr (NT == 2) {
+    g_q = wbs_tensor_gain(A.absmax[0]), g_k = wbs_tensor_gain(A.absmax[1]), g_v = wbs_tensor_gain(A.absmax[2]);
+    g_do = wbs_tensor_gain(A.absmax[3]);
+    x_gain = WHICH == 0 ? WBS_P_GAIN : WBS_DS_GAIN;
+  }
+  const float s_scale = A.scale / (g_q * g_k);
+  const float d_gain = g_do * g_v;
+  // dV^T holds gain(dO) * 2^15 * dV;  dK^T holds gain(Q) * gain(dO) gain(V) 2^-23 * dK / scale
+  const float out_scale = WHICH == 0 ? 1.0f / (g_do * x_gain) : A.scale / (g_q * (NT == 2 ? d_gain * x_gain : 1.0f));
+
   // this lane's key: row n of the wave's block
   const int my_li = ktile * WB6_R + wave * 32 + n;
   int my_kreg = 0;
   const int my_ktok = my_li < G.Lw ? win_token(G, wy, wx, my_li, my_kreg) : -1;
   const bool k_ok = my_ktok >= 0;
-  Wb6Frag kf[8], vf[WHICH ? 8 : 1];
-  wb6_stationary(kf, ks, my_ktok, half);
-  if constexpr (WHICH == 1) wb6_stationary(vf, vs, my_ktok, half);
+  WbsFrag<NT> kf[8], vf[WHICH ? 8 : 1];
+  wbs_stationary<NT>(kf, ks, my_ktok, half, g_k);
+  if constexpr (WHICH == 1) wbs_stationary<NT>(vf, vs, my_ktok, half, g_v);
 
   f32x16 res[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) res[mb] = (f32x16)(0.0f);
-  // NSUB 32-row sub-tiles per iteration (one set of barriers for all of them): 2 in the dV pass, whose LDS need per sub-tile is
-  // one R1, one R2 and one staging tile (the regions of the tensor it does not store are free); 1 in the dK pass
-  constexpr int NSUB = WHICH == 0 ? 2 : 1;
   const int n_iter = (n_tiles + NSUB - 1) / NSUB;
   Wb6TileRegs nq[NSUB], ndo[NSUB];  // the next query / dO sub-tiles, in flight
 #pragma unroll
@@ -654,11 +755,11 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
 #pragma unroll
     for (int sb = 0; sb < NSUB; ++sb) {
       if constexpr (WHICH == 0) {
-        wb6_store_r1(q_r1 + sb * WB6_R1_BYTES, nullptr, nq[sb], tid);
+        wbs_store_r1<NT>(q_r1 + sb * L::R1_BYTES, nullptr, nq[sb], tid, g_q);
         wb6_store_staging(x_st + sb * (WB6_ST_BYTES / 4), ndo[sb], tid);
       } else {
-        wb6_store_r1(q_r1, x_st, nq[sb], tid);
-        wb6_store_r1(do_r1, nullptr, ndo[sb], tid);
+        wbs_store_r1<NT>(q_r1 + sb * L::R1_BYTES, x_st + sb * (WB6_ST_BYTES / 4), nq[sb], tid, g_q);
+        wbs_store_r1<NT>(do_r1 + sb * L::R1_BYTES, nullptr, ndo[sb], tid, g_do);
       }
     }
     if (tid < NSUB * WB6_T) {
@@ -667,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
       const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
       // (1 / sum = 0 for rows beyond the window: they contribute nothing)
       q_info[tid] = make_float4(tok >= 0 ? A.row_m[seq_off + tok] : 0.0f, tok >= 0 ? 1.0f / A.row_l[seq_off + tok] : 0.0f,
-                                tok >= 0 ? A.row_d[seq_off + tok] : 0.0f, __int_as_float(region));
+                                tok >= 0 ? A.row_d[seq_off + tok] * d_gain : 0.0f, __int_as_float(region));
     }
     __syncthreads();
     if (qt + 1 < n_iter) {
@@ -678,13 +779,14 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
       }
     }
 #pragma unroll
-    for (int sb = 0; sb < NSUB; ++sb) wb6_build_r2(x_r2 + sb * WB6_R2_BYTES, x_st + sb * (WB6_ST_BYTES / 4), tid);
+    for (int sb = 0; sb < NSUB; ++sb)
+      wbs_build_r2<NT>(x_r2 + sb * L::R2_BYTES, x_st + sb * (WB6_ST_BYTES / 4), tid, WHICH == 0 ? g_do : g_q);
     __syncthreads();
 #pragma unroll
     for (int sb = 0; sb < NSUB; ++sb) {
-      const f32x16 s_ = wb6_tile_product(q_r1 + sb * WB6_R1_BYTES, kf, n, half);    // S block: rows = queries, columns = keys
+      const f32x16 s_ = wbs_tile_product<NT>(q_r1 + sb * L::R1_BYTES, kf, n, half);    // S block: rows = queries, columns = keys
       f32x16 dp = (f32x16)(0.0f);
-      if constexpr (WHICH == 1) dp = wb6_tile_product(do_r1, vf, n, half);   // dP block
+      if constexpr (WHICH == 1) dp = wbs_tile_product<NT>(do_r1 + sb * L::R1_BYTES, vf, n, half);   // dP block
       float4 info[16];  // one batch of 16 reads, one wait (read where they are used they are 64 reads with a wait each)
 #pragma unroll
       for (int r = 0; r < 16; ++r) info[r] = q_info[sb * WB6_T + wb_row(r, half)];
@@ -692,27 +794,30 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dkv_b6_kernel(WaBwdArgs A) {
       f32x16 x;  // P (dV pass) or dS (dK pass)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float s = wb_score(s_[r], A.scale, A.do_shift && __float_as_int(info[r].w) != my_kreg, k_ok);
+        const float s = wb_score(s_[r], s_scale, A.do_shift && __float_as_int(info[r].w) != my_kreg, k_ok);
         const float pr = k_ok ? __builtin_amdgcn_exp2f(s - info[r].x) * info[r].y : 0.0f;
         x[r] = WHICH == 0 ? pr : pr * (dp[r] - info[r].z);
+        if (WBS_EXP == 4) x[r] = s_[r] + dp[r];
       }
       // dV^T[channel][key] += dO^T[channel][query] P[query][key]   |   dK^T[channel][key] += Q^T[channel][query] dS[query][key]
-      wb6_chain_product(res, x_r2 + sb * WB6_R2_BYTES, x, n, half);
+      wbs_chain_product<NT>(res, x_r2 + sb * L::R2_BYTES, x, n, half, x_gain);
     }
   }
-  if (k_ok) wb6_store_rows((WHICH == 0 ? A.g_v : A.g_k) + (seq_off + my_ktok) * WA_C, res, half, WHICH == 0 ? 1.0f : A.scale);
+  if (k_ok) wb6_store_rows((WHICH == 0 ? A.g_v : A.g_k) + (seq_off + my_ktok) * WA_C, res, half, out_scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- dQ
 // HAVE_STATS: the forward published the row statistics (mnerf_window_attention_presplit_stats): no first pass
-template <bool HAVE_STATS>
-__global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
+template <bool HAVE_STATS, int NT>
+__global__ __launch_bounds__(256, 1) void wa_bwd_dq_split_kernel(WaBwdArgs A) {
+  using L = WbsLds<NT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char wb6_smem[];
-  unsigned char* k_r1 = wb6_smem + WB6_OFF_R1(0);
-  unsigned char* v_r1 = wb6_smem + WB6_OFF_R1(1);
-  unsigned char* k_r2 = wb6_smem + WB6_OFF_R2(0);
-  float* k_st = reinterpret_cast<float*>(wb6_smem + WB6_OFF_ST(0));
-  int* k_info = reinterpret_cast<int*>(wb6_smem + WB6_OFF_MISC);  // per key of the tile: wrap region, -1 beyond the window
+  constexpr int NSUB2 = NT == 2 ? 2 : 1;  // 32-key sub-tiles per iteration of pass 2
+  unsigned char* k_r1 = wb6_smem + L::off_r1(0);
+  unsigned char* v_r1 = wb6_smem + L::off_r1(NSUB2);
+  unsigned char* k_r2 = wb6_smem + L::off_r2(0);
+  float* k_st = reinterpret_cast<float*>(wb6_smem + L::off_st(0));
+  int* k_info = reinterpret_cast<int*>(wb6_smem + L::OFF_MISC);  // per key of the tile: wrap region, -1 beyond the window
 
   const WinGeom& G = A.G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -731,26 +836,30 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
   int my_qreg = 0;
   const int my_qtok = my_li < G.Lw ? win_token(G, wy, wx, my_li, my_qreg) : -1;
   const bool q_ok = my_qtok >= 0;
-  Wb6Frag qf[8], dof[8];
-  wb6_stationary(qf, qs, my_qtok, half);
-  wb6_stationary(dof, gos, my_qtok, half);
-  const float row_d = q_ok ? A.row_d[seq_off + my_qtok] : 0.0f;
 
-  auto publish_keys = [&](int kt) {
-    if (tid < WB6_T) {
-      int region = 0;
-      const int li = kt * WB6_T + tid;
-      const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
-      k_info[tid] = tok >= 0 ? region : -1;
-    }
-  };
+  // gains (NT = 2; all 1 otherwise).  The query is the lane, i.e. a column of every B operand it supplies, so its dO row takes a
+  // gain of its OWN (g_do, from ||dO_i||: the row's elements land below 2^15 however far the row is below the tensor's
+  // maximum) and dS^T a constant one: |dS_ij| <= 2 ||dO_i|| sqrt(128) max|V| < 2^(15 + 4.5 + 15) in gained units, times 2^-20.
+  float g_q = 1.0f, g_k = 1.0f, g_v = 1.0f, g_do = 1.0f, lane_gain = 1.0f;
+  if constexpr (NT == 2) {
+    g_q = wbs_tensor_gain(A.absmax[0]), g_k = wbs_tensor_gain(A.absmax[1]), g_v = wbs_tensor_gain(A.absmax[2]);
+    g_do = pow2i(gain_exp(q_ok ? sqrtf(A.row_n2[seq_off + my_qtok]) : 0.0f));
+    lane_gain = 9.5367431640625e-7f;  // 2^-20
+  }
+  const float s_scale = A.scale / (g_q * g_k);
+  const float d_gain = g_do * g_v;
+
+  WbsFrag<NT> qf[8], dof[8];
+  wbs_stationary<NT>(qf, qs, my_qtok, half, g_q);
+  wbs_stationary<NT>(dof, gos, my_qtok, half, g_do);
+  const float row_d = (q_ok ? A.row_d[seq_off + my_qtok] : 0.0f) * d_gain;
+
   // ---- pass 1: row statistics (online softmax over the key tiles; a wave sees every key of its queries: no merge across waves)
   // (four 32-key sub-tiles per iteration: this pass only needs K in role 1, the LDS of the other regions is free, and one set of
   // barriers then serves 128 keys)
   constexpr int NSUB1 = 4;
   const int n_iter1 = (n_tiles + NSUB1 - 1) / NSUB1;
   float run_m = -INFINITY, run_l = 0.0f;
-  Wb6TileRegs nk, nv;
   if constexpr (HAVE_STATS) {
     run_m = q_ok ? A.row_m[seq_off + my_qtok] : 0.0f;
     run_l = q_ok ? A.row_l[seq_off + my_qtok] : 1.0f;
@@ -761,7 +870,7 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
     for (int kt = 0; kt < n_iter1; ++kt) {
       __syncthreads();
 #pragma unroll
-      for (int sb = 0; sb < NSUB1; ++sb) wb6_store_r1(wb6_smem + sb * WB6_R1_BYTES, nullptr, nk1[sb], tid);
+      for (int sb = 0; sb < NSUB1; ++sb) wbs_store_r1<NT>(wb6_smem + sb * L::R1_BYTES, nullptr, nk1[sb], tid, g_k);
       if (tid < NSUB1 * WB6_T) {
         int region = 0;
         const int li = kt * NSUB1 * WB6_T + tid;
@@ -775,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
       }
 #pragma unroll
       for (int sb = 0; sb < NSUB1; ++sb) {
-        const f32x16 st = wb6_tile_product(wb6_smem + sb * WB6_R1_BYTES, qf, n, half);  // S^T block: rows = keys, columns = queries
+        const f32x16 st = wbs_tile_product<NT>(wb6_smem + sb * L::R1_BYTES, qf, n, half);  // S^T block: rows = keys, columns = queries
         int4 ki[4];  // keys 4 half + 8 g .. + 3 are registers 4 g .. 4 g + 3
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[sb * 8 + half + 2 * gq];
@@ -784,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
-          sc[r] = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
+          sc[r] = wb_score(st[r], s_scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
           mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -807,50 +916,73 @@ __global__ __launch_bounds__(256, 1) void wa_bwd_dq_b6_kernel(WaBwdArgs A) {
       A.row_l[seq_off + my_qtok] = run_l;
     }
   }
-  const float inv_l = 1.0f / run_l;
+  const float inv_l = lane_gain / run_l;  // (the query's dS gain rides on 1 / l)
 
   // ---- pass 2: dQ^T[channel][query] = scale * sum_keys K^T[channel][key] dS^T[key][query]
   f32x16 dq[4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) dq[mb] = (f32x16)(0.0f);
-  wb6_fetch(nk, ks, G, wy, wx, 0, tid);
-  wb6_fetch(nv, vs, G, wy, wx, 0, tid);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    __syncthreads();
-    wb6_store_r1(k_r1, k_st, nk, tid);
-    wb6_store_r1(v_r1, nullptr, nv, tid);
-    publish_keys(kt);
-    __syncthreads();
-    if (kt + 1 < n_tiles) {
-      wb6_fetch(nk, ks, G, wy, wx, (kt + 1) * WB6_T, tid);
-      wb6_fetch(nv, vs, G, wy, wx, (kt + 1) * WB6_T, tid);
-    }
-    wb6_build_r2(k_r2, k_st, tid);
-    __syncthreads();
-    const f32x16 st = wb6_tile_product(k_r1, qf, n, half);
-    const f32x16 dpt = wb6_tile_product(v_r1, dof, n, half);  // dP^T block
-    int4 ki[4];
+  const int n_iter2 = (n_tiles + NSUB2 - 1) / NSUB2;
+  Wb6TileRegs nk[NSUB2], nv[NSUB2];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[half + 2 * gq];
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 ds;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
-      const float s = wb_score(st[r], A.scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
-      const float p = q_ok ? __builtin_amdgcn_exp2f(s - run_m) * inv_l : 0.0f;
-      ds[r] = p * (dpt[r] - row_d);
-    }
-    wb6_chain_product(dq, k_r2, ds, n, half);
+  for (int sb = 0; sb < NSUB2; ++sb) {
+    wb6_fetch(nk[sb], ks, G, wy, wx, sb * WB6_T, tid);
+    wb6_fetch(nv[sb], vs, G, wy, wx, sb * WB6_T, tid);
   }
-  if (q_ok) wb6_store_rows(A.g_q + (seq_off + my_qtok) * WA_C, dq, half, A.scale);
+  for (int kt = 0; kt < n_iter2; ++kt) {
+    __syncthreads();
+#pragma unroll
+    for (int sb = 0; sb < NSUB2; ++sb) {
+      wbs_store_r1<NT>(k_r1 + sb * L::R1_BYTES, k_st + sb * (WB6_ST_BYTES / 4), nk[sb], tid, g_k);
+      wbs_store_r1<NT>(v_r1 + sb * L::R1_BYTES, nullptr, nv[sb], tid, g_v);
+    }
+    if (tid < NSUB2 * WB6_T) {
+      int region = 0;
+      const int li = kt * NSUB2 * WB6_T + tid;
+      const int tok = li < G.Lw ? win_token(G, wy, wx, li, region) : -1;
+      k_info[tid] = tok >= 0 ? region : -1;
+    }
+    __syncthreads();
+    if (kt + 1 < n_iter2) {
+#pragma unroll
+      for (int sb = 0; sb < NSUB2; ++sb) {
+        wb6_fetch(nk[sb], ks, G, wy, wx, ((kt + 1) * NSUB2 + sb) * WB6_T, tid);
+        wb6_fetch(nv[sb], vs, G, wy, wx, ((kt + 1) * NSUB2 + sb) * WB6_T, tid);
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < NSUB2; ++sb) wbs_build_r2<NT>(k_r2 + sb * L::R2_BYTES, k_st + sb * (WB6_ST_BYTES / 4), tid, g_k);
+    __syncthreads();
+#pragma unroll
+    for (int sb = 0; sb < NSUB2; ++sb) {
+      const f32x16 st = wbs_tile_product<NT>(k_r1 + sb * L::R1_BYTES, qf, n, half);
+      const f32x16 dpt = wbs_tile_product<NT>(v_r1 + sb * L::R1_BYTES, dof, n, half);  // dP^T block
+      int4 ki[4];
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) ki[gq] = reinterpret_cast<const int4*>(k_info)[sb * 8 + half + 2 * gq];
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kinfo = (r & 3) == 0 ? ki[r >> 2].x : (r & 3) == 1 ? ki[r >> 2].y : (r & 3) == 2 ? ki[r >> 2].z : ki[r >> 2].w;
+        const float s = wb_score(st[r], s_scale, A.do_shift && kinfo != my_qreg, kinfo >= 0);
+        const float p = q_ok ? __builtin_amdgcn_exp2f(s - run_m) * inv_l : 0.0f;
+        ds[r] = p * (dpt[r] - row_d);
+        if (WBS_EXP == 4) ds[r] = st[r] + dpt[r];
+      }
+      wbs_chain_product<NT>(dq, k_r2 + sb * L::R2_BYTES, ds, n, half, 1.0f);  // (ds already carries its gain)
+    }
+  }
+  // dQ^T holds gain(K) * gain(dO) gain(V) * lane_gain * dQ / scale
+  if (q_ok) wb6_store_rows(A.g_q + (seq_off + my_qtok) * WA_C, dq, half, A.scale / (g_k * (NT == 2 ? d_gain * lane_gain : 1.0f)));
 }
 
 static size_t wb_lds_bytes() { return (size_t)4 * WB_TILE_FLOATS * sizeof(float) + 4 * WB_T * sizeof(int) + 6 * WB_T * sizeof(float); }
 
 extern "C" int64_t mnerf_window_attention_backward_workspace_bytes(int32_t batch, int32_t h, int32_t w) {
   if (batch < 0 || h < 1 || w < 1) return -1;
-  return (int64_t)3 * batch * h * w * (int64_t)sizeof(float);  // row maximum | row sum | <dO, O>
+  // row maximum | row sum | <dO, O> | ||dO||^2 | the four operand maxima (f16x3 form)
+  return ((int64_t)4 * batch * h * w + 4) * (int64_t)sizeof(float);
 }
 
 static int wa_backward_impl(const char* who, const float* q, const float* k, const float* v, const float* out, const float* g_out,
@@ -882,31 +1014,51 @@ static int wa_backward_impl(const char* who, const float* q, const float* k, con
     (void)hipFuncSetAttribute((const void*)wa_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL(wa_bwd_rowdot_kernel, dim3((unsigned)((n_tok + 7) / 8)), dim3(256), 0, st, g_out, out, row_d, n_tok);
-  // MNERF_WA_BWD_MATH (environment, read once): "bf16x6" (default) = the split-bf16 kernels, "f32" = the exact-f32 ones
-  static const int math_b6 = [] {
-    const char* e = getenv("MNERF_WA_BWD_MATH");
-    return (e && !strcmp(e, "f32")) ? 0 : 1;
-  }();
-  if (math_b6) {
-    const size_t lds6 = wb6_lds_bytes();
+  // MNERF_WA_BWD_MATH (environment): "f16x3" (default) / "bf16x6" = the split 16-bit kernels, "f32" = the exact-f32 ones
+  // (read at every call: a dozen getenv per training iteration, and the tests switch forms inside one process)
+  const char* math_env = getenv("MNERF_WA_BWD_MATH");
+  const int math = (math_env && !strcmp(math_env, "f32")) ? 0 : (math_env && !strcmp(math_env, "bf16x6")) ? 3 : 2;
+  float* row_n2 = row_d + n_tok;
+  unsigned* absmax = reinterpret_cast<unsigned*>(row_n2 + n_tok);
+  A.row_n2 = row_n2, A.absmax = absmax;
+  hipLaunchKernelGGL(wa_bwd_rowdot_kernel, dim3((unsigned)((n_tok + 7) / 8)), dim3(256), 0, st, g_out, out, row_d,
+                     math == 2 ? row_n2 : nullptr, n_tok);
+  if (math) {
     static std::atomic<unsigned long long> attr6_set{0};
     if (mnerf_once_per_device(attr6_set)) {
-      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
-      (void)hipFuncSetAttribute((const void*)wa_bwd_dq_b6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
-      (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
-      (void)hipFuncSetAttribute((const void*)wa_bwd_dkv_b6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6);
+#define WBS_ATTR(K_, NT_) (void)hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WbsLds<NT_>::BYTES)
+      WBS_ATTR((wa_bwd_dq_split_kernel<false, 3>), 3);
+      WBS_ATTR((wa_bwd_dq_split_kernel<true, 3>), 3);
+      WBS_ATTR((wa_bwd_dkv_split_kernel<0, 3>), 3);
+      WBS_ATTR((wa_bwd_dkv_split_kernel<1, 3>), 3);
+      WBS_ATTR((wa_bwd_dq_split_kernel<false, 2>), 2);
+      WBS_ATTR((wa_bwd_dq_split_kernel<true, 2>), 2);
+      WBS_ATTR((wa_bwd_dkv_split_kernel<0, 2>), 2);
+      WBS_ATTR((wa_bwd_dkv_split_kernel<1, 2>), 2);
+#undef WBS_ATTR
     }
     const dim3 grid6((G.Lw + WB6_R - 1) / WB6_R, num_splits * num_splits, batch);
     if (row_stats) {  // the forward's statistics: read in place by all three kernels
       A.row_m = const_cast<float*>(row_stats);
       A.row_l = A.row_m + n_tok;
-      hipLaunchKernelGGL(wa_bwd_dq_b6_kernel<true>, grid6, dim3(256), lds6, st, A);
-    } else {
-      hipLaunchKernelGGL(wa_bwd_dq_b6_kernel<false>, grid6, dim3(256), lds6, st, A);
     }
-    hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<0>, grid6, dim3(256), lds6, st, A);
-    hipLaunchKernelGGL(wa_bwd_dkv_b6_kernel<1>, grid6, dim3(256), lds6, st, A);
+    if (math == 2) {
+      if (hipMemsetAsync(absmax, 0, 4 * sizeof(unsigned), st) != hipSuccess) return mnerf_check_launch(who);
+      const long long n4 = n_tok * (WA_C / 4);
+      const unsigned nblk = (unsigned)((n4 + 256 * 8 - 1) / (256 * 8) < 1024 ? (n4 + 256 * 8 - 1) / (256 * 8) : 1024);
+      hipLaunchKernelGGL(wa_bwd_absmax4_kernel, dim3(nblk, 4), dim3(256), 0, st, q, k, v, g_out, n4, absmax);
+      const size_t lds2 = WbsLds<2>::BYTES;
+      if (row_stats) hipLaunchKernelGGL((wa_bwd_dq_split_kernel<true, 2>), grid6, dim3(256), lds2, st, A);
+      else hipLaunchKernelGGL((wa_bwd_dq_split_kernel<false, 2>), grid6, dim3(256), lds2, st, A);
+      hipLaunchKernelGGL((wa_bwd_dkv_split_kernel<0, 2>), grid6, dim3(256), lds2, st, A);
+      hipLaunchKernelGGL((wa_bwd_dkv_split_kernel<1, 2>), grid6, dim3(256), lds2, st, A);
+    } else {
+      const size_t lds3 = WbsLds<3>::BYTES;
+      if (row_stats) hipLaunchKernelGGL((wa_bwd_dq_split_kernel<true, 3>), grid6, dim3(256), lds3, st, A);
+      else hipLaunchKernelGGL((wa_bwd_dq_split_kernel<false, 3>), grid6, dim3(256), lds3, st, A);
+      hipLaunchKernelGGL((wa_bwd_dkv_split_kernel<0, 3>), grid6, dim3(256), lds3, st, A);
+      hipLaunchKernelGGL((wa_bwd_dkv_split_kernel<1, 3>), grid6, dim3(256), lds3, st, A);
+    }
     return mnerf_check_launch(who);
   }
   const int n_tiles = (G.Lw + WB_T - 1) / WB_T;

@@ -1,4 +1,4 @@
-"""The split-bf16 arithmetic of the backward kernels (gemm_b6_kernel, wa_bwd_*_b6_kernel; matchnerf_amd/csrc/gemm_f32.hpp,
+"""The split-bf16 arithmetic of the backward kernels (gemm_b6_kernel, wa_bwd_*_split_kernel<.., 3>, and the f16x3 twin <.., 2>; matchnerf_amd/csrc/gemm_f32.hpp,
 window_attention_backward.hip) restated in numpy — no GPU:
 * three round-to-nearest-even bf16 terms taken as the kernels take them (term, residual, term, residual, term) represent an fp32
   value EXACTLY for |x| >= 2^-100 (below that the third term drops into fp32's subnormals and loses bits; the value is then still
@@ -102,16 +102,37 @@ def mfma6(a_terms, b_terms):
     return acc
 
 
-def test_dk_dv_dataflow_of_the_split_bf16_attention_backward():
-    """wa_bwd_dkv_b6_kernel<0 | 1> for one workgroup, restated: a 96-token window (no shift) against a 128-row stationary key block
-    (32 rows beyond the window), three 32-query streaming tiles; role-1 fragments [row][16 channels of step u], role-2 lines with
-    the permuted rows, P / dS taken register by register from the accumulator map; the forward's row statistics as input.
-    Judge: the dense float64 gradients."""
-    rng = np.random.default_rng(7)
-    lw, c = 96, 128
-    q, k, v, go = (rng.standard_normal((lw, c)).astype(np.float32) * s for s in (0.6, 0.8, 1.0, 1.0))
+def split2h(x, mult):
+    """split8h (split_f16.hpp): x * mult (a power of two) as fp16 hi (nearest even) + fp16 lo of the exact fp32 residual"""
+    xm = (x.astype(np.float32) * np.float32(mult)).astype(np.float32)
+    hi = xm.astype(np.float16)
+    lo = (xm - hi.astype(np.float32)).astype(np.float32).astype(np.float16)
+    assert np.isfinite(hi.astype(np.float32)).all()           # the gain keeps every operand inside fp16's range
+    return hi.astype(np.float32), lo.astype(np.float32)
+
+
+def mfma3(a_terms, b_terms):
+    """one K16-step of the f16x3 form: lo.hi + hi.lo + hi.hi, smallest first, fp32 accumulation"""
+    acc = np.zeros((a_terms[0].shape[0], b_terms[0].shape[1]), np.float32)
+    for ta, tb in ((1, 0), (0, 1), (0, 0)):
+        acc = (acc + (a_terms[ta].astype(np.float64) @ b_terms[tb].astype(np.float64)).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def tensor_gain(x):
+    """wbs_tensor_gain: max|x| * gain in [2^14, 2^15)"""
+    m = float(np.abs(x).max())
+    return 2.0 ** (15 - (np.frexp(np.float32(m))[1] if m > 0 else 0))
+
+
+def _dk_dv_restated(q, k, v, go, form):
+    """wa_bwd_dkv_split_kernel<0 | 1, NT> for one workgroup, restated: a 96-token window (no shift) against a 128-row stationary
+    key block (32 rows beyond the window), three 32-query streaming tiles; role-1 fragments [row][16 channels of step u], role-2
+    lines with the permuted rows, P / dS taken register by register from the accumulator map; the forward's row statistics as
+    input.  form: "bf16x6" (three bf16 terms, no gains) or "f16x3" (two fp16 terms, the kernel's gains).  Returns the workgroup's
+    dV, dK and the dense float64 gradients."""
+    lw, c = q.shape
     scale, log2e = 1.0 / np.sqrt(c), 1.4426950408889634
-    # float64 reference
     s64 = (q.astype(np.float64) @ k.astype(np.float64).T) * scale
     p64 = np.exp(s64 - s64.max(1, keepdims=True))
     p64 /= p64.sum(1, keepdims=True)
@@ -125,9 +146,14 @@ def test_dk_dv_dataflow_of_the_split_bf16_attention_backward():
     row_m = s2.max(1).astype(np.float32)
     row_l = np.exp2(s2 - row_m[:, None]).sum(1).astype(np.float32)
     row_d = d64[:, 0].astype(np.float32)
-
-    def frag_terms(x):
-        return [t for t in split3(x)]
+    if form == "bf16x6":
+        g_q = g_k = g_v = g_do = p_gain = ds_gain = 1.0
+        terms, mfma = (lambda x, mult: list(split3(x))), mfma6
+    else:
+        g_q, g_k, g_v, g_do = (tensor_gain(t) for t in (q, k, v, go))
+        p_gain, ds_gain = 2.0 ** 15, 2.0 ** -23                # WBS_P_GAIN, WBS_DS_GAIN
+        terms, mfma = (lambda x, mult: list(split2h(x, mult))), mfma3
+    s_scale, d_gain = np.float32(scale / (g_q * g_k)), np.float32(g_do * g_v)
 
     dk, dv = np.zeros((128, c), np.float32), np.zeros((128, c), np.float32)
     for wave in range(4):                                   # a wave owns 32 keys
@@ -135,30 +161,55 @@ def test_dk_dv_dataflow_of_the_split_bf16_attention_backward():
         k_ok = key_rows < lw
         kblk = np.where(k_ok[:, None], k[np.minimum(key_rows, lw - 1)], 0.0).astype(np.float32)
         vblk = np.where(k_ok[:, None], v[np.minimum(key_rows, lw - 1)], 0.0).astype(np.float32)
-        kf, vf = frag_terms(kblk), frag_terms(vblk)         # stationary fragments: [32 keys][128 ch] per term
+        kf, vf = terms(kblk, g_k), terms(vblk, g_v)         # stationary fragments: [32 keys][128 ch] per term
         res_k, res_v = np.zeros((c, 32), np.float32), np.zeros((c, 32), np.float32)  # dK^T / dV^T [channel][key]
         for qt in range(3):                                 # streaming tiles of 32 queries
             rows = np.arange(32 * qt, 32 * qt + 32)
             qtile, dotile = q[rows], go[rows]
-            q_r1, do_r1 = frag_terms(qtile), frag_terms(dotile)
+            q_r1, do_r1 = terms(qtile, g_q), terms(dotile, g_do)
             s_blk, dp_blk = np.zeros((32, 32), np.float32), np.zeros((32, 32), np.float32)
             for u in range(8):                              # S = Q K^T and dP = dO V^T over the channels, one K16-step at a time
                 ch = slice(16 * u, 16 * u + 16)
-                s_blk = (s_blk + mfma6([t[:, ch] for t in q_r1], [t[:, ch].T for t in kf])).astype(np.float32)
-                dp_blk = (dp_blk + mfma6([t[:, ch] for t in do_r1], [t[:, ch].T for t in vf])).astype(np.float32)
-            sc = (s_blk * np.float32(scale)) * np.float32(log2e)
+                s_blk = (s_blk + mfma([t[:, ch] for t in q_r1], [t[:, ch].T for t in kf])).astype(np.float32)
+                dp_blk = (dp_blk + mfma([t[:, ch] for t in do_r1], [t[:, ch].T for t in vf])).astype(np.float32)
+            sc = (s_blk * s_scale) * np.float32(log2e)
             p = np.where(k_ok[None, :], np.exp2(sc - row_m[rows][:, None]) / row_l[rows][:, None], 0.0).astype(np.float32)
-            ds = (p * (dp_blk - row_d[rows][:, None])).astype(np.float32)
+            ds = (p * (dp_blk - (row_d[rows] * d_gain)[:, None])).astype(np.float32)   # in the units of the dP accumulator
             # role 2: [channel][position], position 16 s + 8 h + j holds row 16 s + 8 (j >> 2) + 4 h + (j & 3)
             pos_row = np.array([16 * s + 8 * (j >> 2) + 4 * h + (j & 3) for s in range(2) for h in range(2) for j in range(8)])
-            do_r2 = [t[pos_row].T for t in frag_terms(dotile)]   # [term][channel][32 positions]
-            q_r2 = [t[pos_row].T for t in frag_terms(qtile)]
+            do_r2 = [t[pos_row].T for t in terms(dotile, g_do)]   # [term][channel][32 positions]
+            q_r2 = [t[pos_row].T for t in terms(qtile, g_q)]
             for s in range(2):                              # chain products: the B operand is P / dS register by register
                 regs = np.array([wb_row(8 * s + j, h) for h in range(2) for j in range(8)])   # rows in K16 order (h, j)
                 pos = slice(16 * s, 16 * s + 16)
-                res_v = (res_v + mfma6([t[:, pos] for t in do_r2], frag_terms(p[regs]))).astype(np.float32)
-                res_k = (res_k + mfma6([t[:, pos] for t in q_r2], frag_terms(ds[regs]))).astype(np.float32)
-        dv[key_rows], dk[key_rows] = res_v.T, res_k.T * np.float32(scale)
+                res_v = (res_v + mfma([t[:, pos] for t in do_r2], terms(p[regs], p_gain))).astype(np.float32)
+                res_k = (res_k + mfma([t[:, pos] for t in q_r2], terms(ds[regs], ds_gain))).astype(np.float32)
+        dv[key_rows] = res_v.T * np.float32(1.0 / (g_do * p_gain))
+        dk[key_rows] = res_k.T * np.float32(scale / (g_q * (d_gain * ds_gain if form == "f16x3" else 1.0)))
+    return dv, dk, dv_ref, dk_ref
+
+
+def test_dk_dv_dataflow_of_the_split_bf16_attention_backward():
+    """Judge: the dense float64 gradients."""
+    rng = np.random.default_rng(7)
+    lw, c = 96, 128
+    q, k, v, go = (rng.standard_normal((lw, c)).astype(np.float32) * s for s in (0.6, 0.8, 1.0, 1.0))
+    dv, dk, dv_ref, dk_ref = _dk_dv_restated(q, k, v, go, "bf16x6")
     for got, ref in ((dv[:lw], dv_ref), (dk[:lw], dk_ref)):
         assert np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max() < 3e-6
     assert np.all(dv[lw:] == 0) and np.all(dk[lw:] == 0)   # rows beyond the window: nothing
+
+
+def test_dk_dv_dataflow_of_the_split_fp16_attention_backward_and_its_gains():
+    """The f16x3 form with the kernel's gains (one per tensor from its maximum, 2^15 for P, 2^-23 for dS): no operand leaves fp16's
+    range (split2h asserts it) and the gradients are fp32-grade — also with operand scales far from 1 and gradient rows spread over
+    sixteen binades (dK / dV sum over the queries: judged against the tensor's maximum, as the GPU test does)."""
+    rng = np.random.default_rng(8)
+    lw, c = 96, 128
+    for scales, spread in (((0.6, 0.8, 1.0, 1.0), 0), ((3.0, 0.05, 40.0, 1e-3), 16), ((200.0, 1e-3, 1e-4, 3e4), 8)):
+        q, k, v, go = (rng.standard_normal((lw, c)).astype(np.float32) * np.float32(s) for s in scales)
+        go = (go * np.exp2(-rng.integers(0, spread + 1, (lw, 1)))).astype(np.float32)
+        dv, dk, dv_ref, dk_ref = _dk_dv_restated(q, k, v, go, "f16x3")
+        for got, ref in ((dv[:lw], dv_ref), (dk[:lw], dk_ref)):
+            assert np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max() < 3e-6, scales
+        assert np.all(dv[lw:] == 0) and np.all(dk[lw:] == 0)

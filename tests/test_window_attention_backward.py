@@ -18,10 +18,13 @@ pytestmark = pytest.mark.gpu
     (6, 64, 80, 2, True),    # the DTU shape: 3 pairs x 2 directions, 1280-token windows
 ])
 @pytest.mark.parametrize("forward_stats", [False, True])
-def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shifted, forward_stats):
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shifted, forward_stats, math, monkeypatch):
     """forward_stats: the training pair (mnerf_window_attention_presplit_stats -> mnerf_window_attention_backward_stats): the
-    forward publishes the softmax's row statistics, the backward has no statistics pass"""
+    forward publishes the softmax's row statistics, the backward has no statistics pass.  math: the two split 16-bit forms
+    (MNERF_WA_BWD_MATH, read by the library at every call; f16x3 is the default)"""
     from matchnerf_amd import hip
+    monkeypatch.setenv("MNERF_WA_BWD_MATH", math)
     gen = torch.Generator().manual_seed(h * 1000 + w * 10 + splits + int(shifted))
     n, c = h * w, 128
     q = torch.randn(b, n, c, generator=gen) * 0.6       # scores ~ N(0, 0.36 * 0.8^2 * 128 / 11.3^2): a peaked but not one-hot softmax
@@ -48,6 +51,36 @@ def test_window_attention_backward_matches_float64_autograd(b, h, w, splits, shi
         worst[name] = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
     print({kk: f"{vv:.1e}" for kk, vv in worst.items()})
     assert all(vv < 2e-5 for vv in worst.values()), worst
+
+
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6", "f32"])
+def test_backward_with_gradient_rows_over_24_binades(math, monkeypatch):
+    """The f16x3 form's range management on data it was not tuned for: gradient rows scaled by 2^-k, k in [0, 24] (rays hit few
+    tokens hard and most barely), q / k / v at different scales.  dQ carries a gain per query, so EVERY row of it is judged
+    against its own magnitude; dK / dV sum over the queries and are judged against the tensor's maximum."""
+    from matchnerf_amd import hip
+    monkeypatch.setenv("MNERF_WA_BWD_MATH", math)
+    gen = torch.Generator().manual_seed(77)
+    b, h, w, splits, shifted, c = 2, 16, 24, 2, True, 128
+    n = h * w
+    q = torch.randn(b, n, c, generator=gen) * 3.0
+    k = torch.randn(b, n, c, generator=gen) * 0.05
+    v = torch.randn(b, n, c, generator=gen) * 40.0
+    g = torch.randn(b, n, c, generator=gen) * torch.exp2(-torch.randint(0, 25, (b, n, 1), generator=gen).float()) * 1e-3
+    qg, kg, vg, gg = q.cuda(), k.cuda(), v.cuda(), g.cuda()
+    out = hip.window_attention(qg, kg, vg, h, w, splits, shifted)
+    gq, gk, gv = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    (O.window_attention(q64, k64, v64, h, w, splits, shifted) * g.double()).sum().backward()
+    worst = {}
+    for name, got, ref in (("q", gq, q64.grad), ("k", gk, k64.grad), ("v", gv, v64.grad)):
+        assert torch.isfinite(got).all()
+        worst[name] = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    err_rows = (gq.cpu().double() - q64.grad).abs().amax(-1) / q64.grad.abs().amax(-1)
+    worst["q_rows"] = float(err_rows.max())
+    print(math, {kk: f"{vv:.1e}" for kk, vv in worst.items()})
+    assert all(worst[kk] < 2e-5 for kk in "qkv"), worst
+    assert worst["q_rows"] < 5e-6, worst
 
 
 def test_autograd_bridge_uses_the_hip_backward(monkeypatch):

@@ -22,4 +22,4 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 chk = sum(float(t.double().abs().sum()) for t in r)
-print(f"{os.environ.get('MNERF_LIB', 'shipped')[-24:]} {os.environ.get('MNERF_WA_BWD_MATH', 'bf16x6')}: {e0.elapsed_time(e1) / 10:.3f} ms per call, checksum {chk:.6e}", flush=True)
+print(f"{os.environ.get('MNERF_LIB', 'shipped')[-24:]} {os.environ.get('MNERF_WA_BWD_MATH', 'f16x3')}: {e0.elapsed_time(e1) / 10:.3f} ms per call, checksum {chk:.6e}", flush=True)
