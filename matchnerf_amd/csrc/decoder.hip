@@ -1676,6 +1676,10 @@ __device__ __host__ constexpr int pp_seg_off_floats(int s, int i, int fs = 2) { 
 // PP_DMA_IN_M = 0: no request is issued inside a matrix phase (4 measured 16.45-16.53, 2: 16.54-16.6 against 16.35-16.43 ms per
 // frame with all of them in the vector phases: profiles/history/r4_variants.md); the mechanism stays for the next attempt
 constexpr int PP_DMA_IN_M = 0;
+#ifndef MNERF_PP_DMA_RUNS
+#define MNERF_PP_DMA_RUNS 1  // the bursts' requests in runs of four consecutive pieces per M0 write (stage_dma); 0: one by one
+#endif
+static_assert(MNERF_PP_DMA_RUNS == 0 || PP_DMA_IN_M == 0, "requests inside matrix phases take single pieces 2 tw + half + 8 k");
 __device__ __host__ constexpr int pp_km(int n) {
   const int enc_stage = 7;  // (layer 5 takes its activation half first) the stage AFTER the encoding half of layer 5 stays in the burst
   if (n < 3 || n > 11 || n == enc_stage + 1) return 0;
@@ -2112,9 +2116,25 @@ __global__ __launch_bounds__(512, 2) void decoder_pp_kernel(
       const int pieces = i == 0 ? pp_p0(s, FS) : pp_p1(s);
       const unsigned base = PP_SLOT_LDS(s, i);
       const int first = half == 2 ? twl : 2 * twl + half, step = half == 2 ? 4 : 8;
+#if MNERF_PP_DMA_RUNS
+      // round 6: the pieces are dealt in RUNS of four consecutive ones (run r to team r & 1, wave (r >> 1) & 3; all runs to one
+      // team's waves for half = 2), a run is one glds16_sv4 = one M0 write for four requests; what is left of a segment beyond
+      // its last full run (0 or 1 piece in this schedule) goes to the next (team, wave) of the pattern one by one
+      const int n_runs = pieces >> 2;
+      for (int r = first; r <= n_runs; r += step) {
+        const unsigned off = (unsigned)r * 4096u;
+        if (r < n_runs)
+          glds16_sv4(D.wstream, voff, (unsigned)pp_seg_off_floats(s, i, FS) * 4u + off, __builtin_amdgcn_readfirstlane(base + off));
+        else
+          for (int p = 4 * n_runs; p < pieces; ++p)
+            glds16_sv(D.wstream, voff, (unsigned)pp_seg_off_floats(s, i, FS) * 4u + (unsigned)p * 1024u,
+                      __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+      }
+#else
       for (int p = first; p < pieces; p += step)
         glds16_sv(D.wstream, voff, (unsigned)pp_seg_off_floats(s, i, FS) * 4u + (unsigned)p * 1024u,
                   __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+#endif
     }
   };
   // ---- weight requests of a vector phase.  MNERF_PP_DMA_SPREAD = 0 (round 3): team A asks for its half of stage s (the odd

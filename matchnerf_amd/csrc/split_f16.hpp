@@ -71,6 +71,29 @@ __device__ __forceinline__ void glds16_sv(const float* uniform_base, unsigned la
       : "memory");
 }
 
+// FOUR consecutive 1-KiB pieces per M0 write: the instruction offset (0, 1024, 2048, 3072) moves the global AND the LDS address
+// of an LDS-DMA load, so a contiguous 4-KiB run needs one address add, one M0 save / write / restore and one set of hazard nops.
+// tools/exp/ubench/dma_issue.hip (8 waves per CU, requests next to a vector filler, cycles of issue per request):
+// one piece per statement (glds16_s) 74-78, the same without its leading s_nop 4: 50-55, four per M0 write: 40-43.
+__device__ __forceinline__ void glds16_sv4(const float* uniform_base, unsigned lane_off_bytes, unsigned piece_off_bytes,
+                                           unsigned lds_byte_addr) {
+  unsigned keep, vo;
+  asm volatile(
+      "v_add_u32 %1, %4, %2\n\t"
+      "s_nop 3\n\t"
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&v"(vo)
+      : "v"(lane_off_bytes), "s"(uniform_base), "s"(piece_off_bytes), "s"(lds_byte_addr)
+      : "memory");
+}
+
 // glds16_s for data read exactly once (the conditioning rows): non-temporal, so that the stream does not push the weight
 // segments and the register-spill scratch out of L2 (ping-pong decoder, MI355X: FETCH_SIZE 462 -> 212 MB per 65 536-ray launch,
 // L2 misses 40 M -> 17 M, 18.27 -> 17.93 ms per frame; -DMNERF_ROWS_TEMPORAL restores the plain form).
