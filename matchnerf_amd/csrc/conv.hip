@@ -57,8 +57,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   auto stage = [&](int seg) {
     const float* src = P.wstream + (size_t)seg * (size_t)seg_units * 512 + lane * 4;
     const unsigned dst = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
-    for (int p = wave; p < pieces; p += CONV_NW)
-      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+    glds_segment(src, dst, pieces, wave, CONV_NW);
   };
   stage(0);
 
@@ -394,8 +393,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_stem_kernel(StemParams P
   const int n = lane & 31, hl = lane >> 5;
   {
     const float* src = P.wstream + lane * 4;
-    for (int p = wave; p < STEM_W_BYTES / 1024; p += CONV_NW)
-      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(buf0 + (unsigned)p * 1024u));
+    glds_segment(src, buf0, STEM_W_BYTES / 1024, wave, CONV_NW);
   }
   const int hw_in = P.h_in * P.w_in;
   for (int k = tid; k < 16 * STEM_STEPS; k += CONV_NW * 64) {

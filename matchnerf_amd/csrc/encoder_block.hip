@@ -44,8 +44,7 @@ __device__ __forceinline__ void eb_prefetch(const float* __restrict__ wstream, i
                                             int wave, int lane) {
   if (seg >= n_seg) return;
   const float* src = wstream + (size_t)seg * EB_SEG_FLOATS + lane * 4;
-  for (int p = wave; p < EB_SEG_FLOATS / 256; p += NW)
-    glds16(src + p * 256, __builtin_amdgcn_readfirstlane(base + (unsigned)p * 1024u));
+  glds_segment(src, base, EB_SEG_FLOATS / 256, wave, NW);
 }
 
 // LayerNorm over the 128 features of a token held in accumulator layout: register r of block m of lane (n, half) is

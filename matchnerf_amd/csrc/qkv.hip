@@ -60,8 +60,7 @@ __global__ __launch_bounds__(QKV_NW * 64, 2) void qkv_kernel(QkvParams P) {
   auto stage = [&](int seg) {
     const float* src = P.wstream + (size_t)seg * QKV_SEG_FLOATS + lane * 4;
     const unsigned dst = buf0 + (unsigned)(seg & 1) * (QKV_SEG_FLOATS * 4u);
-    for (int p = wave; p < QKV_SEG_FLOATS / 256; p += QKV_NW)
-      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+    glds_segment(src, dst, QKV_SEG_FLOATS / 256, wave, QKV_NW);
   };
   stage(0);
 
@@ -170,8 +169,7 @@ __global__ __launch_bounds__(QKV_NW * 64, 2) void qkv_images_kernel(QkvImgParams
   auto stage = [&](int seg) {
     const float* src = P.wstream + (size_t)seg * QKV_SEG_FLOATS + lane * 4;
     const unsigned dst = buf0 + (unsigned)(seg & 1) * (QKV_SEG_FLOATS * 4u);
-    for (int p = wave; p < QKV_SEG_FLOATS / 256; p += QKV_NW)
-      glds16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + (unsigned)p * 1024u));
+    glds_segment(src, dst, QKV_SEG_FLOATS / 256, wave, QKV_NW);
   };
   stage(0);
 

@@ -34,6 +34,30 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_byte_addr
       : "memory");
 }
 
+// glds16 for FOUR consecutive pieces (see glds16_sv4 below: one M0 write, the instruction offset moves both addresses)
+__device__ __forceinline__ void glds16x4(const float* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+// A contiguous segment of `pieces` 1-KiB pieces copied by the `nw` waves of a workgroup: runs of four dealt round-robin (one M0
+// write each), the remainder piece by piece.  src_lane = segment + lane * 4 floats; wave / pieces wave-uniform.
+__device__ __forceinline__ void glds_segment(const float* src_lane, unsigned lds_byte_addr, int pieces, int wave, int nw) {
+  const int n_runs = pieces >> 2;
+  for (int r = wave; r < n_runs; r += nw) glds16x4(src_lane + r * 1024, __builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)r * 4096u));
+  for (int p = 4 * n_runs + wave; p < pieces; p += nw) glds16(src_lane + p * 256, __builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)p * 1024u));
+}
+
 // The same copy with a wave-uniform source base in a scalar register pair and the per-lane byte offset (lane * 16) in ONE
 // vector register that never changes: no per-piece vector address arithmetic.  (s_nop 4: a base that came through
 // v_readfirstlane is a VALU-written SGPR read by a memory instruction.)

@@ -43,6 +43,24 @@ __device__ __forceinline__ void wa_glds16(const float* gsrc, unsigned lds_byte_a
       : "memory");
 }
 
+// four consecutive 1-KiB pieces per M0 write: the instruction offset moves the global AND the LDS address of an LDS-DMA load
+// (split_f16.hpp: glds16_sv4; tools/exp/ubench/dma_issue.hip: 40-43 instead of 74-78 cycles of issue per request)
+__device__ __forceinline__ void wa_glds16x4(const float* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+
 // One K/V tile = 32 keys x 128 channels of each matrix = 2 x 16 KiB, copied as 32 pieces of
 // 1 KiB (one wave instruction = 2 token rows).  V keeps its natural row-major image.  K is
 // swizzled on the SOURCE side: the 16-byte column group c4 of LDS row `key` holds channels
@@ -777,12 +795,15 @@ __global__ __launch_bounds__(NQW * 64, 2) void window_attention_pre_kernel(
     const int ktn = kt + 1 < n_tiles ? kt + 1 : kt;
     const u32x4* img_next = img_win + (size_t)ktn * (WA_IMG_BYTES / 16) + lane;
     const unsigned lds_next = smem0 + (unsigned)(cur ^ 1) * WA_IMG_BYTES;
+    // (round 6) a wave copies a CONTIGUOUS range of the next image, 32 / NQW pieces, in runs of four per M0 write; the runs are
+    // spread over the tile's eight request slots (NQW = 4: slots 0 and 4)
 #define WA_SLOT(slot)                                                                        \
   do {                                                                                       \
-    _Pragma("unroll") for (int pp_ = 0; pp_ < PPS; ++pp_) {                                  \
-      const int piece = wave + NQW * ((slot)*PPS + pp_);                                     \
-      wa_glds16(reinterpret_cast<const float*>(img_next + piece * 64),                       \
-                __builtin_amdgcn_readfirstlane(lds_next + (unsigned)piece * 1024u));         \
+    constexpr int PW_ = 8 * PPS, EVERY_ = 8 / (PW_ / 4);                                     \
+    if ((slot) % EVERY_ == 0) {                                                              \
+      const int piece = wave * PW_ + 4 * ((slot) / EVERY_);                                  \
+      wa_glds16x4(reinterpret_cast<const float*>(img_next + piece * 64),                     \
+                  __builtin_amdgcn_readfirstlane(lds_next + (unsigned)piece * 1024u));       \
     }                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                       \
   } while (0)
