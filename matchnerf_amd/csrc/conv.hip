@@ -23,8 +23,20 @@
 #include "split_f16.hpp"
 
 #define CONV_NW 4
+#ifndef CONV_EXP
+#define CONV_EXP 0  // removal experiments (wrong results, meaningful times; tools/exp/conv_removal.sh): 1 no matrix instructions,
+#endif              // 2 no operand loads, 3 no operand split, 4 no weight requests / segment barriers, 5 no tap geometry
 #define CONV_BUF_BYTES 36864u  // one LDS weight buffer (36 KiB: six K16-steps x three 32-row blocks)
 
+#if CONV_EXP == 1
+__device__ __forceinline__ f32x16 conv_nomfma(f16x8 a, f16x8 b, f32x16 c) {
+  asm volatile("" : "+v"(a), "+v"(b));
+  return c;
+}
+#define CONV_MFMA conv_nomfma
+#else
+#define CONV_MFMA mfma16h
+#endif
 struct ConvParams {
   const float* in;
   const float* wstream;
@@ -106,6 +118,7 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   float vn[TPW][16];  // [tile][K16-step of the pair * 8 + j], as loaded: the padding mask is applied at the USE
   bool vok[TPW];      // (a select next to the load would make the wave wait for the data one iteration early)
   auto load_pair = [&]() {
+    if (CONV_EXP == 2) return;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const float* src = P.in + toff[t] + (long long)(32 * cpair) * P.sc;
@@ -117,14 +130,25 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
           vn[t][8 * u + 0] = a4.x; vn[t][8 * u + 1] = a4.y; vn[t][8 * u + 2] = a4.z; vn[t][8 * u + 3] = a4.w;
           vn[t][8 * u + 4] = b4.x; vn[t][8 * u + 5] = b4.y; vn[t][8 * u + 6] = b4.z; vn[t][8 * u + 7] = b4.w;
         } else {
+          // (round 6) one wave-uniform 64-bit base per channel (scalar adds) + this lane's 32-bit byte offset: the global load's
+          // scalar-base form, instead of a 64-bit vector address per load (16 x TPW x ~4 vector instructions per iteration:
+          // half of this kernel's vector instructions by the counters).  The host checks that the input is below 4 GiB.
+          typedef const char __attribute__((address_space(1)))* gchar_cptr;   // (explicitly GLOBAL: behind the asm below a generic
+          typedef const float __attribute__((address_space(1)))* gfloat_cptr;  //  pointer would be read with flat loads)
+          gchar_cptr cb = (gchar_cptr)(size_t)P.in + ((long long)(32 * cpair + 16 * u) * P.sc) * 4;
+          const unsigned lo = (unsigned)toff[t] * 4u;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) vn[t][8 * u + j] = src[(long long)(16 * u + j) * P.sc];
+          for (int j = 0; j < 8; ++j) {
+            gchar_cptr cj = cb + ((long long)j * P.sc) * 4;
+            asm volatile("" : "+s"(cj));  // (opaque and in scalar registers: hipcc otherwise re-associates to (base + lane) + channel)
+            vn[t][8 * u + j] = *(gfloat_cptr)(cj + (size_t)lo);
+          }
         }
       }
     }
     if (++cpair == cpairs) {
       cpair = 0;
-      if (++tap < P.ksize * P.ksize) tap_geometry();
+      if (++tap < P.ksize * P.ksize && CONV_EXP != 5) tap_geometry();
     }
   };
   tap_geometry();
@@ -142,7 +166,6 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
   int iter = 0;
   const int seg_iters = P.seg_steps >> 1;
   for (int seg = 0; seg < P.n_seg; ++seg) {
-    if (seg + 1 < P.n_seg) stage(seg + 1);
     const unsigned cur = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
     for (int it = 0; it < seg_iters; ++it, ++iter) {
       PartsH b[2][TPW];
@@ -153,8 +176,17 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
           float v8[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v8[j] = vok[t] ? vn[t][8 * u + j] : 0.0f;
+          if (CONV_EXP == 3) {
+            b[u][t].hi = __builtin_bit_cast(f16x8, (u32x4){__float_as_uint(v8[0]), __float_as_uint(v8[1]), __float_as_uint(v8[2]), __float_as_uint(v8[3])});
+            b[u][t].lo = __builtin_bit_cast(f16x8, (u32x4){__float_as_uint(v8[4]), __float_as_uint(v8[5]), __float_as_uint(v8[6]), __float_as_uint(v8[7])});
+          } else
           b[u][t] = split8h(v8, mult);
         }
+      // The next weight segment is requested HERE, behind the wait for this iteration's operands and in front of the next
+      // iteration's operand loads (round 6).  hipcc does not see the asm LDS-DMA: its `s_waitcnt vmcnt(0)` for the operands also
+      // waits for every request in flight - asked for at the top of the segment, the requests were waited for right away, once per
+      // segment; in this place they are older than the loads the next wait is for and arrive before them.
+      if (CONV_EXP != 4 && it == 0 && seg + 1 < P.n_seg) stage(seg + 1);
       if (iter + 1 < n_iter) load_pair();
       lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)(cur + (unsigned)(2 * it * NMB) * H16_UNIT_BYTES) + lane;
 #pragma unroll
@@ -165,13 +197,14 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
           const f16x8 ah = __builtin_bit_cast(f16x8, a[unit * 128]), al = __builtin_bit_cast(f16x8, a[unit * 128 + 64]);
           // the two pixel tiles alternate: no matrix instruction has the accumulator of its predecessor
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].lo, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = CONV_MFMA(ah, b[u][t].lo, acc[t][m]);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(al, b[u][t].hi, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = CONV_MFMA(al, b[u][t].hi, acc[t][m]);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t][m] = mfma16h(ah, b[u][t].hi, acc[t][m]);
+          for (int t = 0; t < TPW; ++t) acc[t][m] = CONV_MFMA(ah, b[u][t].hi, acc[t][m]);
         }
     }
+    if (CONV_EXP == 4) continue;
     segment_wait();   // this wave's pieces of the next segment (and its operand prefetch) have landed
     __syncthreads();  // ... everybody's; the current buffer is free
   }
@@ -326,6 +359,9 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
     p.sc = 1; p.sx = cv->c_in; p.sy = (long long)w_in * cv->c_in; p.si = (long long)h_in * w_in * cv->c_in;
   } else {
     p.sx = 1; p.sy = w_in; p.sc = (long long)h_in * w_in; p.si = (long long)h_in * w_in * cv->c_in;
+    // (the kernel addresses a lane's pixel with a 32-bit byte offset next to a scalar channel base)
+    MNERF_REQUIRE((long long)n_img * p.si * 4 < (1ll << 32), MNERF_E_UNSUPPORTED, "%s: an NCHW input of %lld bytes (built: below 4 GiB)", who,
+                  (long long)n_img * p.si * 4);
   }
   p.ew = cv->ew;
   const int nmb = cv->c_out / 32, n_steps = cv->ksize * cv->ksize * (cv->c_in / 16);
