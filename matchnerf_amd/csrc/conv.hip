@@ -37,7 +37,23 @@ __device__ __forceinline__ f32x16 conv_nomfma(f16x8 a, f16x8 b, f32x16 c) {
 #else
 #define CONV_MFMA mfma16h
 #endif
+#ifdef CONV_TIMELINE
+// debug build (tools/exp/conv_timeline.py): s_memtime stamps of wave 0 of a few workgroups at the phase boundaries of every
+// iteration: [workgroup slot][iteration][point]  0 top | 1 operands arrived + split | 2 next loads issued | 3 matrix instructions
+// issued | (last iteration of a segment) 4 weight requests landed | 5 behind the barrier
+#define CONV_TL_POINTS 6
+#define CONV_TL_ITERS 64
+#define CONV_TL_STAMP(k)                                                                                       \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    if (tl_out && iter < CONV_TL_ITERS) tl_out[iter * CONV_TL_POINTS + (k)] = __builtin_amdgcn_s_memtime();    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#else
+#define CONV_TL_STAMP(k) do {} while (0)
+#endif
 struct ConvParams {
+  unsigned long long* tl;  // timeline build only (NULL otherwise)
   const float* in;
   const float* wstream;
   const float* bias;
@@ -165,9 +181,15 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
 
   int iter = 0;
   const int seg_iters = P.seg_steps >> 1;
+#ifdef CONV_TIMELINE
+  // workgroups 0, 1, g/2, g/2 + 1 (two co-resident pairs), wave 0, lane 0
+  const int tl_slot = blockIdx.x < 2 ? (int)blockIdx.x : (blockIdx.x == gridDim.x / 2 ? 2 : (blockIdx.x == gridDim.x / 2 + 1 ? 3 : -1));
+  unsigned long long* tl_out = (P.tl && tl_slot >= 0 && tid == 0) ? P.tl + (size_t)tl_slot * CONV_TL_ITERS * CONV_TL_POINTS : nullptr;
+#endif
   for (int seg = 0; seg < P.n_seg; ++seg) {
     const unsigned cur = buf0 + (unsigned)(seg & 1) * CONV_BUF_BYTES;
     for (int it = 0; it < seg_iters; ++it, ++iter) {
+      CONV_TL_STAMP(0);
       PartsH b[2][TPW];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -186,8 +208,10 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
       // iteration's operand loads (round 6).  hipcc does not see the asm LDS-DMA: its `s_waitcnt vmcnt(0)` for the operands also
       // waits for every request in flight - asked for at the top of the segment, the requests were waited for right away, once per
       // segment; in this place they are older than the loads the next wait is for and arrive before them.
+      CONV_TL_STAMP(1);
       if (CONV_EXP != 4 && it == 0 && seg + 1 < P.n_seg) stage(seg + 1);
       if (iter + 1 < n_iter) load_pair();
+      CONV_TL_STAMP(2);
       lds_u32x4_cptr a = (lds_u32x4_cptr)(size_t)(cur + (unsigned)(2 * it * NMB) * H16_UNIT_BYTES) + lane;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -203,10 +227,19 @@ __global__ __launch_bounds__(CONV_NW * 64, 2) void conv_kernel(ConvParams P) {
 #pragma unroll
           for (int t = 0; t < TPW; ++t) acc[t][m] = CONV_MFMA(ah, b[u][t].hi, acc[t][m]);
         }
+      CONV_TL_STAMP(3);
     }
     if (CONV_EXP == 4) continue;
     segment_wait();   // this wave's pieces of the next segment (and its operand prefetch) have landed
+#ifdef CONV_TIMELINE
+    --iter;
+    CONV_TL_STAMP(4);
+#endif
     __syncthreads();  // ... everybody's; the current buffer is free
+#ifdef CONV_TIMELINE
+    CONV_TL_STAMP(5);
+    ++iter;
+#endif
   }
 
   // ---- epilogue: scale back, bias, LeakyReLU, largest magnitude, NCHW store (32 consecutive pixels per register)
@@ -341,6 +374,10 @@ extern "C" int mnerf_conv2d(const mnerf_conv* cv, const float* in, int32_t in_ch
   p.wstream = cv->wstream;
   p.bias = cv->bias;
   p.out = out;
+  p.tl = nullptr;
+#ifdef CONV_TIMELINE
+  if (const char* e = getenv("MNERF_CONV_TL")) p.tl = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+#endif
   p.in_absmax = in_absmax;
   p.out_absmax = out_absmax;
   p.add_up = add_bilinear2x;
