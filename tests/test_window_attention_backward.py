@@ -83,6 +83,44 @@ def test_backward_with_gradient_rows_over_24_binades(math, monkeypatch):
     assert worst["q_rows"] < 5e-6, worst
 
 
+@pytest.mark.parametrize("math", ["f16x3", "bf16x6"])
+def test_backward_degenerate_inputs(math, monkeypatch):
+    """Edge cases of the range management: a zero gradient (absmax 0: gains of an all-zero tensor), a gradient with ONE non-zero row
+    (every other query's row norm is 0), a one-hot softmax (scores scaled until P is 0 / 1) and operands at 1e-20 / 1e+18."""
+    from matchnerf_amd import hip
+    monkeypatch.setenv("MNERF_WA_BWD_MATH", math)
+    gen = torch.Generator().manual_seed(5)
+    b, h, w, splits, shifted, c = 1, 16, 24, 2, True, 128
+    n = h * w
+    mk = lambda s: torch.randn(b, n, c, generator=gen) * s
+
+    def run(q, k, v, g):
+        qg, kg, vg, gg = q.cuda(), k.cuda(), v.cuda(), g.cuda()
+        out = hip.window_attention(qg, kg, vg, h, w, splits, shifted)
+        got = hip.window_attention_backward(qg, kg, vg, out, gg, h, w, splits, shifted)
+        q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+        (O.window_attention(q64, k64, v64, h, w, splits, shifted) * g.double()).sum().backward()
+        return got, (q64.grad, k64.grad, v64.grad)
+
+    # zero gradient: exact zeros
+    got, _ = run(mk(0.6), mk(0.8), mk(1.0), torch.zeros(b, n, c))
+    assert all(torch.equal(t.cpu(), torch.zeros(b, n, c)) for t in got)
+    # one non-zero row
+    g = torch.zeros(b, n, c)
+    g[0, 77] = torch.randn(c, generator=gen)
+    got, ref = run(mk(0.6), mk(0.8), mk(1.0), g)
+    for a, r in zip(got, ref):
+        assert torch.isfinite(a).all() and float((a.cpu().double() - r).abs().max() / r.abs().max()) < 2e-5
+    # one-hot softmax
+    got, ref = run(mk(6.0), mk(8.0), mk(1.0), mk(1.0))
+    for a, r in zip(got, ref):
+        assert torch.isfinite(a).all() and float((a.cpu().double() - r).abs().max() / r.abs().max()) < 2e-5
+    # tiny and huge operands (fp32 products of the maxima stay finite)
+    got, ref = run(mk(0.6), mk(0.8), mk(1e-20), mk(1e18))
+    for a, r in zip(got, ref):
+        assert torch.isfinite(a).all() and float((a.cpu().double() - r).abs().max() / r.abs().max()) < 2e-5
+
+
 def test_autograd_bridge_uses_the_hip_backward(monkeypatch):
     """autograd.window_attention: HIP forward + HIP backward; the torch re-evaluation (MNERF_WA_BACKWARD=torch) agrees."""
     from matchnerf_amd import autograd as ag
