@@ -127,10 +127,12 @@ extern "C" int64_t mnerf_encoder_layer_backward_workspace_bytes(int32_t n_tokens
   return n_tokens < 0 ? -1 : (int64_t)n_tokens * EW_FLOATS * (int64_t)sizeof(float);
 }
 
-extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, const float* attn, const float* source,
-                                            const float* g_out, float* g_attn, float* g_source, int32_t n_tokens,
-                                            void* workspace, void* stream) {
-  const char* who = "mnerf_encoder_layer_backward";
+// z1_saved / m2_saved (both or neither; FFN layers): mlp.0's output before the GELU and mlp.2's output before norm2 as the training
+// forward left them (mnerf_encoder_block_save) - the three GEMMs that would re-evaluate them (2 x [N,1024] K = 128, [N,128] K = 1024:
+// 25 of the layer's 75 GFLOP at the DTU shape) are skipped
+static int encoder_layer_backward_impl(const char* who, const mnerf_encoder_layer_train* L, const float* attn, const float* source,
+                                       const float* g_out, const float* z1_saved, const float* m2_saved, float* g_attn,
+                                       float* g_source, int32_t n_tokens, void* workspace, void* stream) {
   MNERF_REQUIRE(L && attn && source && g_out && g_attn && g_source, MNERF_E_NULL, "%s: NULL argument", who);
   MNERF_REQUIRE(n_tokens >= 0, MNERF_E_RANGE, "%s: n_tokens=%d", who, n_tokens);
   if (n_tokens == 0) return MNERF_OK;
@@ -147,6 +149,7 @@ extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, 
   auto at = [&](int off) { return ws + (size_t)off * N; };
   float *m1 = at(EW_M1), *xh1 = at(EW_XH1), *n1 = at(EW_N1), *dn1 = at(EW_DN1), *m2 = at(EW_M2), *xh2 = at(EW_XH2), *dm2 = at(EW_DM2),
         *z1 = at(EW_Z1), *g1 = at(EW_G1), *dg = at(EW_DG), *rstd1 = at(EW_RSTD), *rstd2 = at(EW_RSTD) + N;
+  if (z1_saved) z1 = const_cast<float*>(z1_saved), m2 = const_cast<float*>(m2_saved);  // (read only from here on)
   const float eps = 1e-5f;  // nn.LayerNorm's default (transformer.py:136, 144)
 
   // ================= forward, everything kept
@@ -154,10 +157,12 @@ extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, 
   hipLaunchKernelGGL(eb_ln_fwd_kernel, dim3(eb_row_grid(N)), dim3(256), 0, st, m1, L->ln1_w, L->ln1_b, xh1, n1, rstd1, (long long)N, eps);
   const float* d_n1 = g_out;  // gradient of the norm1 output; without the FFN it is the layer's output gradient
   if (L->ffn) {
-    linear_fwd(st, source, EB_C, L->w_mlp0, 2 * EB_C, nullptr, z1, EB_H, N, EB_H, EB_C);                 // cat[source, message]:
-    linear_fwd(st, n1, EB_C, L->w_mlp0 + EB_C, 2 * EB_C, nullptr, z1, EB_H, N, EB_H, EB_C, true);        // two column halves
+    if (!z1_saved) {
+      linear_fwd(st, source, EB_C, L->w_mlp0, 2 * EB_C, nullptr, z1, EB_H, N, EB_H, EB_C);                 // cat[source, message]:
+      linear_fwd(st, n1, EB_C, L->w_mlp0 + EB_C, 2 * EB_C, nullptr, z1, EB_H, N, EB_H, EB_C, true);        // two column halves
+    }
     hipLaunchKernelGGL(eb_gelu_kernel, dim3(eb_grid(nH)), dim3(256), 0, st, nH, z1, g1);
-    linear_fwd(st, g1, EB_H, L->w_mlp2, EB_H, nullptr, m2, EB_C, N, EB_C, EB_H);
+    if (!z1_saved) linear_fwd(st, g1, EB_H, L->w_mlp2, EB_H, nullptr, m2, EB_C, N, EB_C, EB_H);
     hipLaunchKernelGGL(eb_ln_fwd_kernel, dim3(eb_row_grid(N)), dim3(256), 0, st, m2, L->ln2_w, L->ln2_b, xh2, (float*)nullptr, rstd2,
                        (long long)N, eps);
     // ================= backward: norm2, mlp.2, GELU, mlp.0
@@ -181,6 +186,23 @@ extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, 
   linear_bwd_weight(st, m1, EB_C, attn, EB_C, L->g_w_merge, EB_C, N, EB_C, EB_C);
   linear_bwd_data(st, m1, EB_C, L->w_merge, EB_C, g_attn, EB_C, N, EB_C, EB_C, false);
   return mnerf_check_launch(who);
+}
+
+extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, const float* attn, const float* source,
+                                            const float* g_out, float* g_attn, float* g_source, int32_t n_tokens,
+                                            void* workspace, void* stream) {
+  return encoder_layer_backward_impl("mnerf_encoder_layer_backward", L, attn, source, g_out, nullptr, nullptr, g_attn, g_source,
+                                     n_tokens, workspace, stream);
+}
+
+extern "C" int mnerf_encoder_layer_backward_saved(const mnerf_encoder_layer_train* L, const float* attn, const float* source,
+                                                  const float* g_out, const float* z1, const float* m2, float* g_attn,
+                                                  float* g_source, int32_t n_tokens, void* workspace, void* stream) {
+  const char* who = "mnerf_encoder_layer_backward_saved";
+  MNERF_REQUIRE(L && L->ffn, MNERF_E_UNSUPPORTED, "%s: a layer with an FFN is expected", who);
+  MNERF_REQUIRE(n_tokens == 0 || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
+                "%s: z1 / m2 NULL or not 16-byte aligned", who);
+  return encoder_layer_backward_impl(who, L, attn, source, g_out, z1, m2, g_attn, g_source, n_tokens, workspace, stream);
 }
 
 // q = x_q Wq^T, k = x_kv Wk^T, v = x_kv Wv^T  ->  g_xq = g_q Wq,  g_xkv = g_k Wk + g_v Wv,  dW* += g*^T x*

@@ -37,6 +37,9 @@ struct EbParams {
   int n_tokens;
   int ffn;
   int ew_merge, ew_w1, ew_w2;
+  // training forward (template SAVE): what the layer's backward would otherwise re-evaluate with three GEMMs -
+  float* save_z1;  // [n_tokens][1024] mlp.0's output before the GELU
+  float* save_m2;  // [n_tokens][128]  mlp.2's output before norm2
 };
 
 template <int NW>
@@ -99,7 +102,12 @@ __device__ __forceinline__ float eb_gelu(float x) {
   return 0.5f * x * (x >= 0.0f ? 2.0f - erfc_z : erfc_z);
 }
 
-template <int NW>
+// SAVE (round 6, the training forward of an FFN layer; the inference instance's code is unchanged): the pre-GELU hidden
+// activations and mlp.2's output are written out for mnerf_encoder_layer_backward_saved.  A chunk's 128 hidden units leave as 16
+// float4 per lane (registers 4 g .. 4 g + 3 of block m are four consecutive units).  Ordinary stores count in vmcnt next to the
+// weight requests and need not retire in order with them, so the partial waits of eb_wait_next are not safe while stores are in
+// flight: the segment that follows a chunk's stores ends with a full wait (one drained prefetch per chunk: +7 % on this instance).
+template <int NW, bool SAVE = false>
 __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
   extern __shared__ __attribute__((aligned(16))) float eb_smem[];
   const unsigned wbuf0_lds = __builtin_amdgcn_groupstaticsize();
@@ -145,6 +153,12 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
     eb_wait_next(seg);  \
     __syncthreads();    \
     ++seg;              \
+  } while (0)
+#define EB_END_DRAIN()                                   \
+  do {                                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+    __syncthreads();                                     \
+    ++seg;                                               \
   } while (0)
 
   // ---------------------------------------------------------------- merge: 128 -> 128 on the attention output
@@ -241,6 +255,17 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
         EB_END();
       }
       // GELU; the chunk's largest activation sets (or lowers) the operand gain of mlp.2
+      if constexpr (SAVE) {
+        if (tok_ok) {
+          float* zp = P.save_z1 + (size_t)tok * EB_HIDDEN + 128 * c + 4 * hl;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(zp + 32 * m + 8 * g) =
+                  make_float4(hd[m][4 * g + 0] * c1, hd[m][4 * g + 1] * c1, hd[m][4 * g + 2] * c1, hd[m][4 * g + 3] * c1);
+        }
+      }
       float gmax = 0.0f;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -269,7 +294,8 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
         EB_BEGIN();
         kblock_h<4>(y, EB_CUR, lane, hd[2 * sgi], mult2);
         kblock_h<4>(y, EB_CUR + 8 * H16_UNIT_BYTES, lane, hd[2 * sgi + 1], mult2);
-        EB_END();
+        if (SAVE && sgi == 0) EB_END_DRAIN();  // (the chunk's stores are in flight)
+        else EB_END();
       }
     }
     const float c2 = pow2i(-(P.ew_w2 + eg2));
@@ -277,11 +303,22 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[m][r] *= c2;
+    if constexpr (SAVE) {
+      if (tok_ok) {
+        float* mp = P.save_m2 + (size_t)tok * EB_C + 4 * hl;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(mp + 32 * m + 8 * g) = make_float4(y[m][4 * g + 0], y[m][4 * g + 1], y[m][4 * g + 2], y[m][4 * g + 3]);
+      }
+    }
     eb_layer_norm(y, ln_lds + 2 * EB_C, ln_lds + 3 * EB_C, hl);
   }
 #undef EB_CUR
 #undef EB_BEGIN
 #undef EB_END
+#undef EB_END_DRAIN
 
   // ---------------------------------------------------------------- out = source + message (accumulator layout: 16 float4)
   if (tok_ok) {
@@ -302,8 +339,8 @@ extern "C" int64_t mnerf_encoder_block_wstream_floats(int32_t ffn) {
   return (int64_t)(ffn ? 2 + EB_CHUNKS * 6 : 2) * EB_SEG_FLOATS;
 }
 
-extern "C" int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
-                                   int32_t n_tokens, void* stream) {
+static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out, float* save_z1,
+                              float* save_m2, int32_t n_tokens, void* stream) {
   MNERF_REQUIRE(blk, MNERF_E_NULL, "mnerf_encoder_block: blk is NULL");
   MNERF_REQUIRE(n_tokens >= 0, MNERF_E_RANGE, "mnerf_encoder_block: n_tokens=%d", n_tokens);
   if (n_tokens == 0) return MNERF_OK;
@@ -325,12 +362,36 @@ extern "C" int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* 
   p.ew_merge = blk->ew_merge;
   p.ew_w1 = blk->ew_w1;
   p.ew_w2 = blk->ew_w2;
+  p.save_z1 = save_z1;
+  p.save_m2 = save_m2;
   constexpr int NW = 4;
   const size_t lds = ((size_t)EB_NBUF * EB_SEG_FLOATS + 4 * EB_C) * sizeof(float);
   static std::atomic<unsigned long long> attr_set{0};
   if (mnerf_once_per_device(attr_set))
     (void)hipFuncSetAttribute((const void*)encoder_block_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = (n_tokens + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL(encoder_block_kernel<NW>, dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, p);
+  if (save_z1) {
+    static std::atomic<unsigned long long> attr_save{0};
+    if (mnerf_once_per_device(attr_save))
+      (void)hipFuncSetAttribute((const void*)encoder_block_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((encoder_block_kernel<NW, true>), dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(encoder_block_kernel<NW>, dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, p);
+  }
   return mnerf_check_launch("mnerf_encoder_block");
+}
+
+extern "C" int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
+                                   int32_t n_tokens, void* stream) {
+  return encoder_block_impl(blk, attn, source, out, nullptr, nullptr, n_tokens, stream);
+}
+
+// Training forward of an FFN layer: the same result bit for bit, and mlp.0's output before the GELU (z1 [n_tokens][1024]) and
+// mlp.2's output before norm2 (m2 [n_tokens][128]) written out for mnerf_encoder_layer_backward_saved.
+extern "C" int mnerf_encoder_block_save(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
+                                        float* z1, float* m2, int32_t n_tokens, void* stream) {
+  MNERF_REQUIRE(blk && blk->ffn, MNERF_E_UNSUPPORTED, "mnerf_encoder_block_save: a layer with an FFN is expected");
+  MNERF_REQUIRE(n_tokens == 0 || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
+                "mnerf_encoder_block_save: z1 / m2 NULL or not 16-byte aligned");
+  return encoder_block_impl(blk, attn, source, out, z1, m2, n_tokens, stream);
 }

@@ -31,7 +31,7 @@ EXPORTS = ("mnerf_abi_version", "mnerf_last_error", "mnerf_struct_size", "mnerf_
            "mnerf_render_chunk", "mnerf_render_chunk_fused", "mnerf_render_chunk_is_fused", "mnerf_render_takes_pose_table", "mnerf_window_attention",
            "mnerf_window_attention_presplit", "mnerf_window_attention_workspace_bytes", "mnerf_window_attention_backward", "mnerf_window_attention_backward_workspace_bytes", "mnerf_qkv_projection", "mnerf_qkv_wstream_floats", "mnerf_qkv_window_images", "mnerf_window_attention_images", "mnerf_instance_norm", "mnerf_instance_norm_backward", "mnerf_upsample_bilinear2x", "mnerf_upsample_bilinear2x_backward", "mnerf_conv2d", "mnerf_conv_wstream_floats", "mnerf_conv_stem", "mnerf_conv_stem_wstream_floats", "mnerf_absmax", "mnerf_conv2d_backward_data", "mnerf_conv2d_backward_weight", "mnerf_conv2d_backward_weight_workspace_bytes", "mnerf_conv2d_backward_weight_f16x3", "mnerf_conv2d_forward_f32", "mnerf_conv_stem_backward_weight", "mnerf_conv_stem_backward_weight_workspace_bytes", "mnerf_encoder_block", "mnerf_encoder_block_wstream_floats",
            "mnerf_encoder_layer_backward", "mnerf_encoder_layer_backward_workspace_bytes", "mnerf_qkv_backward", "mnerf_debug_gemm",
-           "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats")
+           "mnerf_window_attention_presplit_stats", "mnerf_window_attention_backward_stats", "mnerf_encoder_block_save", "mnerf_encoder_layer_backward_saved")
 
 
 class MnerfError(RuntimeError):
@@ -790,11 +790,12 @@ def window_attention_images(q, workspace, h, w, num_splits, shifted, out=None, s
     return out
 
 
-def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None):
+def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None, saved=None):
     """Backward of everything after the attention in a transformer layer (mnerf_encoder_layer_backward).  ``layer``: the
     TransformerLayer module (merge / norm1 / mlp / norm2 parameters are read in torch's layouts); attn, source, g_out [N,128];
     ``grads``: dict parameter tensor -> gradient tensor to ACCUMULATE into (a missing entry skips that parameter).
-    -> (g_attn, g_source) [N,128]."""
+    ``saved``: (z1 [N,1024], m2 [N,128]) as ``encoder_block(..., save=True)`` returned them (mnerf_encoder_layer_backward_saved: the
+    three GEMMs that would re-evaluate them are skipped).  -> (g_attn, g_source) [N,128]."""
     import torch
     lib = load()
     for t, name in ((attn, "attn"), (source, "source"), (g_out, "g_out")):
@@ -825,6 +826,17 @@ def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None):
     g_attn, g_source = torch.empty_like(source), torch.empty_like(source)
     ws = _grow_only_workspace(source.device, int(lib.mnerf_encoder_layer_backward_workspace_bytes(n)) // 4, stream)
     with _on(source.device, stream) as st:
+        if saved is not None:
+            z1, m2 = saved
+            _f32c(z1, "z1"), _f32c(m2, "m2")
+            if tuple(z1.shape) != (n, 1024) or tuple(m2.shape) != (n, 128):
+                raise MnerfError(f"encoder_layer_backward: saved z1 {tuple(z1.shape)}, m2 {tuple(m2.shape)}")
+            fn = lib.mnerf_encoder_layer_backward_saved
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] * 8 + [C.c_int32, C.c_void_p, C.c_void_p]
+            check(fn(C.addressof(L), attn.data_ptr(), source.data_ptr(), g_out.data_ptr(), z1.data_ptr(), m2.data_ptr(),
+                     g_attn.data_ptr(), g_source.data_ptr(), n, ws.data_ptr(), st), "mnerf_encoder_layer_backward_saved")
+            return g_attn, g_source
         check(lib.mnerf_encoder_layer_backward(C.byref(L), _ptr(attn), _ptr(source), _ptr(g_out), _ptr(g_attn), _ptr(g_source), n,
                                                C.c_void_p(ws.data_ptr()), st), "mnerf_encoder_layer_backward")
     return g_attn, g_source
@@ -1088,9 +1100,11 @@ def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.
     return out
 
 
-def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None):
+def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None, save=False):
     """K7 (gmflow/transformer.py:176-185): out = source + norm2(mlp(cat[source, norm1(merge(attn))])) (or without the
-    FFN).  attn, source [N,128]; wstream / ews from gmflow.pack_encoder_block; ln [4,128]."""
+    FFN).  attn, source [N,128]; wstream / ews from gmflow.pack_encoder_block; ln [4,128].  ``save`` (FFN layers, training):
+    -> (out, z1 [N,1024], m2 [N,128]) - mlp.0's output before the GELU and mlp.2's output before norm2 for
+    ``encoder_layer_backward(..., saved=(z1, m2))`` (mnerf_encoder_block_save)."""
     import torch
     lib = load()
     _f32c(attn, "attn"), _f32c(source, "source"), _f32c(wstream, "wstream"), _f32c(ln, "ln")
@@ -1103,5 +1117,15 @@ def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None):
     blk.wstream, blk.wstream_floats, blk.ln = wstream.data_ptr(), wstream.numel(), ln.data_ptr()
     blk.ffn, blk.ew_merge, blk.ew_w1, blk.ew_w2 = int(bool(ffn)), int(ews[0]), int(ews[1]), int(ews[2])
     with _on(source.device, stream) as st:
+        if save:
+            if not ffn:
+                raise MnerfError("encoder_block: save=True needs a layer with an FFN")
+            z1, m2 = torch.empty(n, 1024, device=source.device), torch.empty(n, 128, device=source.device)
+            fn = lib.mnerf_encoder_block_save
+            fn.restype = C.c_int
+            fn.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
+            check(fn(C.addressof(blk), attn.data_ptr(), source.data_ptr(), out.data_ptr(), z1.data_ptr(), m2.data_ptr(), n, st),
+                  "mnerf_encoder_block_save")
+            return out, z1, m2
         check(lib.mnerf_encoder_block(C.byref(blk), _ptr(attn), _ptr(source), _ptr(out), n, st), "mnerf_encoder_block")
     return out

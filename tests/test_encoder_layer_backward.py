@@ -27,8 +27,12 @@ def _layer(no_ffn, seed):
     (False, 4, 8, 12, 1, False, True),     # one window = the whole map
     (False, 6, 32, 40, 2, True, True),     # 6 sequences, 320-token windows
 ])
-def test_transformer_layer_gradients_match_float64_autograd(no_ffn, b, h, w, splits, shifted, cross):
+@pytest.mark.parametrize("enc_save", ["1", "0"])
+def test_transformer_layer_gradients_match_float64_autograd(no_ffn, b, h, w, splits, shifted, cross, enc_save, monkeypatch):
+    """enc_save: "1" (default) - an FFN layer's training forward keeps mlp.0's pre-GELU output and mlp.2's output
+    (mnerf_encoder_block_save -> mnerf_encoder_layer_backward_saved); "0" - the backward re-evaluates them"""
     from matchnerf_amd import autograd as ag
+    monkeypatch.setenv("MNERF_ENC_SAVE", enc_save)
     layer = _layer(no_ffn, seed=h + w + splits)
     gen = torch.Generator().manual_seed(7 * h + w)
     n = h * w
@@ -55,6 +59,27 @@ def test_transformer_layer_gradients_match_float64_autograd(no_ffn, b, h, w, spl
         worst[k] = float((p.grad.cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-30))
     print({k: f"{v:.1e}" for k, v in worst.items()})
     assert all(v < 5e-5 for v in worst.values()), worst
+
+
+def test_encoder_block_save_is_the_inference_kernel_plus_two_tensors():
+    """mnerf_encoder_block_save: `out` bit-identical to mnerf_encoder_block's; z1 = mlp.0(cat[source, norm1(merge(attn))]) and
+    m2 = mlp.2(GELU(z1)) against float64 (ragged token count: the last workgroup's dead lanes write nothing)."""
+    from matchnerf_amd import hip
+    layer = _layer(False, seed=3)
+    gen = torch.Generator().manual_seed(11)
+    n = 1000
+    attn, source = torch.randn(n, 128, generator=gen).cuda(), torch.randn(n, 128, generator=gen).cuda()
+    bws, ln, bews = layer._packed_block(attn.device)
+    out0 = hip.encoder_block(attn, source, bws, ln, True, bews)
+    out1, z1, m2 = hip.encoder_block(attn, source, bws, ln, True, bews, save=True)
+    assert torch.equal(out0, out1)
+    a64, s64 = attn.double().cpu(), source.double().cpu()
+    P = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    msg = torch.nn.functional.layer_norm(a64 @ P["merge.weight"].t(), (128,), P["norm1.weight"], P["norm1.bias"])
+    z_ref = torch.cat([s64, msg], -1) @ P["mlp.0.weight"].t()
+    m_ref = torch.nn.functional.gelu(z_ref) @ P["mlp.2.weight"].t()
+    assert float((z1.cpu().double() - z_ref).abs().max() / z_ref.abs().max()) < 5e-6
+    assert float((m2.cpu().double() - m_ref).abs().max() / m_ref.abs().max()) < 5e-6
 
 
 def test_hip_and_torch_backward_of_the_encoder_agree(monkeypatch):

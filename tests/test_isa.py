@@ -34,7 +34,7 @@ def test_scan_sees_the_kernels(kernels):
     names = list(kernels)
     for want in ("decoder_pp_kernel<64, 2, false, 3>", "decoder_pp_kernel<64, 2, true, 3>", "decoder_pp_kernel<64, 4, false, 3>", "decoder_pp_kernel<64, 2, false, 1>", "decoder_pp_kernel<128, 2, true, 3>", "decoder_kernel<4, 64, 2, 0>", "decoder_kernel<4, 64, 2, 1>", "decoder_kernel<8, 256, 2, 0>",
                  "cost_volume_lean_kernel<8, false, false>", "cost_volume_lean_kernel<8, false, true>", "cost_volume_backward_kernel", "conv_kernel<4, 2, false>",
-                 "window_attention_pre_kernel<4, false>", "window_attention_pre_kernel<4, true>", "encoder_block_kernel<4>", "qkv_images_kernel", "ray_head_kernel",
+                 "window_attention_pre_kernel<4, false>", "window_attention_pre_kernel<4, true>", "encoder_block_kernel<4, false>", "encoder_block_kernel<4, true>", "qkv_images_kernel", "ray_head_kernel",
                  "wa_bwd_dq_kernel", "wa_bwd_dkv_kernel", "wa_bwd_dq_split_kernel<false, 3>", "wa_bwd_dq_split_kernel<true, 2>", "wa_bwd_dkv_split_kernel<0, 2>", "wa_bwd_dkv_split_kernel<1, 2>", "wa_bwd_dkv_split_kernel<1, 3>",
                  "gemm_b6_kernel<true, true, 128, 128>", "cost_volume_backward_walk_kernel", "eb_ln_bwd_kernel"):
         hit = [n for n in names if want in n]
