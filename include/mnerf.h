@@ -553,14 +553,15 @@ int64_t mnerf_encoder_layer_backward_workspace_bytes(int32_t n_tokens);
 int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* layer, const float* attn, const float* source,
                                  const float* g_out, float* g_attn, float* g_source, int32_t n_tokens, void* workspace,
                                  void* stream);
-/* Training pair of an FFN layer (round 6): the forward that also writes mlp.0's output before the GELU (z1 [n_tokens,1024]) and
- * mlp.2's output before norm2 (m2 [n_tokens,128]) - `out` equal to mnerf_encoder_block's bit for bit -, and the backward that reads
- * them instead of re-evaluating them (three of its eleven matrix products).  Same workspace. */
-int mnerf_encoder_block_save(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out, float* z1,
-                             float* m2, int32_t n_tokens, void* stream);
+/* Training pair (round 6): the forward that also writes the pre-norm activations - merge's output before norm1 (m1 [n_tokens,128])
+ * and, for a layer with an FFN, mlp.0's output before the GELU (z1 [n_tokens,1024]) and mlp.2's output before norm2 (m2
+ * [n_tokens,128]; NULL without an FFN); `out` equal to mnerf_encoder_block's bit for bit -, and the backward that reads them instead
+ * of re-evaluating them (four of an FFN layer's eleven matrix products).  Same workspace. */
+int mnerf_encoder_block_save(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out, float* m1,
+                             float* z1, float* m2, int32_t n_tokens, void* stream);
 int mnerf_encoder_layer_backward_saved(const mnerf_encoder_layer_train* layer, const float* attn, const float* source,
-                                       const float* g_out, const float* z1, const float* m2, float* g_attn, float* g_source,
-                                       int32_t n_tokens, void* workspace, void* stream);
+                                       const float* g_out, const float* m1, const float* z1, const float* m2, float* g_attn,
+                                       float* g_source, int32_t n_tokens, void* workspace, void* stream);
 /* q = x_q Wq^T, k = x_kv Wk^T, v = x_kv Wv^T (mnerf_qkv_projection without the batch swap: the caller passes the key / value
  * source it used):  g_xq = g_q Wq and g_xkv = g_k Wk + g_v Wv are OVERWRITTEN ([n_tokens,128], two different buffers),
  * gw_* [128,128] += g_*^T x_* (NULL: skipped). */

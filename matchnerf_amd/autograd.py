@@ -125,12 +125,13 @@ class _TransformerLayerFn(torch.autograd.Function):
         stats = torch.empty(2, b * n, device=source.device) if _forward_stats() else None
         attn = hip.window_attention(q, k, v, h, w, splits, shifted, row_stats=stats)
         bws, ln, bews = layer._packed_block(source.device)
-        # FFN layers keep mlp.0's pre-GELU output and mlp.2's output (MNERF_ENC_SAVE=0: the backward re-evaluates them with three GEMMs)
-        ctx.saved_ffn = None
-        if not layer.no_ffn and os.environ.get("MNERF_ENC_SAVE", "1") != "0":
-            out, z1, m2 = hip.encoder_block(attn.reshape(b * n, c), source.reshape(b * n, c), bws, ln, True, bews, save=True)
+        # the layer keeps its pre-norm activations - merge's output and, with an FFN, mlp.0's pre-GELU output and mlp.2's output
+        # (MNERF_ENC_SAVE=0: the backward re-evaluates them with one / four GEMMs)
+        ctx.saved_pre = None
+        if os.environ.get("MNERF_ENC_SAVE", "1") != "0":
+            out, m1, z1, m2 = hip.encoder_block(attn.reshape(b * n, c), source.reshape(b * n, c), bws, ln, not layer.no_ffn, bews, save=True)
             out = out.reshape(b, n, c)
-            ctx.saved_ffn = (z1, m2)
+            ctx.saved_pre = (m1, z1, m2)
         else:
             out = hip.encoder_block(attn.reshape(b * n, c), source.reshape(b * n, c), bws, ln, not layer.no_ffn, bews).reshape(b, n, c)
         ctx.save_for_backward(source, target, q, k, v, attn)
@@ -153,7 +154,7 @@ class _TransformerLayerFn(torch.autograd.Function):
         for p in need:
             grads[p] = flat_grads[off:off + p.numel()].view_as(p)
             off += p.numel()
-        g_attn, g_source = hip.encoder_layer_backward(layer, flat(attn), flat(source), flat(g_out.contiguous()), grads, saved=ctx.saved_ffn)
+        g_attn, g_source = hip.encoder_layer_backward(layer, flat(attn), flat(source), flat(g_out.contiguous()), grads, saved=ctx.saved_pre)
         gq, gk, gv = hip.window_attention_backward(q, k, v, attn, g_attn.reshape(b, n, c), h, w, splits, shifted, row_stats=ctx.stats)
         wq, wk, wv = layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight
         g_xq, g_xkv = hip.qkv_backward(wq, wk, wv, flat(source), flat(target), flat(gq), flat(gk), flat(gv),

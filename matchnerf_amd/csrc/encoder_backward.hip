@@ -127,12 +127,12 @@ extern "C" int64_t mnerf_encoder_layer_backward_workspace_bytes(int32_t n_tokens
   return n_tokens < 0 ? -1 : (int64_t)n_tokens * EW_FLOATS * (int64_t)sizeof(float);
 }
 
-// z1_saved / m2_saved (both or neither; FFN layers): mlp.0's output before the GELU and mlp.2's output before norm2 as the training
-// forward left them (mnerf_encoder_block_save) - the three GEMMs that would re-evaluate them (2 x [N,1024] K = 128, [N,128] K = 1024:
-// 25 of the layer's 75 GFLOP at the DTU shape) are skipped
+// m1_saved, z1_saved / m2_saved (all or none; the latter two for FFN layers): merge's output before norm1, mlp.0's output before the
+// GELU and mlp.2's output before norm2 as the training forward left them (mnerf_encoder_block_save) - the GEMMs that would
+// re-evaluate them (merge; 2 x [N,1024] K = 128, [N,128] K = 1024: 26 of an FFN layer's 76 GFLOP at the DTU shape) are skipped
 static int encoder_layer_backward_impl(const char* who, const mnerf_encoder_layer_train* L, const float* attn, const float* source,
-                                       const float* g_out, const float* z1_saved, const float* m2_saved, float* g_attn,
-                                       float* g_source, int32_t n_tokens, void* workspace, void* stream) {
+                                       const float* g_out, const float* m1_saved, const float* z1_saved, const float* m2_saved,
+                                       float* g_attn, float* g_source, int32_t n_tokens, void* workspace, void* stream) {
   MNERF_REQUIRE(L && attn && source && g_out && g_attn && g_source, MNERF_E_NULL, "%s: NULL argument", who);
   MNERF_REQUIRE(n_tokens >= 0, MNERF_E_RANGE, "%s: n_tokens=%d", who, n_tokens);
   if (n_tokens == 0) return MNERF_OK;
@@ -153,8 +153,10 @@ static int encoder_layer_backward_impl(const char* who, const mnerf_encoder_laye
   const float eps = 1e-5f;  // nn.LayerNorm's default (transformer.py:136, 144)
 
   // ================= forward, everything kept
-  linear_fwd(st, attn, EB_C, L->w_merge, EB_C, nullptr, m1, EB_C, N, EB_C, EB_C);
-  hipLaunchKernelGGL(eb_ln_fwd_kernel, dim3(eb_row_grid(N)), dim3(256), 0, st, m1, L->ln1_w, L->ln1_b, xh1, n1, rstd1, (long long)N, eps);
+  if (!m1_saved) linear_fwd(st, attn, EB_C, L->w_merge, EB_C, nullptr, m1, EB_C, N, EB_C, EB_C);
+  // (the workspace's m1 later takes the gradient of the merge output: the saved tensor is only read)
+  hipLaunchKernelGGL(eb_ln_fwd_kernel, dim3(eb_row_grid(N)), dim3(256), 0, st, m1_saved ? m1_saved : m1, L->ln1_w, L->ln1_b, xh1, n1, rstd1,
+                     (long long)N, eps);
   const float* d_n1 = g_out;  // gradient of the norm1 output; without the FFN it is the layer's output gradient
   if (L->ffn) {
     if (!z1_saved) {
@@ -191,18 +193,20 @@ static int encoder_layer_backward_impl(const char* who, const mnerf_encoder_laye
 extern "C" int mnerf_encoder_layer_backward(const mnerf_encoder_layer_train* L, const float* attn, const float* source,
                                             const float* g_out, float* g_attn, float* g_source, int32_t n_tokens,
                                             void* workspace, void* stream) {
-  return encoder_layer_backward_impl("mnerf_encoder_layer_backward", L, attn, source, g_out, nullptr, nullptr, g_attn, g_source,
-                                     n_tokens, workspace, stream);
+  return encoder_layer_backward_impl("mnerf_encoder_layer_backward", L, attn, source, g_out, nullptr, nullptr, nullptr, g_attn,
+                                     g_source, n_tokens, workspace, stream);
 }
 
 extern "C" int mnerf_encoder_layer_backward_saved(const mnerf_encoder_layer_train* L, const float* attn, const float* source,
-                                                  const float* g_out, const float* z1, const float* m2, float* g_attn,
-                                                  float* g_source, int32_t n_tokens, void* workspace, void* stream) {
+                                                  const float* g_out, const float* m1, const float* z1, const float* m2,
+                                                  float* g_attn, float* g_source, int32_t n_tokens, void* workspace, void* stream) {
   const char* who = "mnerf_encoder_layer_backward_saved";
-  MNERF_REQUIRE(L && L->ffn, MNERF_E_UNSUPPORTED, "%s: a layer with an FFN is expected", who);
-  MNERF_REQUIRE(n_tokens == 0 || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
+  MNERF_REQUIRE(L, MNERF_E_NULL, "%s: NULL argument", who);
+  MNERF_REQUIRE(n_tokens == 0 || (m1 && mnerf_aligned16(m1)), MNERF_E_NULL, "%s: m1 NULL or not 16-byte aligned", who);
+  MNERF_REQUIRE(n_tokens == 0 || !L->ffn || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
                 "%s: z1 / m2 NULL or not 16-byte aligned", who);
-  return encoder_layer_backward_impl(who, L, attn, source, g_out, z1, m2, g_attn, g_source, n_tokens, workspace, stream);
+  return encoder_layer_backward_impl(who, L, attn, source, g_out, m1, L->ffn ? z1 : nullptr, L->ffn ? m2 : nullptr, g_attn, g_source,
+                                     n_tokens, workspace, stream);
 }
 
 // q = x_q Wq^T, k = x_kv Wk^T, v = x_kv Wv^T  ->  g_xq = g_q Wq,  g_xkv = g_k Wk + g_v Wv,  dW* += g*^T x*

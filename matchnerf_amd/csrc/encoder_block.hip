@@ -38,8 +38,9 @@ struct EbParams {
   int ffn;
   int ew_merge, ew_w1, ew_w2;
   // training forward (template SAVE): what the layer's backward would otherwise re-evaluate with three GEMMs -
-  float* save_z1;  // [n_tokens][1024] mlp.0's output before the GELU
-  float* save_m2;  // [n_tokens][128]  mlp.2's output before norm2
+  float* save_m1;  // [n_tokens][128]  merge's output before norm1
+  float* save_z1;  // [n_tokens][1024] mlp.0's output before the GELU       (FFN layers)
+  float* save_m2;  // [n_tokens][128]  mlp.2's output before norm2          (FFN layers)
 };
 
 template <int NW>
@@ -197,6 +198,19 @@ __global__ __launch_bounds__(NW * 64, 1) void encoder_block_kernel(EbParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) m1[m][r] *= cm;
   }
+  if constexpr (SAVE) {
+    // (no weight request is waited for by count between here and the first FFN segment's end other than through EB_END's partial
+    // wait: the stores go out BEHIND the drain below)
+    if (tok_ok) {
+      float* mp = P.save_m1 + (size_t)tok * EB_C + 4 * hl;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(mp + 32 * m + 8 * g) = make_float4(m1[m][4 * g + 0], m1[m][4 * g + 1], m1[m][4 * g + 2], m1[m][4 * g + 3]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stores and weight requests do not retire in order with each other
+  }
   eb_layer_norm(m1, ln_lds, ln_lds + EB_C, hl);
 
   f32x16 y[4];
@@ -339,8 +353,8 @@ extern "C" int64_t mnerf_encoder_block_wstream_floats(int32_t ffn) {
   return (int64_t)(ffn ? 2 + EB_CHUNKS * 6 : 2) * EB_SEG_FLOATS;
 }
 
-static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out, float* save_z1,
-                              float* save_m2, int32_t n_tokens, void* stream) {
+static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out, float* save_m1,
+                              float* save_z1, float* save_m2, int32_t n_tokens, void* stream) {
   MNERF_REQUIRE(blk, MNERF_E_NULL, "mnerf_encoder_block: blk is NULL");
   MNERF_REQUIRE(n_tokens >= 0, MNERF_E_RANGE, "mnerf_encoder_block: n_tokens=%d", n_tokens);
   if (n_tokens == 0) return MNERF_OK;
@@ -362,6 +376,7 @@ static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn,
   p.ew_merge = blk->ew_merge;
   p.ew_w1 = blk->ew_w1;
   p.ew_w2 = blk->ew_w2;
+  p.save_m1 = save_m1;
   p.save_z1 = save_z1;
   p.save_m2 = save_m2;
   constexpr int NW = 4;
@@ -370,7 +385,7 @@ static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn,
   if (mnerf_once_per_device(attr_set))
     (void)hipFuncSetAttribute((const void*)encoder_block_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = (n_tokens + NW * 32 - 1) / (NW * 32);
-  if (save_z1) {
+  if (save_m1) {
     static std::atomic<unsigned long long> attr_save{0};
     if (mnerf_once_per_device(attr_save))
       (void)hipFuncSetAttribute((const void*)encoder_block_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -383,15 +398,18 @@ static int encoder_block_impl(const mnerf_encoder_layer* blk, const float* attn,
 
 extern "C" int mnerf_encoder_block(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
                                    int32_t n_tokens, void* stream) {
-  return encoder_block_impl(blk, attn, source, out, nullptr, nullptr, n_tokens, stream);
+  return encoder_block_impl(blk, attn, source, out, nullptr, nullptr, nullptr, n_tokens, stream);
 }
 
-// Training forward of an FFN layer: the same result bit for bit, and mlp.0's output before the GELU (z1 [n_tokens][1024]) and
-// mlp.2's output before norm2 (m2 [n_tokens][128]) written out for mnerf_encoder_layer_backward_saved.
+// Training forward: the same result bit for bit, and the pre-norm activations written out for mnerf_encoder_layer_backward_saved:
+// merge's output before norm1 (m1 [n_tokens][128]) and, for a layer with an FFN, mlp.0's output before the GELU (z1
+// [n_tokens][1024]) and mlp.2's output before norm2 (m2 [n_tokens][128]; both NULL for a layer without).
 extern "C" int mnerf_encoder_block_save(const mnerf_encoder_layer* blk, const float* attn, const float* source, float* out,
-                                        float* z1, float* m2, int32_t n_tokens, void* stream) {
-  MNERF_REQUIRE(blk && blk->ffn, MNERF_E_UNSUPPORTED, "mnerf_encoder_block_save: a layer with an FFN is expected");
-  MNERF_REQUIRE(n_tokens == 0 || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
+                                        float* m1, float* z1, float* m2, int32_t n_tokens, void* stream) {
+  MNERF_REQUIRE(blk, MNERF_E_NULL, "mnerf_encoder_block_save: blk is NULL");
+  if (n_tokens == 0) return MNERF_OK;
+  MNERF_REQUIRE(m1 && mnerf_aligned16(m1), MNERF_E_NULL, "mnerf_encoder_block_save: m1 NULL or not 16-byte aligned");
+  MNERF_REQUIRE(!blk->ffn || (z1 && m2 && mnerf_aligned16(z1) && mnerf_aligned16(m2)), MNERF_E_NULL,
                 "mnerf_encoder_block_save: z1 / m2 NULL or not 16-byte aligned");
-  return encoder_block_impl(blk, attn, source, out, z1, m2, n_tokens, stream);
+  return encoder_block_impl(blk, attn, source, out, m1, blk->ffn ? z1 : nullptr, blk->ffn ? m2 : nullptr, n_tokens, stream);
 }

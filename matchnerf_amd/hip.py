@@ -794,8 +794,8 @@ def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None, saved
     """Backward of everything after the attention in a transformer layer (mnerf_encoder_layer_backward).  ``layer``: the
     TransformerLayer module (merge / norm1 / mlp / norm2 parameters are read in torch's layouts); attn, source, g_out [N,128];
     ``grads``: dict parameter tensor -> gradient tensor to ACCUMULATE into (a missing entry skips that parameter).
-    ``saved``: (z1 [N,1024], m2 [N,128]) as ``encoder_block(..., save=True)`` returned them (mnerf_encoder_layer_backward_saved: the
-    three GEMMs that would re-evaluate them are skipped).  -> (g_attn, g_source) [N,128]."""
+    ``saved``: (m1 [N,128], z1 [N,1024], m2 [N,128]) as ``encoder_block(..., save=True)`` returned them (z1, m2 None without an FFN;
+    mnerf_encoder_layer_backward_saved: the GEMMs that would re-evaluate them are skipped).  -> (g_attn, g_source) [N,128]."""
     import torch
     lib = load()
     for t, name in ((attn, "attn"), (source, "source"), (g_out, "g_out")):
@@ -827,14 +827,19 @@ def encoder_layer_backward(layer, attn, source, g_out, grads, stream=None, saved
     ws = _grow_only_workspace(source.device, int(lib.mnerf_encoder_layer_backward_workspace_bytes(n)) // 4, stream)
     with _on(source.device, stream) as st:
         if saved is not None:
-            z1, m2 = saved
-            _f32c(z1, "z1"), _f32c(m2, "m2")
-            if tuple(z1.shape) != (n, 1024) or tuple(m2.shape) != (n, 128):
-                raise MnerfError(f"encoder_layer_backward: saved z1 {tuple(z1.shape)}, m2 {tuple(m2.shape)}")
+            m1, z1, m2 = saved
+            _f32c(m1, "m1")
+            if tuple(m1.shape) != (n, 128):
+                raise MnerfError(f"encoder_layer_backward: saved m1 {tuple(m1.shape)}")
+            if not layer.no_ffn:
+                _f32c(z1, "z1"), _f32c(m2, "m2")
+                if tuple(z1.shape) != (n, 1024) or tuple(m2.shape) != (n, 128):
+                    raise MnerfError(f"encoder_layer_backward: saved z1 {tuple(z1.shape)}, m2 {tuple(m2.shape)}")
             fn = lib.mnerf_encoder_layer_backward_saved
             fn.restype = C.c_int
-            fn.argtypes = [C.c_void_p] * 8 + [C.c_int32, C.c_void_p, C.c_void_p]
-            check(fn(C.addressof(L), attn.data_ptr(), source.data_ptr(), g_out.data_ptr(), z1.data_ptr(), m2.data_ptr(),
+            fn.argtypes = [C.c_void_p] * 9 + [C.c_int32, C.c_void_p, C.c_void_p]
+            check(fn(C.addressof(L), attn.data_ptr(), source.data_ptr(), g_out.data_ptr(), m1.data_ptr(),
+                     None if layer.no_ffn else z1.data_ptr(), None if layer.no_ffn else m2.data_ptr(),
                      g_attn.data_ptr(), g_source.data_ptr(), n, ws.data_ptr(), st), "mnerf_encoder_layer_backward_saved")
             return g_attn, g_source
         check(lib.mnerf_encoder_layer_backward(C.byref(L), _ptr(attn), _ptr(source), _ptr(g_out), _ptr(g_attn), _ptr(g_source), n,
@@ -1102,9 +1107,9 @@ def conv2d(x, wstream, bias, c_in, c_out, ksize, stride, ew, in_absmax, leaky=1.
 
 def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None, save=False):
     """K7 (gmflow/transformer.py:176-185): out = source + norm2(mlp(cat[source, norm1(merge(attn))])) (or without the
-    FFN).  attn, source [N,128]; wstream / ews from gmflow.pack_encoder_block; ln [4,128].  ``save`` (FFN layers, training):
-    -> (out, z1 [N,1024], m2 [N,128]) - mlp.0's output before the GELU and mlp.2's output before norm2 for
-    ``encoder_layer_backward(..., saved=(z1, m2))`` (mnerf_encoder_block_save)."""
+    FFN).  attn, source [N,128]; wstream / ews from gmflow.pack_encoder_block; ln [4,128].  ``save`` (training): -> (out, m1 [N,128], z1 [N,1024],
+    m2 [N,128]) - merge's output before norm1 and, with an FFN (None otherwise), mlp.0's output before the GELU and mlp.2's output
+    before norm2 - for ``encoder_layer_backward(..., saved=(m1, z1, m2))`` (mnerf_encoder_block_save)."""
     import torch
     lib = load()
     _f32c(attn, "attn"), _f32c(source, "source"), _f32c(wstream, "wstream"), _f32c(ln, "ln")
@@ -1118,14 +1123,14 @@ def encoder_block(attn, source, wstream, ln, ffn, ews, out=None, stream=None, sa
     blk.ffn, blk.ew_merge, blk.ew_w1, blk.ew_w2 = int(bool(ffn)), int(ews[0]), int(ews[1]), int(ews[2])
     with _on(source.device, stream) as st:
         if save:
-            if not ffn:
-                raise MnerfError("encoder_block: save=True needs a layer with an FFN")
-            z1, m2 = torch.empty(n, 1024, device=source.device), torch.empty(n, 128, device=source.device)
+            m1 = torch.empty(n, 128, device=source.device)
+            z1 = torch.empty(n, 1024, device=source.device) if ffn else None
+            m2 = torch.empty(n, 128, device=source.device) if ffn else None
             fn = lib.mnerf_encoder_block_save
             fn.restype = C.c_int
-            fn.argtypes = [C.c_void_p] * 6 + [C.c_int32, C.c_void_p]
-            check(fn(C.addressof(blk), attn.data_ptr(), source.data_ptr(), out.data_ptr(), z1.data_ptr(), m2.data_ptr(), n, st),
-                  "mnerf_encoder_block_save")
-            return out, z1, m2
+            fn.argtypes = [C.c_void_p] * 7 + [C.c_int32, C.c_void_p]
+            check(fn(C.addressof(blk), attn.data_ptr(), source.data_ptr(), out.data_ptr(), m1.data_ptr(),
+                     z1.data_ptr() if ffn else None, m2.data_ptr() if ffn else None, n, st), "mnerf_encoder_block_save")
+            return out, m1, z1, m2
         check(lib.mnerf_encoder_block(C.byref(blk), _ptr(attn), _ptr(source), _ptr(out), n, st), "mnerf_encoder_block")
     return out

@@ -71,15 +71,24 @@ def test_encoder_block_save_is_the_inference_kernel_plus_two_tensors():
     attn, source = torch.randn(n, 128, generator=gen).cuda(), torch.randn(n, 128, generator=gen).cuda()
     bws, ln, bews = layer._packed_block(attn.device)
     out0 = hip.encoder_block(attn, source, bws, ln, True, bews)
-    out1, z1, m2 = hip.encoder_block(attn, source, bws, ln, True, bews, save=True)
+    out1, m1, z1, m2 = hip.encoder_block(attn, source, bws, ln, True, bews, save=True)
     assert torch.equal(out0, out1)
     a64, s64 = attn.double().cpu(), source.double().cpu()
     P = {k: v.detach().double().cpu() for k, v in layer.named_parameters()}
+    assert float((m1.cpu().double() - a64 @ P["merge.weight"].t()).abs().max()) < 5e-6 * float((a64 @ P["merge.weight"].t()).abs().max())
     msg = torch.nn.functional.layer_norm(a64 @ P["merge.weight"].t(), (128,), P["norm1.weight"], P["norm1.bias"])
     z_ref = torch.cat([s64, msg], -1) @ P["mlp.0.weight"].t()
     m_ref = torch.nn.functional.gelu(z_ref) @ P["mlp.2.weight"].t()
     assert float((z1.cpu().double() - z_ref).abs().max() / z_ref.abs().max()) < 5e-6
     assert float((m2.cpu().double() - m_ref).abs().max() / m_ref.abs().max()) < 5e-6
+    # a layer without an FFN keeps merge's output only
+    layer2 = _layer(True, seed=4)
+    bws2, ln2, bews2 = layer2._packed_block(attn.device)
+    o0 = hip.encoder_block(attn, source, bws2, ln2, False, bews2)
+    o1, m1b, z1b, m2b = hip.encoder_block(attn, source, bws2, ln2, False, bews2, save=True)
+    assert torch.equal(o0, o1) and z1b is None and m2b is None
+    ref = a64 @ layer2.merge.weight.detach().double().cpu().t()
+    assert float((m1b.cpu().double() - ref).abs().max() / ref.abs().max()) < 5e-6
 
 
 def test_hip_and_torch_backward_of_the_encoder_agree(monkeypatch):
