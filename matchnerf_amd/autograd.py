@@ -110,9 +110,12 @@ def window_attention(q, k, v, h, w, splits, shifted):
 class _TransformerLayerFn(torch.autograd.Function):
     """TransformerLayer.forward (gmflow/transformer.py:147-185) as one autograd node.  Forward: the inference kernels
     (mnerf_qkv_projection, K6 with its row statistics, K7 = mnerf_encoder_block).  Backward, all HIP:
-    mnerf_encoder_layer_backward (the chain after the attention, re-evaluated in fp32 from the saved attention output and layer
-    input; GEMMs split-bf16 or, MNERF_GEMM_MATH=f32, exact) -> mnerf_window_attention_backward_stats -> mnerf_qkv_backward.
-    Saved: the layer's two inputs, q, k, v, the attention output (six [B, h*w, 128] tensors) and two floats per token."""
+    mnerf_encoder_layer_backward_saved (the chain after the attention from the pre-norm activations the training forward kept:
+    merge's output and, with an FFN, mlp.0's pre-GELU output and mlp.2's output; norms and GELU re-evaluated; MNERF_ENC_SAVE=0:
+    everything re-evaluated from the attention output and the layer input; GEMMs split-bf16 or, MNERF_GEMM_MATH=f32, exact)
+    -> mnerf_window_attention_backward_stats -> mnerf_qkv_backward.
+    Saved: the layer's two inputs, q, k, v, the attention output (six [B, h*w, 128] tensors), two floats per token and the
+    pre-norm activations ([B h w, 128] + with an FFN [B h w, 1024] + [B h w, 128])."""
 
     @staticmethod
     def forward(ctx, source, target, geom, layer, *params):
