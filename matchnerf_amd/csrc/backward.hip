@@ -252,14 +252,17 @@ __global__ __launch_bounds__(256) void cost_volume_backward_kernel(mnerf_scene s
 __global__ __launch_bounds__(256, CVB_WALK_WAVES) void cost_volume_backward_walk_kernel(mnerf_scene sc, mnerf_rays R, int cond_stride,
                                                                         const float* __restrict__ g_cond,
                                                                         float* __restrict__ g_feat0,
-                                                                        float* __restrict__ g_feat1) {
+                                                                        float* __restrict__ g_feat1, int n_seg) {
+  // n_seg (round 6): a ray's samples in n_seg consecutive segments, one slot each.  A training batch is 1 024 rays: 6 144 (ray,
+  // pair, scale) items = 1.5 workgroups per CU, each a serial walk over all samples; with segments of >= 8 samples the launch
+  // fills the chip (a cell that straddles a segment boundary goes out twice - the atomics were unordered before, too).
   constexpr int CPL = 8, LPS = FEAT_C / CPL;
   const int sub = threadIdx.x % LPS;
   const int S = R.n_samples, V = sc.n_views, NS = sc.n_scales;
   const int P = V * (V - 1) / 2;
   const float wm1 = (float)(R.width - 1), hm1 = (float)(R.height - 1);
   const float inv_pairs = 1.0f / (float)P;
-  const long long total = (long long)R.n_rays * P * NS;
+  const long long total = (long long)R.n_rays * P * NS * n_seg;
   const long long slots = ((long long)gridDim.x * blockDim.x) / LPS;
   const long long rounds = (total + slots - 1) / slots;  // every lane takes part in the DPP reductions of every round
   const long long slot0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPS;
@@ -267,8 +270,11 @@ __global__ __launch_bounds__(256, CVB_WALK_WAVES) void cost_volume_backward_walk
     const long long it_raw = slot0 + rnd * slots;
     const bool live = it_raw < total;
     const long long it = live ? it_raw : total - 1;
-    const int ray = (int)(it / (P * NS));
-    const int rem = (int)(it - (long long)ray * (P * NS));
+    const long long it_rps = it / n_seg;
+    const int seg = (int)(it - it_rps * n_seg);
+    const int j_begin = (int)(((long long)S * seg) / n_seg), j_end = (int)(((long long)S * (seg + 1)) / n_seg);
+    const int ray = (int)(it_rps / (P * NS));
+    const int rem = (int)(it_rps - (long long)ray * (P * NS));
     const int p = rem / NS, s = rem - p * NS;
     int va = 0, vb = p;  // pair p = (va, vb), va < vb, lexicographic order
     while (vb >= V - 1 - va) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, CVB_WALK_WAVES) void cost_volume_backward_walk
           acc[t][c] = 0.0f;
         }
     };
-    for (int j = 0; j < S; ++j) {
+    for (int j = j_begin; j < j_end; ++j) {
       const float d = sample_depth(R, ray, j);
       float px, py, pz;
       ray_point(g, d, px, py, pz);
@@ -384,11 +390,20 @@ extern "C" int mnerf_cost_volume_backward(const mnerf_scene* scene, const mnerf_
     return (e && e[0] == '0') ? 0 : 1;
   }();
   if (walk) {
-    const long long items = (long long)rays->n_rays * (scene->n_views * (scene->n_views - 1) / 2) * scene->n_scales;
-    long long blocks = (items + 15) / 16;  // 16 slots per 256-thread workgroup, one (ray, pair, scale) each
+    long long items = (long long)rays->n_rays * (scene->n_views * (scene->n_views - 1) / 2) * scene->n_scales;
+    // segments per ray (MNERF_CV_BWD_SEGS overrides): enough items for ~6 workgroups per CU, segments of at least 8 samples
+    static const int seg_env = [] {
+      const char* e = getenv("MNERF_CV_BWD_SEGS");
+      return e ? atoi(e) : 0;
+    }();
+    int n_seg = seg_env > 0 ? seg_env : (int)((16 * 1536 + items - 1) / items);  // (1 024 rays x 3 pairs x 2 scales: 4 segments; measured 1.07 / 1.06 / 0.93 / 0.97 ms for 1 / 2 / 4 / 8)
+    if (n_seg > rays->n_samples / 8) n_seg = rays->n_samples / 8;
+    if (n_seg < 1) n_seg = 1;
+    items *= n_seg;
+    long long blocks = (items + 15) / 16;  // 16 slots per 256-thread workgroup, one (ray, pair, scale, segment) each
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(cost_volume_backward_walk_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *scene, *rays,
-                       cond_stride, g_cond, g_feat0, g_feat1);
+                       cond_stride, g_cond, g_feat0, g_feat1, n_seg);
     return mnerf_check_launch("mnerf_cost_volume_backward");
   }
   const long long total = (long long)rays->n_rays * rays->n_samples;
